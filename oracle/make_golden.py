@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own CPU code -- TEST INFRASTRUCTURE.
+
+Runs oracle/_ref/sph_ref (the reference's SPH/particleSystem.cpp compiled where
+it lies, OMP mode; see oracle/Makefile and oracle/ref_harness.cpp) on seeded
+inputs produced by gpufluidsimulator_amd.ic and stores inputs + expected outputs
+as small fixtures.  Only runs in the build container (needs /root/reference to
+have built oracle/_ref); the fixtures are what travels.
+
+    python oracle/make_golden.py            # all fixtures
+    python oracle/make_golden.py c1 random  # a subset
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gpufluidsimulator_amd import ic  # noqa: E402
+from oracle import refio  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def _phase_arrays(recs, steps):
+    out = {}
+    for s in steps:
+        for k in ("zindex", "order", "sorted_z", "bcells", "bprime", "dens", "force", "coll", "state", "hpos"):
+            out[f"s{s}_{k}"] = recs[(k, s)]
+    return out
+
+
+def gen_c1():
+    """BASELINE config 1: 16^3 lattice, box 4, grid 64^3, dt 5e-7, 100 steps."""
+    cfg = ic.CONFIGS["C1"]
+    for tag, jitter in (("c1_lattice", False), ("c1_jitter", True)):
+        pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=jitter)
+        # phases for the first two steps (exact checks need the reference's tie order)
+        recs, _ = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, 2, phases=True)
+        arrs = _phase_arrays(recs, (1, 2))
+        # the long run: states after 1, 10, 100 steps
+        recs, stats = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, 100, dump_steps=(1, 10, 100))
+        for s in (1, 10, 100):
+            arrs[f"state_{s}"] = recs[("state", s)]
+        _save(tag, pos=pos, vel=vel, box=np.float32(cfg["box"]), grid=np.uint32(cfg["grid"]),
+              dt=np.float32(ic.DEFAULT_DT), **arrs)
+
+
+def gen_random():
+    """Reference-style CONFIG_RANDOM box (particleSystem.cpp:880-905) made nastier:
+    random velocities, a clump of 150 particles inside one cell (more than
+    GRID_COMPACT_WIDTH = 32, so B' gets several chunks per cell), particles
+    sitting on the walls, and an empty cell 0."""
+    box, grid, n = (2.0, 2.0, 2.0), 32, 6000
+    pos, vel = ic.random_box(n, box, speed=40.0, fill=0.45)
+    pos[:, 0] += np.float32(0.3)            # keep Morton cell 0 empty
+    rng = np.random.default_rng(7)
+    clump = slice(0, 150)
+    pos[clump] = (np.float32([-0.5, -0.5, -0.5]) + rng.uniform(0.002, 0.060, (150, 3))).astype(np.float32)
+    wall = slice(150, 250)                     # on / beyond the walls: clamp + damping branch
+    pos[wall, 1] = np.float32(-1.0) + rng.uniform(-1e-6, 3e-5, 100).astype(np.float32)
+    vel[wall, 1] = np.float32(-30.0)
+    pos[250:300, 0] = np.float32(1.0) - np.float32(1e-5)
+    vel[250:300, 0] = np.float32(25.0)
+    dt = np.float32(2e-6)
+    recs, _ = refio.run_ref(pos, vel, box, grid, dt, 4, phases=True)
+    arrs = _phase_arrays(recs, (1, 2, 3, 4))
+    _save("random_clump", pos=pos, vel=vel, box=np.float32(box), grid=np.uint32((grid,) * 3), dt=dt, **arrs)
+
+
+def gen_c2():
+    """BASELINE config 2: 64^3 lattice, box 8, grid 128^3.  3 steps; stores every
+    61st particle plus float64 checksums of the full arrays."""
+    cfg = ic.CONFIGS["C2"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
+    recs, stats = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, 3, dump_steps=(1, 2, 3))
+    print("c2 reference timing:", stats)
+    sample = np.arange(0, pos.shape[0], 61, dtype=np.int64)
+    arrs = {}
+    for s in (1, 2, 3):
+        st = recs[("state", s)]
+        arrs[f"state_{s}_sample"] = st[sample]
+        arrs[f"state_{s}_sum"] = st.astype(np.float64).sum(axis=0)
+        arrs[f"state_{s}_abs_sum"] = np.abs(st.astype(np.float64)).sum(axis=0)
+    _save("c2_sample", sample=sample, box=np.float32(cfg["box"]), grid=np.uint32(cfg["grid"]),
+          lattice=np.uint32(cfg["lattice"]), dt=np.float32(ic.DEFAULT_DT), **arrs)
+
+
+def gen_morton():
+    """Known answers for coord2zIndex / zIndex2coord from the reference run itself:
+    zindex of every C1 particle together with the cell coordinates the hash must
+    produce (positions are exact lattice points, so the coordinates are known)."""
+    cfg = ic.CONFIGS["C1"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=False)
+    recs, _ = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, 1, phases=True)
+    _save("morton_c1", pos=pos, zindex=recs[("zindex", 1)], box=np.float32(cfg["box"]), grid=np.uint32(cfg["grid"]))
+
+
+GENS = {"c1": gen_c1, "random": gen_random, "c2": gen_c2, "morton": gen_morton}
+
+if __name__ == "__main__":
+    if not refio.available():
+        sys.exit("oracle/_ref/sph_ref missing: run `make -C oracle ref` in the build container")
+    for name in (sys.argv[1:] or list(GENS)):
+        GENS[name]()
