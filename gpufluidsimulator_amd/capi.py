@@ -1,0 +1,292 @@
+"""ctypes binding of the C ABI in include/sph_hip.h (libsph_hip.so).
+
+This is plumbing only: every compute call lands in the hand-written HIP library.  There is
+no CPU fallback -- a missing library or a missing gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsph_hip.so")
+
+PHASES = ("z-index", "sort", "b-grid", "dens", "force", "collision", "integrate")
+HALO_RECORD_FLOATS = 8
+
+
+class SphError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """`sph_params` of include/sph_hip.h."""
+    _fields_ = [("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("grid", C.c_uint32 * 3),
+                ("h", C.c_float), ("mass", C.c_float), ("rest_density", C.c_float), ("gas_constant", C.c_float),
+                ("viscosity", C.c_float), ("gravity_y", C.c_float), ("wall_eps", C.c_float),
+                ("wall_damping", C.c_float), ("restitution", C.c_float), ("collision_param", C.c_float),
+                ("particle_radius", C.c_float)]
+
+
+# name -> (restype, argtypes); also the list the symbol-export test walks
+_P = C.c_void_p
+_U32 = C.c_uint32
+SIGNATURES = {
+    "sph_abi_version": (C.c_int, []),
+    "sph_last_error": (C.c_char_p, []),
+    "sph_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sph_default_params": (None, [C.POINTER(Params), C.POINTER(C.c_float), C.POINTER(_U32)]),
+    "sph_grid_dim_for_edge": (_U32, [C.c_float, C.c_float]),
+    "sph_create": (C.c_int, [C.POINTER(_P), C.c_int, _U32, C.POINTER(Params)]),
+    "sph_create_slab": (C.c_int, [C.POINTER(_P), C.c_int, _U32, C.POINTER(Params), _U32, _U32, _U32]),
+    "sph_destroy": (None, [_P]),
+    "sph_set_stream": (C.c_int, [_P, _P]),
+    "sph_set_params": (C.c_int, [_P, C.POINTER(Params)]),
+    "sph_get_params": (C.c_int, [_P, C.POINTER(Params)]),
+    "sph_sync": (C.c_int, [_P]),
+    "sph_num_particles": (_U32, [_P]),
+    "sph_capacity": (_U32, [_P]),
+    "sph_upload": (C.c_int, [_P, _U32, _P, _P, _P]),
+    "sph_download": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
+    "sph_download_forces": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
+    "sph_positions_dev": (C.c_int, [_P, C.POINTER(_P)]),
+    "sph_download_positions4": (C.c_int, [_P, _P]),
+    "sph_get_keys": (C.c_int, [_P, _P]),
+    "sph_get_order": (C.c_int, [_P, _P]),
+    "sph_get_cell_range": (C.c_int, [_P, _U32, C.POINTER(_U32), C.POINTER(_U32)]),
+    "sph_get_cells": (C.c_int, [_P, _U32, _P, _P, _P]),
+    "sph_cell_key": (_U32, [_P, _U32, _U32, _U32]),
+    "sph_hash": (C.c_int, [_P]),
+    "sph_sort": (C.c_int, [_P]),
+    "sph_build_cells": (C.c_int, [_P]),
+    "sph_density": (C.c_int, [_P]),
+    "sph_force": (C.c_int, [_P]),
+    "sph_collide": (C.c_int, [_P]),
+    "sph_integrate": (C.c_int, [_P, C.c_float]),
+    "sph_step": (C.c_int, [_P, C.c_float, _U32]),
+    "sph_step_phased": (C.c_int, [_P, C.c_float, _U32]),
+    "sph_timing_enable": (C.c_int, [_P, C.c_int]),
+    "sph_timing_get": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U32)]),
+    "sph_timing_reset": (C.c_int, [_P]),
+    "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
+    "sph_migrants_pack": (C.c_int, [_P, C.POINTER(_P), _U32]),
+    "sph_migrants_append": (C.c_int, [_P, _P, _U32]),
+    "sph_halo_count": (C.c_int, [_P, C.POINTER(_U32)]),
+    "sph_halo_pack": (C.c_int, [_P, C.POINTER(_P), _U32]),
+    "sph_halo_unpack": (C.c_int, [_P, _P, _U32, _P, _U32]),
+    "sph_halo_pack_density": (C.c_int, [_P, C.POINTER(_P), _U32]),
+    "sph_halo_unpack_density": (C.c_int, [_P, _P, _P]),
+    "sph_layer_histogram": (C.c_int, [_P, _P, _U32]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libsph_hip.so (building it first if it is missing) and type its entry points."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            from . import build as _b
+            _b.build()
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if lib.sph_abi_version() != 1:
+            raise SphError("libsph_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise SphError(f"libsph_hip error {rc}: {load().sph_last_error().decode()}")
+    return rc
+
+
+def default_params(box, grid) -> Params:
+    p = Params()
+    load().sph_default_params(C.byref(p), (C.c_float * 3)(*[float(b) for b in box]),
+                              (C.c_uint32 * 3)(*[int(g) for g in grid]))
+    return p
+
+
+def device_count():
+    flag = C.c_int(0)
+    n = load().sph_device_count(C.byref(flag))
+    return n, bool(flag.value)
+
+
+def _f32(a, cols):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a.reshape(-1, cols)
+
+
+class Context:
+    """One `sph_ctx`: the device state of a particle system (or of one z-slab of it)."""
+
+    def __init__(self, capacity, box=None, grid=None, params: Params | None = None, device=0,
+                 slab=None, ghost_capacity=0):
+        self.L = load()
+        self.params = params if params is not None else default_params(box, grid)
+        h = _P()
+        if slab is None:
+            _check(self.L.sph_create(C.byref(h), device, int(capacity), C.byref(self.params)))
+        else:
+            _check(self.L.sph_create_slab(C.byref(h), device, int(capacity), C.byref(self.params),
+                                          int(slab[0]), int(slab[1]), int(ghost_capacity)))
+        self.h = h
+        self.capacity = int(capacity)
+        self.index_base = 0
+        self.index_count = int(capacity)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- state ---------------------------------------------------------------------------------
+    @property
+    def n(self):
+        return int(self.L.sph_num_particles(self.h))
+
+    def set_stream(self, stream_handle):
+        _check(self.L.sph_set_stream(self.h, _P(stream_handle)))
+
+    def set_params(self, params: Params):
+        _check(self.L.sph_set_params(self.h, C.byref(params)))
+        self.params = params
+
+    def upload(self, pos, vel=None, index=None):
+        pos = _f32(pos, 3)
+        n = pos.shape[0]
+        vel = _f32(vel, 3) if vel is not None else None
+        idx = np.ascontiguousarray(index, dtype=np.uint32) if index is not None else None
+        _check(self.L.sph_upload(self.h, n, pos.ctypes.data, vel.ctypes.data if vel is not None else None,
+                                 idx.ctypes.data if idx is not None else None))
+
+    def download(self, index_base=0, count=None, want=("pos", "vel", "density", "pressure")):
+        """State by creation index; rows of particles this context does not own stay NaN."""
+        count = self.index_count if count is None else count
+        out = {}
+        for k in want:
+            out[k] = np.full((count, 3) if k in ("pos", "vel") else (count,), np.nan, dtype=np.float32)
+        ptr = lambda k: out[k].ctypes.data if k in out else None
+        _check(self.L.sph_download(self.h, int(index_base), ptr("pos"), ptr("vel"), ptr("density"), ptr("pressure")))
+        return out
+
+    def download_forces(self, index_base=0, count=None, force=True, collision=True):
+        count = self.index_count if count is None else count
+        out = {}
+        if force:
+            out["fpress"] = np.full((count, 3), np.nan, dtype=np.float32)
+            out["fvisc"] = np.full((count, 3), np.nan, dtype=np.float32)
+        if collision:
+            out["dv"] = np.full((count, 3), np.nan, dtype=np.float32)
+            out["count"] = np.full((count,), -1, dtype=np.int32)
+        ptr = lambda k: out[k].ctypes.data if k in out else None
+        _check(self.L.sph_download_forces(self.h, int(index_base), ptr("fpress"), ptr("fvisc"), ptr("dv"), ptr("count")))
+        return out
+
+    def positions4(self):
+        out = np.empty((self.capacity, 4), dtype=np.float32)
+        _check(self.L.sph_download_positions4(self.h, out.ctypes.data))
+        return out
+
+    def positions_dev(self):
+        p = _P()
+        _check(self.L.sph_positions_dev(self.h, C.byref(p)))
+        return p.value
+
+    def keys(self):
+        out = np.empty(self.n, dtype=np.uint32)
+        _check(self.L.sph_get_keys(self.h, out.ctypes.data))
+        return out
+
+    def order(self):
+        out = np.empty(self.n, dtype=np.uint32)
+        _check(self.L.sph_get_order(self.h, out.ctypes.data))
+        return out
+
+    def cells(self, max_cells=None):
+        max_cells = self.n + 16 if max_cells is None else max_cells
+        k = np.empty(max_cells, dtype=np.uint32)
+        s = np.empty(max_cells, dtype=np.uint32)
+        c = np.empty(max_cells, dtype=np.uint32)
+        m = _check(self.L.sph_get_cells(self.h, max_cells, k.ctypes.data, s.ctypes.data, c.ctypes.data))
+        m = min(m, max_cells)
+        return k[:m], s[:m], c[:m]
+
+    def cell_key(self, x, y, z):
+        return int(self.L.sph_cell_key(self.h, int(x), int(y), int(z)))
+
+    # -- phases ---------------------------------------------------------------------------------
+    def hash(self): _check(self.L.sph_hash(self.h))
+    def sort(self): _check(self.L.sph_sort(self.h))
+    def build_cells(self): _check(self.L.sph_build_cells(self.h))
+    def density(self): _check(self.L.sph_density(self.h))
+    def force(self): _check(self.L.sph_force(self.h))
+    def collide(self): _check(self.L.sph_collide(self.h))
+    def integrate(self, dt): _check(self.L.sph_integrate(self.h, float(dt)))
+    def step(self, dt, n=1): _check(self.L.sph_step(self.h, float(dt), int(n)))
+    def step_phased(self, dt, n=1): _check(self.L.sph_step_phased(self.h, float(dt), int(n)))
+    def sync(self): _check(self.L.sph_sync(self.h))
+
+    # -- timing ---------------------------------------------------------------------------------
+    def timing(self, on=True): _check(self.L.sph_timing_enable(self.h, 1 if on else 0))
+    def timing_reset(self): _check(self.L.sph_timing_reset(self.h))
+
+    def timing_get(self):
+        ms = (C.c_float * len(PHASES))()
+        steps = _U32(0)
+        _check(self.L.sph_timing_get(self.h, ms, C.byref(steps)))
+        return {PHASES[k]: float(ms[k]) for k in range(len(PHASES))}, int(steps.value)
+
+    # -- slab halo (device pointers: ints, e.g. torch.Tensor.data_ptr()) ----------------------------
+    def _pair(self, fn, *a):
+        cnt = (_U32 * 2)()
+        _check(fn(self.h, cnt, *a))
+        return int(cnt[0]), int(cnt[1])
+
+    def migrants_count(self): return self._pair(self.L.sph_migrants_count)
+    def halo_count(self): return self._pair(self.L.sph_halo_count)
+
+    def migrants_pack(self, buf_lo, buf_hi, capacity):
+        _check(self.L.sph_migrants_pack(self.h, (_P * 2)(buf_lo, buf_hi), int(capacity)))
+
+    def migrants_append(self, buf, n):
+        _check(self.L.sph_migrants_append(self.h, _P(buf), int(n)))
+
+    def halo_pack(self, buf_lo, buf_hi, capacity):
+        _check(self.L.sph_halo_pack(self.h, (_P * 2)(buf_lo, buf_hi), int(capacity)))
+
+    def halo_unpack(self, lo, n_lo, hi, n_hi):
+        _check(self.L.sph_halo_unpack(self.h, _P(lo), int(n_lo), _P(hi), int(n_hi)))
+
+    def halo_pack_density(self, buf_lo, buf_hi, capacity):
+        _check(self.L.sph_halo_pack_density(self.h, (_P * 2)(buf_lo, buf_hi), int(capacity)))
+
+    def halo_unpack_density(self, lo, hi):
+        _check(self.L.sph_halo_unpack_density(self.h, _P(lo), _P(hi)))
+
+    def layer_histogram(self):
+        n = int(self.params.grid[2])
+        out = np.zeros(n, dtype=np.uint32)
+        _check(self.L.sph_layer_histogram(self.h, out.ctypes.data, n))
+        return out

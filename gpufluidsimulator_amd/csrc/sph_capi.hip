@@ -1,0 +1,618 @@
+// sph_capi.hip -- the C ABI of include/sph_hip.h: context lifetime, state transfer, phase
+// sequencing and device timing.  Host code only; kernels live in sph_sort.hip / sph_pairs.hip /
+// sph_halo.hip.
+#include "sph_common.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace sph {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    return SPH_E_DEVICE;
+}
+
+static uint32_t next_pow2(uint32_t x) {   // nextPow2, SPH/particleSystem.h:34-43
+    x--; x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 16; x++;
+    return x;
+}
+
+static int derive(sph_ctx* c, const sph_params* p, uint32_t z_lo, uint32_t z_hi) {
+    for (int a = 0; a < 3; a++) {
+        SPH_REQUIRE(p->grid[a] >= 1 && p->grid[a] <= 4096, SPH_E_INVALID, "grid[%d] = %u out of range", a, p->grid[a]);
+        SPH_REQUIRE(p->box_max[a] > p->box_min[a], SPH_E_INVALID, "empty box on axis %d", a);
+    }
+    SPH_REQUIRE(p->h > 0.f && p->mass > 0.f && p->particle_radius > 0.f, SPH_E_INVALID, "h, mass, radius must be > 0");
+    SPH_REQUIRE(z_lo < z_hi && z_hi <= p->grid[2], SPH_E_INVALID, "bad slab [%u, %u) of %u layers", z_lo, z_hi, p->grid[2]);
+    c->params = *p;
+    GridDesc& g = c->grid;
+    for (int a = 0; a < 3; a++) {
+        g.box_min[a] = p->box_min[a];
+        g.box_dims[a] = p->box_max[a] - p->box_min[a];
+        g.g[a] = p->grid[a];
+        g.gf[a] = (float)p->grid[a];
+    }
+    g.z_lo = z_lo;
+    g.zl = z_hi - z_lo + 2;
+    uint64_t nc = (uint64_t)g.g[0] * g.g[1] * g.zl;
+    SPH_REQUIRE(nc < (1ull << 32), SPH_E_INVALID, "cell table too large (%llu cells)", (unsigned long long)nc);
+    g.ncells = (uint32_t)nc;
+    c->key_bits = 1;
+    while (c->key_bits < 32 && (1ull << c->key_bits) < nc) c->key_bits++;
+
+    // constants exactly as the reference's float expressions evaluate (particleSystem.cu:30,41,42)
+    const float PI_F = 3.141592654f;
+    Phys& ph = c->phys;
+    ph.h = p->h;
+    ph.h2 = p->h * p->h;
+    ph.mass = p->mass;
+    ph.rest_density = p->rest_density;
+    ph.gas_constant = p->gas_constant;
+    const float poly6 = 315.f / (65.f * PI_F * powf(p->h, 9.f));   // note the 65, as in the reference
+    const float spiky = 45.f / (PI_F * powf(p->h, 6.f));
+    ph.poly6_mass = p->mass * poly6;
+    ph.spiky_half_mass = p->mass * spiky * 0.5f;
+    ph.visc_coef = (p->viscosity * p->mass) * spiky;
+    ph.gravity_y = p->gravity_y;
+    ph.wall_eps = p->wall_eps;
+    ph.wall_damping = p->wall_damping;
+    const double cd = (double)p->collision_param * 2.0 * (double)p->particle_radius;
+    ph.coll_dist2 = (float)(cd * cd);
+    ph.coll_mass = p->mass * (1.f + p->restitution);
+    for (int a = 0; a < 3; a++) { ph.box_min[a] = p->box_min[a]; ph.box_max[a] = p->box_max[a]; }
+    return SPH_OK;
+}
+
+template <class T>
+static int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return SPH_E_NOMEM;
+    }
+    return SPH_OK;
+}
+
+static void free_all(sph_ctx* c) {
+    hipFree(c->posi); hipFree(c->velr); hipFree(c->posi2); hipFree(c->velr2); hipFree(c->keyS); hipFree(c->dp);
+    hipFree(c->fpress); hipFree(c->fvisc); hipFree(c->dvel); hipFree(c->pos_out); hipFree(c->cells);
+    hipFree(c->k0); hipFree(c->v0); hipFree(c->k1); hipFree(c->v1); hipFree(c->hist); hipFree(c->digit_tot);
+    hipFree(c->d_scratch);
+    if (c->h_scratch) hipHostFree(c->h_scratch);
+}
+
+static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_params* p, uint32_t z_lo, uint32_t z_hi,
+                       uint32_t gcap, bool slab) {
+    SPH_REQUIRE(out && p, SPH_E_INVALID, "null argument");
+    *out = nullptr;
+    SPH_REQUIRE(capacity > 0 && (uint64_t)capacity + 2ull * gcap < (1ull << 31), SPH_E_INVALID, "bad capacity");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (%s): libsph_hip has no CPU fallback", hipGetErrorString(e));
+        return SPH_E_DEVICE;
+    }
+    SPH_REQUIRE(device >= 0 && device < ndev, SPH_E_DEVICE, "device %d out of range (%d devices)", device, ndev);
+    SPH_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SPH_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libsph_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return SPH_E_DEVICE;
+    }
+    sph_ctx* c = new (std::nothrow) sph_ctx();
+    SPH_REQUIRE(c, SPH_E_NOMEM, "out of host memory");
+    c->device = device;
+    int rc = derive(c, p, z_lo, z_hi);
+    if (rc) { delete c; return rc; }
+    c->cap = capacity; c->gcap = gcap; c->tot = capacity + 2 * gcap; c->slab = slab;
+    c->own_off = gcap;
+    c->sort_blocks_cap = ceil_div(capacity, 4096) + 1;
+    c->pos_out_cap = slab ? 0 : capacity;
+    const size_t tot = c->tot;
+    rc = dev_alloc(&c->posi, tot);
+    if (!rc) rc = dev_alloc(&c->velr, tot);
+    if (!rc) rc = dev_alloc(&c->posi2, tot);
+    if (!rc) rc = dev_alloc(&c->velr2, tot);
+    if (!rc) rc = dev_alloc(&c->keyS, tot);
+    if (!rc) rc = dev_alloc(&c->dp, tot);
+    if (!rc) rc = dev_alloc(&c->fpress, tot);
+    if (!rc) rc = dev_alloc(&c->fvisc, tot);
+    if (!rc) rc = dev_alloc(&c->dvel, tot);
+    if (!rc) rc = dev_alloc(&c->pos_out, (size_t)c->pos_out_cap);
+    if (!rc) rc = dev_alloc(&c->cells, (size_t)c->grid.ncells);
+    if (!rc) rc = dev_alloc(&c->k0, (size_t)capacity);
+    if (!rc) rc = dev_alloc(&c->v0, (size_t)capacity);
+    if (!rc) rc = dev_alloc(&c->k1, (size_t)capacity);
+    if (!rc) rc = dev_alloc(&c->v1, (size_t)capacity);
+    if (!rc) rc = dev_alloc(&c->hist, (size_t)256 * c->sort_blocks_cap);
+    if (!rc) rc = dev_alloc(&c->digit_tot, (size_t)256);
+    if (!rc) rc = dev_alloc(&c->d_scratch, (size_t)64);
+    if (!rc && hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(uint32_t)) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        rc = SPH_E_NOMEM;
+    }
+    if (!rc && hipMemset(c->cells, 0, (size_t)c->grid.ncells * sizeof(uint2)) != hipSuccess) {
+        set_error("hipMemset(cells) failed");
+        rc = SPH_E_DEVICE;
+    }
+    if (!rc && hipMemset(c->dp, 0, tot * sizeof(float2)) != hipSuccess) rc = SPH_E_DEVICE;
+    if (rc) { free_all(c); delete c; return rc; }
+    *out = c;
+    return SPH_OK;
+}
+
+// ---- device timing --------------------------------------------------------------------------------------
+struct PhaseTimer {
+    sph_ctx* c; int phase; hipEvent_t a = nullptr, b = nullptr;
+    PhaseTimer(sph_ctx* c_, int ph) : c(c_), phase(ph) {
+        if (!c->timing) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        hipEventRecord(a, c->stream);
+    }
+    ~PhaseTimer() {
+        if (!a || !b) return;
+        hipEventRecord(b, c->stream);
+        c->events.push_back(a);
+        c->events.push_back(b);
+        c->events.push_back((hipEvent_t)(intptr_t)phase);   // tag
+    }
+};
+
+static void timing_collect(sph_ctx* c) {
+    for (size_t k = 0; k + 3 <= c->events.size(); k += 3) {
+        hipEvent_t a = c->events[k], b = c->events[k + 1];
+        int phase = (int)(intptr_t)c->events[k + 2];
+        hipEventSynchronize(b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, a, b) == hipSuccess) c->ph_ms[phase] += ms;
+        hipEventDestroy(a);
+        hipEventDestroy(b);
+    }
+    c->events.clear();
+}
+
+// ---- phase bodies ------------------------------------------------------------------------------------------
+static int do_hash(sph_ctx* c) {
+    PhaseTimer t(c, SPH_PH_ZINDEX);
+    int rc = launch_cells_clear(c);      // the table of the previous step dies with its keys
+    if (rc) return rc;
+    rc = launch_hash(c);
+    if (rc) return rc;
+    c->stage = sph_ctx::ST_HASHED;
+    return SPH_OK;
+}
+
+static int do_sort(sph_ctx* c) {
+    PhaseTimer t(c, SPH_PH_SORT);
+    int rc = launch_sort(c);
+    if (rc) return rc;
+    c->n_glo = c->n_ghi = 0;
+    c->stage = sph_ctx::ST_SORTED;
+    c->have_dens = c->have_force = c->have_coll = false;
+    return SPH_OK;
+}
+
+static int do_cells(sph_ctx* c) {
+    PhaseTimer t(c, SPH_PH_BGRID);
+    int rc = launch_cells_clear(c);      // no-op unless a table is still installed (ghosts re-installed)
+    if (rc) return rc;
+    rc = launch_cells_build(c);
+    if (rc) return rc;
+    c->stage = sph_ctx::ST_CELLS;
+    return SPH_OK;
+}
+
+static int do_density(sph_ctx* c) {
+    PhaseTimer t(c, SPH_PH_DENS);
+    int rc = launch_density(c);
+    if (rc) return rc;
+    c->have_dens = true;
+    return SPH_OK;
+}
+
+}  // namespace sph
+
+using namespace sph;
+
+extern "C" {
+
+int sph_abi_version(void) { return SPH_ABI_VERSION; }
+
+const char* sph_last_error(void) { return g_err.c_str(); }
+
+int sph_device_count(int* is_gfx950) {
+    int n = 0;
+    if (is_gfx950) *is_gfx950 = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return SPH_E_DEVICE; }
+    if (n > 0 && is_gfx950) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, 0) == hipSuccess) *is_gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    }
+    return n;
+}
+
+void sph_default_params(sph_params* p, const float box_dims[3], const uint32_t grid[3]) {
+    memset(p, 0, sizeof(*p));
+    for (int a = 0; a < 3; a++) {
+        p->box_min[a] = -box_dims[a] / 2;      // particleSystem.cpp:55-60
+        p->box_max[a] = box_dims[a] / 2;
+        p->grid[a] = grid[a];
+    }
+    p->h = 0.1f;                                // particles_kernel.cuh:20-33
+    p->mass = 65.f;
+    p->rest_density = 1000.f;
+    p->gas_constant = 2000.f;
+    p->viscosity = 250.f;
+    p->gravity_y = -9.81f * 11000;
+    p->wall_eps = 0.00001f;
+    p->wall_damping = -.75f;                    // particleSystem.cu:376
+    p->restitution = 0.f;
+    p->collision_param = 1.0f;
+    p->particle_radius = 1.0f / 64.0f;          // particleSystem.cpp:51
+}
+
+uint32_t sph_grid_dim_for_edge(float edge, float h) { return next_pow2((uint32_t)(edge / (0.66666f * h))); }
+
+int sph_create(sph_ctx** out, int device, uint32_t capacity, const sph_params* p) {
+    if (!p) { set_error("null params"); return SPH_E_INVALID; }
+    return create_impl(out, device, capacity, p, 0, p->grid[2], 0, false);
+}
+
+int sph_create_slab(sph_ctx** out, int device, uint32_t capacity, const sph_params* p, uint32_t z_lo, uint32_t z_hi,
+                    uint32_t ghost_capacity) {
+    if (!p) { set_error("null params"); return SPH_E_INVALID; }
+    return create_impl(out, device, capacity, p, z_lo, z_hi, ghost_capacity, true);
+}
+
+void sph_destroy(sph_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    timing_collect(c);
+    free_all(c);
+    delete c;
+}
+
+int sph_set_stream(sph_ctx* c, void* s) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    c->stream = (hipStream_t)s;
+    return SPH_OK;
+}
+
+int sph_set_params(sph_ctx* c, const sph_params* p) {
+    SPH_REQUIRE(c && p, SPH_E_INVALID, "null argument");
+    for (int a = 0; a < 3; a++)
+        SPH_REQUIRE(p->grid[a] == c->params.grid[a], SPH_E_INVALID, "the grid cannot change after sph_create");
+    sph_ctx tmp;   // validate first
+    tmp.params = c->params;
+    uint32_t z_lo = c->grid.z_lo, z_hi = c->grid.z_lo + c->grid.zl - 2;
+    int rc = derive(&tmp, p, z_lo, z_hi);
+    if (rc) return rc;
+    c->params = tmp.params; c->grid = tmp.grid; c->phys = tmp.phys;
+    return SPH_OK;
+}
+
+int sph_get_params(const sph_ctx* c, sph_params* p) {
+    SPH_REQUIRE(c && p, SPH_E_INVALID, "null argument");
+    *p = c->params;
+    return SPH_OK;
+}
+
+int sph_sync(sph_ctx* c) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+uint32_t sph_num_particles(const sph_ctx* c) { return c ? c->n : 0; }
+uint32_t sph_capacity(const sph_ctx* c) { return c ? c->cap : 0; }
+
+int sph_upload(sph_ctx* c, uint32_t n, const float* pos, const float* vel, const uint32_t* index) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(n <= c->cap, SPH_E_CAPACITY, "%u particles > capacity %u", n, c->cap);
+    SPH_REQUIRE(n == 0 || pos, SPH_E_INVALID, "null positions");
+    SPH_HIP(hipSetDevice(c->device));
+    std::vector<float4> hp(n), hv(n);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t idx = index ? index[i] : i;
+        if (!c->slab) SPH_REQUIRE(idx < c->pos_out_cap, SPH_E_INVALID, "creation index %u >= capacity %u", idx, c->pos_out_cap);
+        float w;
+        memcpy(&w, &idx, 4);
+        hp[i] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], w);
+        hv[i] = vel ? make_float4(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    int rc = launch_cells_clear(c);
+    if (rc) return rc;
+    c->own_off = c->gcap;
+    c->n = n; c->n_glo = c->n_ghi = 0;
+    if (n) {
+        SPH_HIP(hipMemcpyAsync(c->posi + c->own_off, hp.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        SPH_HIP(hipMemcpyAsync(c->velr + c->own_off, hv.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        SPH_HIP(hipMemsetAsync(c->dp + c->own_off, 0, n * sizeof(float2), c->stream));
+        if (!c->slab) {
+            // gl_pos starts as the initial positions (initGrid writes m_hPos, particleSystem.cpp:865-868)
+            std::vector<float4> ho(c->pos_out_cap, make_float4(0.f, 0.f, 0.f, 0.f));
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t idx = index ? index[i] : i;
+                ho[idx] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], 1.0f);
+            }
+            SPH_HIP(hipMemcpyAsync(c->pos_out, ho.data(), ho.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+            SPH_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    c->stage = sph_ctx::ST_LOADED;
+    c->have_dens = c->have_force = c->have_coll = false;
+    return SPH_OK;
+}
+
+static int fetch_sorted(sph_ctx* c, std::vector<float4>* hp, std::vector<float4>* hv, std::vector<float2>* hd) {
+    SPH_HIP(hipSetDevice(c->device));
+    const uint32_t n = c->n;
+    if (hp) { hp->resize(n); if (n) SPH_HIP(hipMemcpyAsync(hp->data(), c->posi + c->own_off, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream)); }
+    if (hv) { hv->resize(n); if (n) SPH_HIP(hipMemcpyAsync(hv->data(), c->velr + c->own_off, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream)); }
+    if (hd) { hd->resize(n); if (n) SPH_HIP(hipMemcpyAsync(hd->data(), c->dp + c->own_off, n * sizeof(float2), hipMemcpyDeviceToHost, c->stream)); }
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+static inline uint32_t idx_of(const float4& p) { uint32_t u; memcpy(&u, &p.w, 4); return u; }
+
+int sph_download(sph_ctx* c, uint32_t base, float* pos, float* vel, float* density, float* pressure) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    std::vector<float4> hp, hv;
+    std::vector<float2> hd;
+    int rc = fetch_sorted(c, &hp, vel ? &hv : nullptr, (density || pressure) ? &hd : nullptr);
+    if (rc) return rc;
+    for (uint32_t s = 0; s < c->n; s++) {
+        size_t i = (size_t)(idx_of(hp[s]) - base);
+        if (pos) { pos[3 * i] = hp[s].x; pos[3 * i + 1] = hp[s].y; pos[3 * i + 2] = hp[s].z; }
+        if (vel) { vel[3 * i] = hv[s].x; vel[3 * i + 1] = hv[s].y; vel[3 * i + 2] = hv[s].z; }
+        if (density) density[i] = hd[s].x;
+        if (pressure) pressure[i] = hd[s].y;
+    }
+    return SPH_OK;
+}
+
+int sph_download_forces(sph_ctx* c, uint32_t base, float* fp, float* fv, float* dv, int32_t* count) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE((!fp && !fv) || c->have_force, SPH_E_STATE, "sph_force has not run for this particle order");
+    SPH_REQUIRE((!dv && !count) || c->have_coll, SPH_E_STATE, "sph_collide has not run for this particle order");
+    std::vector<float4> hp;
+    int rc = fetch_sorted(c, &hp, nullptr, nullptr);
+    if (rc) return rc;
+    const uint32_t n = c->n;
+    std::vector<float4> a(n), b(n), d(n);
+    if (n && (fp || fv)) {
+        SPH_HIP(hipMemcpy(a.data(), c->fpress + c->own_off, n * sizeof(float4), hipMemcpyDeviceToHost));
+        SPH_HIP(hipMemcpy(b.data(), c->fvisc + c->own_off, n * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    if (n && (dv || count)) SPH_HIP(hipMemcpy(d.data(), c->dvel + c->own_off, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (uint32_t s = 0; s < n; s++) {
+        size_t i = (size_t)(idx_of(hp[s]) - base);
+        if (fp) { fp[3 * i] = a[s].x; fp[3 * i + 1] = a[s].y; fp[3 * i + 2] = a[s].z; }
+        if (fv) { fv[3 * i] = b[s].x; fv[3 * i + 1] = b[s].y; fv[3 * i + 2] = b[s].z; }
+        if (dv) { dv[3 * i] = d[s].x; dv[3 * i + 1] = d[s].y; dv[3 * i + 2] = d[s].z; }
+        if (count) { uint32_t u; memcpy(&u, &d[s].w, 4); count[i] = (int32_t)u; }
+    }
+    return SPH_OK;
+}
+
+int sph_positions_dev(sph_ctx* c, void** out) {
+    SPH_REQUIRE(c && out, SPH_E_INVALID, "null argument");
+    SPH_REQUIRE(!c->slab, SPH_E_STATE, "slab contexts keep no by-index position buffer");
+    *out = c->pos_out;
+    return SPH_OK;
+}
+
+int sph_download_positions4(sph_ctx* c, float* out) {
+    SPH_REQUIRE(c && out, SPH_E_INVALID, "null argument");
+    SPH_REQUIRE(!c->slab, SPH_E_STATE, "slab contexts keep no by-index position buffer");
+    SPH_HIP(hipSetDevice(c->device));
+    SPH_HIP(hipMemcpyAsync(out, c->pos_out, (size_t)c->pos_out_cap * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_get_keys(sph_ctx* c, uint32_t* keys) {
+    SPH_REQUIRE(c && keys, SPH_E_INVALID, "null argument");
+    SPH_REQUIRE(c->stage >= sph_ctx::ST_HASHED, SPH_E_STATE, "sph_hash has not run");
+    SPH_HIP(hipSetDevice(c->device));
+    const uint32_t* src = c->stage == sph_ctx::ST_HASHED ? c->k0 : c->keyS + c->own_off;
+    if (c->n) SPH_HIP(hipMemcpyAsync(keys, src, c->n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_get_order(sph_ctx* c, uint32_t* index) {
+    SPH_REQUIRE(c && index, SPH_E_INVALID, "null argument");
+    std::vector<float4> hp;
+    int rc = fetch_sorted(c, &hp, nullptr, nullptr);
+    if (rc) return rc;
+    for (uint32_t s = 0; s < c->n; s++) index[s] = idx_of(hp[s]);
+    return SPH_OK;
+}
+
+int sph_get_cell_range(sph_ctx* c, uint32_t cell, uint32_t* start, uint32_t* end) {
+    SPH_REQUIRE(c && start && end, SPH_E_INVALID, "null argument");
+    SPH_REQUIRE(c->cells_valid, SPH_E_STATE, "sph_build_cells has not run");
+    SPH_REQUIRE(cell < c->grid.ncells, SPH_E_INVALID, "cell %u out of range", cell);
+    uint2 v;
+    SPH_HIP(hipSetDevice(c->device));
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    SPH_HIP(hipMemcpy(&v, c->cells + cell, sizeof(v), hipMemcpyDeviceToHost));
+    *start = v.x - (v.y > v.x ? c->own_off - c->n_glo : 0);
+    *end = v.y - (v.y > v.x ? c->own_off - c->n_glo : 0);
+    return SPH_OK;
+}
+
+int sph_get_cells(sph_ctx* c, uint32_t max_cells, uint32_t* key, uint32_t* start, uint32_t* count) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(c->cells_valid, SPH_E_STATE, "sph_build_cells has not run");
+    SPH_HIP(hipSetDevice(c->device));
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t lo = c->cells_lo, hi = c->cells_hi;
+    std::vector<uint32_t> ks(hi - lo);
+    if (hi > lo) SPH_HIP(hipMemcpy(ks.data(), c->keyS + lo, (hi - lo) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t m = 0;
+    for (uint32_t s = 0; s < hi - lo; s++) {
+        if (s && ks[s] == ks[s - 1]) continue;
+        if (m < max_cells) {
+            uint2 v;
+            SPH_HIP(hipMemcpy(&v, c->cells + ks[s], sizeof(v), hipMemcpyDeviceToHost));
+            if (key) key[m] = ks[s];
+            if (start) start[m] = v.x - lo;
+            if (count) count[m] = v.y - v.x;
+        }
+        m++;
+    }
+    return (int)m;
+}
+
+uint32_t sph_cell_key(const sph_ctx* c, uint32_t x, uint32_t y, uint32_t z) {
+    if (!c) return 0;
+    return ((z - c->grid.z_lo + 1) * c->grid.g[1] + y) * c->grid.g[0] + x;
+}
+
+// ---- phases -------------------------------------------------------------------------------------------------------
+int sph_hash(sph_ctx* c) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_HIP(hipSetDevice(c->device));
+    return do_hash(c);
+}
+
+int sph_sort(sph_ctx* c) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(c->stage == sph_ctx::ST_HASHED, SPH_E_STATE, "sph_sort needs sph_hash first");
+    SPH_HIP(hipSetDevice(c->device));
+    return do_sort(c);
+}
+
+int sph_build_cells(sph_ctx* c) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(c->stage >= sph_ctx::ST_SORTED, SPH_E_STATE, "sph_build_cells needs sph_sort first");
+    SPH_HIP(hipSetDevice(c->device));
+    return do_cells(c);
+}
+
+int sph_density(sph_ctx* c) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(c->stage >= sph_ctx::ST_CELLS && c->cells_valid, SPH_E_STATE, "sph_density needs sph_build_cells first");
+    SPH_HIP(hipSetDevice(c->device));
+    return do_density(c);
+}
+
+int sph_force(sph_ctx* c) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(c->stage >= sph_ctx::ST_CELLS && c->have_dens, SPH_E_STATE, "sph_force needs sph_density first");
+    SPH_HIP(hipSetDevice(c->device));
+    PhaseTimer t(c, SPH_PH_FORCE);
+    int rc = launch_force(c, true, false, false, 0.f);
+    if (rc) return rc;
+    c->have_force = true;
+    return SPH_OK;
+}
+
+int sph_collide(sph_ctx* c) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(c->stage >= sph_ctx::ST_CELLS && c->cells_valid, SPH_E_STATE, "sph_collide needs sph_build_cells first");
+    SPH_HIP(hipSetDevice(c->device));
+    PhaseTimer t(c, SPH_PH_COLLISION);
+    int rc = launch_force(c, false, true, false, 0.f);
+    if (rc) return rc;
+    c->have_coll = true;
+    return SPH_OK;
+}
+
+int sph_integrate(sph_ctx* c, float dt) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(c->have_dens && c->have_force && c->have_coll, SPH_E_STATE,
+                "sph_integrate needs sph_density, sph_force and sph_collide first");
+    SPH_HIP(hipSetDevice(c->device));
+    PhaseTimer t(c, SPH_PH_INTEGRATE);
+    int rc = launch_integrate(c, dt);
+    if (rc) return rc;
+    c->have_force = c->have_coll = false;   // consumed; positions moved
+    return SPH_OK;
+}
+
+int sph_step(sph_ctx* c, float dt, uint32_t n_steps) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_HIP(hipSetDevice(c->device));
+    for (uint32_t s = 0; s < n_steps; s++) {
+        int rc = do_hash(c);
+        if (!rc) rc = do_sort(c);
+        if (!rc) rc = do_cells(c);
+        if (!rc) rc = do_density(c);
+        if (rc) return rc;
+        {
+            PhaseTimer t(c, SPH_PH_FORCE);
+            rc = launch_force(c, true, true, true, dt);
+            if (rc) return rc;
+        }
+        c->have_force = c->have_coll = false;
+        if (c->timing) { c->timed_steps++; if (c->events.size() > 3 * 4096) timing_collect(c); }
+    }
+    return SPH_OK;
+}
+
+int sph_step_phased(sph_ctx* c, float dt, uint32_t n_steps) {
+    for (uint32_t s = 0; s < n_steps; s++) {
+        int rc = sph_hash(c);
+        if (!rc) rc = sph_sort(c);
+        if (!rc) rc = sph_build_cells(c);
+        if (!rc) rc = sph_density(c);
+        if (!rc) rc = sph_force(c);
+        if (!rc) rc = sph_collide(c);
+        if (!rc) rc = sph_integrate(c, dt);
+        if (rc) return rc;
+        if (c->timing) { c->timed_steps++; if (c->events.size() > 3 * 4096) timing_collect(c); }
+    }
+    return SPH_OK;
+}
+
+int sph_timing_enable(sph_ctx* c, int on) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    c->timing = on != 0;
+    return SPH_OK;
+}
+
+int sph_timing_get(sph_ctx* c, float ms[SPH_PH_COUNT], uint32_t* n_steps) {
+    SPH_REQUIRE(c && ms, SPH_E_INVALID, "null argument");
+    SPH_HIP(hipSetDevice(c->device));
+    timing_collect(c);
+    for (int k = 0; k < SPH_PH_COUNT; k++) ms[k] = (float)c->ph_ms[k];
+    if (n_steps) *n_steps = c->timed_steps;
+    return SPH_OK;
+}
+
+int sph_timing_reset(sph_ctx* c) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_HIP(hipSetDevice(c->device));
+    timing_collect(c);
+    for (int k = 0; k < SPH_PH_COUNT; k++) c->ph_ms[k] = 0;
+    c->timed_steps = 0;
+    return SPH_OK;
+}
+
+}  // extern "C"

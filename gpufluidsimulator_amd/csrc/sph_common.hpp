@@ -1,0 +1,137 @@
+// sph_common.hpp -- shared declarations of libsph_hip.so (host side + device helpers).
+// MI355X / gfx950 only: wave64, no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/sph_hip.h"
+
+namespace sph {
+
+constexpr int WAVE = 64;
+
+// Grid description passed by value to kernels (replaces the device-resident SimParams*
+// every reference kernel dereferences, particleSystem.cu:93-103,127-130).
+struct GridDesc {
+    float box_min[3];
+    float box_dims[3];     // box_max - box_min
+    uint32_t g[3];         // global cells per axis
+    float gf[3];           // (float)g
+    uint32_t z_lo;         // first owned global z layer
+    uint32_t zl;           // local z layers = owned + 2 ghost layers
+    uint32_t ncells;       // g[0]*g[1]*zl
+};
+
+struct Phys {
+    float h, h2;
+    float mass;
+    float rest_density, gas_constant;
+    float poly6_mass;      // MASS * 315/(65*pi*h^9)        (particleSystem.cu:30,35)
+    float spiky_half_mass; // MASS * 45/(pi*h^6) / 2         (particleSystem.cu:41,47; sign folded)
+    float visc_coef;       // VISC * MASS * 45/(pi*h^6)      (particleSystem.cu:42,48)
+    float gravity_y;
+    float wall_eps, wall_damping;
+    float coll_dist2;      // (COLLISION_PARAM * 2 * radius)^2 (particleSystem.cu:61)
+    float coll_mass;       // MASS * (1 + RESTITUTION)        (particleSystem.cu:62)
+    float box_min[3], box_max[3];
+};
+
+}  // namespace sph
+
+// The opaque context of include/sph_hip.h.
+struct sph_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    sph_params params{};
+    sph::GridDesc grid{};
+    sph::Phys phys{};
+
+    uint32_t cap = 0;        // owned capacity
+    uint32_t gcap = 0;       // ghost capacity per side (0: whole-domain context)
+    uint32_t tot = 0;        // gcap + cap + gcap
+    bool slab = false;
+
+    // counts
+    uint32_t n = 0;          // owned particles
+    uint32_t own_off = 0;    // offset of the owned range inside posi/velr (gcap after a sort)
+    uint32_t n_glo = 0, n_ghi = 0;   // ghosts installed below / above
+    uint32_t index_hi = 0;   // max creation index + 1 seen at upload (size of pos_out)
+
+    // sorted SoA state, `tot` entries each; the owned range starts at own_off
+    float4* posi = nullptr;   // x, y, z, creation index (bits)
+    float4* velr = nullptr;   // vx, vy, vz, unused
+    float4* posi2 = nullptr;  // ping-pong targets of reorder / integrate
+    float4* velr2 = nullptr;
+    uint32_t* keyS = nullptr; // cell key per slot (same indexing as posi)
+    float2* dp = nullptr;     // density, pressure
+    float4* fpress = nullptr; // phase API outputs
+    float4* fvisc = nullptr;
+    float4* dvel = nullptr;   // delta_velocity xyz, collision count
+    float4* pos_out = nullptr;// (x,y,z,1) by creation index: the gl_pos analogue
+    uint32_t pos_out_cap = 0;
+
+    // cell table: {start, end} per local cell, zero = empty
+    uint2* cells = nullptr;
+    uint32_t cells_lo = 0, cells_hi = 0;   // slot range the table was built from
+    bool cells_valid = false;
+
+    // radix sort scratch
+    uint32_t* k0 = nullptr; uint32_t* v0 = nullptr;
+    uint32_t* k1 = nullptr; uint32_t* v1 = nullptr;
+    uint32_t* hist = nullptr;       // 256 * nblocks
+    uint32_t* digit_tot = nullptr;  // 256
+    uint32_t sort_blocks_cap = 0;
+    uint32_t key_bits = 0;
+    uint32_t* d_scratch = nullptr;  // small device scratch (counts)
+    uint32_t* h_scratch = nullptr;  // pinned host mirror
+
+    // state machine for the phase API
+    enum Stage { ST_LOADED = 0, ST_HASHED, ST_SORTED, ST_CELLS, ST_DENS, ST_FORCE, ST_COLL } stage = ST_LOADED;
+    bool have_force = false, have_coll = false, have_dens = false;
+
+    // device timing
+    bool timing = false;
+    static constexpr int EV_STEPS = 128;
+    std::vector<hipEvent_t> events;   // EV_STEPS * (SPH_PH_COUNT + 1)
+    uint32_t ev_steps_pending = 0;
+    double ph_ms[SPH_PH_COUNT] = {0};
+    uint32_t timed_steps = 0;
+};
+
+namespace sph {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define SPH_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return sph::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define SPH_REQUIRE(cond, code, ...)          \
+    do {                                      \
+        if (!(cond)) {                        \
+            sph::set_error(__VA_ARGS__);      \
+            return (code);                    \
+        }                                     \
+    } while (0)
+
+// kernel launchers (defined in the .hip files)
+int launch_hash(sph_ctx* c);
+int launch_sort(sph_ctx* c);          // radix sort of (k0,v0)[0,n) + reorder into posi2/velr2/keyS
+int launch_cells_clear(sph_ctx* c);
+int launch_cells_build(sph_ctx* c);
+int launch_density(sph_ctx* c);
+int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt);
+int launch_integrate(sph_ctx* c, float dt);
+int launch_halo(sph_ctx* c);
+
+inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+}  // namespace sph

@@ -1,0 +1,66 @@
+// sph_device.hpp -- device-side helpers (gfx950, wave64).
+#pragma once
+
+#include "sph_common.hpp"
+
+namespace sph {
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// ---- wave64 reductions over DPP (no LDS): row reductions by quad_perm / mirrors, then
+//      row_bcast15 / row_bcast31 carry the partial results to lane 63 (gfx9 DPP controls).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_u32<0xB1>(0xFFFFFFFFu, v));        // quad_perm [1,0,3,2]
+    v = min(v, dpp_u32<0x4E>(0xFFFFFFFFu, v));        // quad_perm [2,3,0,1]
+    v = min(v, dpp_u32<0x141>(0xFFFFFFFFu, v));       // row_half_mirror
+    v = min(v, dpp_u32<0x140>(0xFFFFFFFFu, v));       // row_mirror
+    v = min(v, dpp_u32<0x142, 0xA>(0xFFFFFFFFu, v));  // row_bcast15 -> rows 1,3
+    v = min(v, dpp_u32<0x143, 0xC>(0xFFFFFFFFu, v));  // row_bcast31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp_u32<0xB1>(0u, v));
+    v = max(v, dpp_u32<0x4E>(0u, v));
+    v = max(v, dpp_u32<0x141>(0u, v));
+    v = max(v, dpp_u32<0x140>(0u, v));
+    v = max(v, dpp_u32<0x142, 0xA>(0u, v));
+    v = max(v, dpp_u32<0x143, 0xC>(0u, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ---- cell hashing -------------------------------------------------------------------------
+// get_Z_index of the reference (particleSystem.cu:93-103): subtract boxMin, DIVIDE by the box
+// dimension, THEN multiply by the grid size, floor.  IEEE division (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt) so that the cell coordinates are bit-identical to the
+// CPU.  Unlike the reference, out-of-box positions are clamped into the grid instead of producing
+// out-of-range Morton codes.
+__device__ __forceinline__ uint32_t cell_coord(float p, float bmin, float bdim, float gf, uint32_t g) {
+    float rel = p - bmin;
+    float q = (rel / bdim) * gf;
+    int c = (int)floorf(q);
+    c = c < 0 ? 0 : c;
+    c = c >= (int)g ? (int)g - 1 : c;
+    return (uint32_t)c;
+}
+
+// Local cell key: x fastest, then y, then the slab-local z layer (global z - z_lo + 1; layer 0 and
+// layer zl-1 are the ghost layers).  The reference numbers cells in Morton order
+// (particleSystem.cu:68-91); the numbering is internal: results are reported by creation index.
+__device__ __forceinline__ uint32_t cell_key(const GridDesc& g, float x, float y, float z) {
+    uint32_t cx = cell_coord(x, g.box_min[0], g.box_dims[0], g.gf[0], g.g[0]);
+    uint32_t cy = cell_coord(y, g.box_min[1], g.box_dims[1], g.gf[1], g.g[1]);
+    uint32_t cz = cell_coord(z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]);
+    // particles outside [z_lo-1, z_lo+zl-2] cannot be represented: clamp into the ghost layers
+    int lz = (int)cz - (int)g.z_lo + 1;
+    lz = lz < 0 ? 0 : lz;
+    lz = lz >= (int)g.zl ? (int)g.zl - 1 : lz;
+    return ((uint32_t)lz * g.g[1] + cy) * g.g[0] + cx;
+}
+
+}  // namespace sph

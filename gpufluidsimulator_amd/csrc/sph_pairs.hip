@@ -1,0 +1,348 @@
+// sph_pairs.hip -- cell table and the neighbour passes (density, force, collision, integrate).
+//
+// Replaces cudaConstructBGrid / cudaConstructGridArray / cudaComputeDensities / cudaComputeForces /
+// cudaParticleCollisions / cudaIntegrate (particleSystem.cu:479-534, kernels :132-420).
+//
+// Work mapping (MI355X, wave64).  The reference launches one 32-thread block per <=32-particle
+// chunk of one cell (B'), i.e. ~8 live lanes of 32 at rest density, and re-stages whole 88-byte
+// structs of the 27 neighbour cells through shared memory with three block barriers per batch.
+// Here a wave takes 64 CONSECUTIVE particles of the sorted SoA arrays (always 64 live lanes).
+// Cells are numbered x-fastest, so for every particle the 27 neighbour cells are 9 ROWS
+// (dz, dy) of up to 3 consecutive cells = 9 contiguous slot ranges [lo, hi) of the sorted arrays.
+// Per row the wave stages the hull of its lanes' ranges (about 10 cells, ~80 particles at rest
+// density) into a wave-private LDS slice with coalesced 16-byte loads, then every lane walks ITS
+// OWN range, so each lane tests exactly its 27-cell candidates (~216) -- the reference semantics
+// (the 3x3x3 stencil truncates the support ball: cell edge 0.0625 < h = 0.1).
+// No block barriers: LDS traffic of one wave is processed in order.
+#include "sph_device.hpp"
+
+namespace sph {
+
+constexpr int PAIR_THREADS = 256;   // 4 independent waves
+constexpr int PAIR_WAVES = PAIR_THREADS / WAVE;
+constexpr int PIECE = 128;          // staged candidates per piece (2 coalesced loads per lane)
+
+// ---- cell table -----------------------------------------------------------------------------------
+// {start, end} per occupied cell; empty cells stay {0, 0}.  Only the cells touched by the previous
+// build are cleared (the reference memsets the whole table every step, particleSystem.cu:506, which
+// is 1 GiB at 512^3).  No atomics (the reference: one atomicAdd per particle, :318,327).
+__global__ __launch_bounds__(256) void k_cells_clear(const uint32_t* __restrict__ key, uint32_t lo, uint32_t hi,
+                                                     uint2* __restrict__ cells) {
+    uint32_t s = lo + blockIdx.x * 256u + threadIdx.x;
+    if (s >= hi) return;
+    uint32_t k = key[s];
+    if (s == lo || key[s - 1] != k) cells[k] = make_uint2(0u, 0u);
+}
+
+__global__ __launch_bounds__(256) void k_cells_build(const uint32_t* __restrict__ key, uint32_t lo, uint32_t hi,
+                                                     uint2* __restrict__ cells) {
+    uint32_t s = lo + blockIdx.x * 256u + threadIdx.x;
+    if (s >= hi) return;
+    uint32_t k = key[s];
+    if (s == lo || key[s - 1] != k) cells[k].x = s;
+    if (s + 1 == hi || key[s + 1] != k) cells[k].y = s + 1;
+}
+
+int launch_cells_clear(sph_ctx* c) {
+    if (!c->cells_valid || c->cells_hi <= c->cells_lo) { c->cells_valid = false; return SPH_OK; }
+    hipLaunchKernelGGL(k_cells_clear, dim3(ceil_div(c->cells_hi - c->cells_lo, 256)), dim3(256), 0, c->stream, c->keyS,
+                       c->cells_lo, c->cells_hi, c->cells);
+    SPH_HIP(hipGetLastError());
+    c->cells_valid = false;
+    return SPH_OK;
+}
+
+int launch_cells_build(sph_ctx* c) {
+    uint32_t lo = c->own_off - c->n_glo, hi = c->own_off + c->n + c->n_ghi;
+    c->cells_lo = lo; c->cells_hi = hi; c->cells_valid = true;
+    if (hi <= lo) return SPH_OK;
+    hipLaunchKernelGGL(k_cells_build, dim3(ceil_div(hi - lo, 256)), dim3(256), 0, c->stream, c->keyS, lo, hi, c->cells);
+    SPH_HIP(hipGetLastError());
+    return SPH_OK;
+}
+
+// ---- per-lane candidate ranges -----------------------------------------------------------------------
+struct Rows {
+    uint32_t lo[9], hi[9];
+};
+
+// first non-empty start / last non-empty end of up to three consecutive cells of one row
+__device__ __forceinline__ void row_range(const uint2* __restrict__ cells, uint32_t rowbase, uint32_t cx, uint32_t gx,
+                                          bool rowvalid, uint32_t& lo, uint32_t& hi) {
+    uint2 a = make_uint2(0u, 0u), b = a, d = a;
+    if (rowvalid) {
+        if (cx > 0) a = cells[rowbase + cx - 1];
+        b = cells[rowbase + cx];
+        if (cx + 1 < gx) d = cells[rowbase + cx + 1];
+    }
+    lo = a.y > a.x ? a.x : (b.y > b.x ? b.x : d.x);
+    hi = d.y > d.x ? d.y : (b.y > b.x ? b.y : a.y);
+}
+
+// rows in (dz, dy) order, cells of a row in dx order, particles of a cell in slot order: the
+// candidate order of one particle is fixed, so its fp32 sums are reproducible run to run.
+__device__ __forceinline__ void lane_rows(const uint2* __restrict__ cells, const GridDesc& g, uint32_t key, bool active,
+                                          Rows& R) {
+    const uint32_t gx = g.g[0], gy = g.g[1];
+    uint32_t cx = key % gx;
+    uint32_t t = key / gx;
+    uint32_t cy = t % gy;
+    uint32_t lz = t / gy;      // owned targets: 1 <= lz <= zl-2, so lz-1 and lz+1 are valid layers
+#pragma unroll
+    for (int dz = -1; dz <= 1; dz++) {
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+            const int r = (dz + 1) * 3 + (dy + 1);
+            int ny = (int)cy + dy;
+            int nz = (int)lz + dz;
+            bool ok = active && ny >= 0 && ny < (int)gy && nz >= 0 && nz < (int)g.zl;
+            uint32_t rowbase = ((uint32_t)nz * gy + (uint32_t)ny) * gx;
+            row_range(cells, ok ? rowbase : 0u, cx, gx, ok, R.lo[r], R.hi[r]);
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // one wave's LDS operations are processed in issue order; only the compiler must not move them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- density + pressure (kernelComputeDensities, particleSystem.cu:132-187) ---------------------------
+// rho_i = sum_{j in 27 cells, r2 < h2} m * POLY6 * (h2 - r2)^3   (self included)   (.cu:28-37)
+// p_i   = max(0, k * (rho_i - rho0))                                              (.cu:15-17)
+__global__ __launch_bounds__(PAIR_THREADS) void k_density(const float4* __restrict__ posi,
+                                                          const uint32_t* __restrict__ keyS,
+                                                          const uint2* __restrict__ cells, float2* __restrict__ dp,
+                                                          uint32_t tgt_lo, uint32_t tgt_hi, GridDesc g, Phys ph) {
+    __shared__ float2 s_xy[PAIR_WAVES][PIECE];
+    __shared__ float s_z[PAIR_WAVES][PIECE];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t i = tgt_lo + (blockIdx.x * PAIR_WAVES + wave) * WAVE + lane;
+    const bool active = i < tgt_hi;
+    const uint32_t ii = active ? i : tgt_hi - 1;
+    const float4 pi = posi[ii];
+    Rows R;
+    lane_rows(cells, g, keyS[ii], active, R);
+    float2* sxy = s_xy[wave];
+    float* sz = s_z[wave];
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const bool has = R.hi[r] > R.lo[r];
+        const uint32_t A = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
+        const uint32_t B = wave_max_u32(has ? R.hi[r] : 0u);
+        for (uint32_t a = A; a < B; a += PIECE) {
+            const uint32_t b = min(a + PIECE, B);
+            const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
+            if (__ballot(l0 < l1) == 0ull) continue;
+            for (uint32_t k = lane; k < b - a; k += WAVE) {
+                float4 q = posi[a + k];
+                sxy[k] = make_float2(q.x, q.y);
+                sz[k] = q.z;
+            }
+            wave_lds_sync();
+            for (uint32_t j = l0; j < l1; j++) {
+                float2 xy = sxy[j - a];
+                float z = sz[j - a];
+                float dx = pi.x - xy.x, dy = pi.y - xy.y, dz = pi.z - z;
+                float r2 = dx * dx + dy * dy + dz * dz;
+                float d = ph.h2 - r2;
+                d = d > 0.f ? d : 0.f;         // r2 < h2
+                acc += d * d * d;
+            }
+            wave_lds_sync();
+        }
+    }
+    if (active) {
+        float rho = acc * ph.poly6_mass;
+        float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
+        dp[i] = make_float2(rho, p);
+    }
+}
+
+int launch_density(sph_ctx* c) {
+    if (c->n == 0) return SPH_OK;
+    uint32_t lo = c->own_off, hi = c->own_off + c->n;
+    hipLaunchKernelGGL(k_density, dim3(ceil_div(c->n, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
+                       c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
+    SPH_HIP(hipGetLastError());
+    return SPH_OK;
+}
+
+// ---- integrate one particle (kernelIntegrate, particleSystem.cu:375-420) ------------------------------
+// a = (f_press + f_visc + (0, g*G*rho, 0)) / rho ; v += dt*a + dv ; x += dt*v ; walls per axis X,Y,Z
+// (lower wall first): x = wall +- eps, v *= -0.75 ; out[index] = (x, y, z, 1).
+__device__ __forceinline__ void wall(float& x, float& v, float lo, float hi, float eps, float damp) {
+    if (x - eps < lo) { x = lo + eps; v *= damp; }
+    if (x + eps > hi) { x = hi - eps; v *= damp; }
+}
+
+__device__ __forceinline__ void integrate_one(const Phys& ph, float dt, float4& pi, float4& vi, float rho, float fx,
+                                              float fy, float fz, float dvx, float dvy, float dvz) {
+    fy += ph.gravity_y * rho;
+    float ax = fx / rho, ay = fy / rho, az = fz / rho;
+    vi.x += dt * ax + dvx;
+    vi.y += dt * ay + dvy;
+    vi.z += dt * az + dvz;
+    pi.x += dt * vi.x;
+    pi.y += dt * vi.y;
+    pi.z += dt * vi.z;
+    wall(pi.x, vi.x, ph.box_min[0], ph.box_max[0], ph.wall_eps, ph.wall_damping);
+    wall(pi.y, vi.y, ph.box_min[1], ph.box_max[1], ph.wall_eps, ph.wall_damping);
+    wall(pi.z, vi.z, ph.box_min[2], ph.box_max[2], ph.wall_eps, ph.wall_damping);
+}
+
+// ---- force / collision / integrate in ONE neighbour traversal ------------------------------------------
+// kernelComputeForces (.cu:189-243, pair .cu:39-50):
+//   f_press_i += -r^_ij * m * (p_i + p_j) / (2 rho_j) * SPIKY_GRAD * (h - r)^2,  r < h
+//   f_visc_i  += VISC * m * (v_j - v_i) / rho_j * VISC_LAP * (h - r)
+//   a zero r_ij normalises to zero (Eigen Dot.h:124-134): self / coincident pairs add no pressure.
+// kernelComputeCollisions (.cu:245-300, pair .cu:52-65): j != i, d <= 2R and r.v < 0:
+//   dv += m (1 + e) (r.v / d^2) r, count++ ; finally dv = -dv / (m (1 + count)).
+// The reference runs three separate traversals plus an integrate pass; FORCE, COLL and INTEG select
+// what this instantiation does so that the phase API can still run them one at a time.
+template <bool FORCE, bool COLL, bool INTEG>
+__global__ __launch_bounds__(PAIR_THREADS) void k_force(const float4* __restrict__ posi,
+                                                        const float4* __restrict__ velr,
+                                                        const float2* __restrict__ dp,
+                                                        const uint32_t* __restrict__ keyS,
+                                                        const uint2* __restrict__ cells, float4* __restrict__ fpress,
+                                                        float4* __restrict__ fvisc, float4* __restrict__ dvel,
+                                                        float4* __restrict__ posi_out, float4* __restrict__ velr_out,
+                                                        float4* __restrict__ pos_by_index, uint32_t tgt_lo,
+                                                        uint32_t tgt_hi, float dt, GridDesc g, Phys ph) {
+    __shared__ float2 s_a[PAIR_WAVES][PIECE];   // x, y
+    __shared__ float2 s_b[PAIR_WAVES][PIECE];   // z, vx
+    __shared__ float2 s_c[PAIR_WAVES][PIECE];   // vy, vz
+    __shared__ float2 s_d[PAIR_WAVES][PIECE];   // p, 1/rho
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t i = tgt_lo + (blockIdx.x * PAIR_WAVES + wave) * WAVE + lane;
+    const bool active = i < tgt_hi;
+    const uint32_t ii = active ? i : tgt_hi - 1;
+    float4 pi = posi[ii];
+    float4 vi = velr[ii];
+    const float2 dpi = dp[ii];
+    Rows R;
+    lane_rows(cells, g, keyS[ii], active, R);
+    float2* sa = s_a[wave];
+    float2* sb = s_b[wave];
+    float2* sc = s_c[wave];
+    float2* sd = s_d[wave];
+    float fpx = 0.f, fpy = 0.f, fpz = 0.f, fvx = 0.f, fvy = 0.f, fvz = 0.f;
+    float cvx = 0.f, cvy = 0.f, cvz = 0.f;
+    uint32_t ccount = 0;
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const bool has = R.hi[r] > R.lo[r];
+        const uint32_t A = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
+        const uint32_t B = wave_max_u32(has ? R.hi[r] : 0u);
+        for (uint32_t a = A; a < B; a += PIECE) {
+            const uint32_t b = min(a + PIECE, B);
+            const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
+            if (__ballot(l0 < l1) == 0ull) continue;
+            for (uint32_t k = lane; k < b - a; k += WAVE) {
+                float4 q = posi[a + k];
+                float4 w = velr[a + k];
+                float2 e = dp[a + k];
+                sa[k] = make_float2(q.x, q.y);
+                sb[k] = make_float2(q.z, w.x);
+                sc[k] = make_float2(w.y, w.z);
+                sd[k] = make_float2(e.y, 1.0f / e.x);
+            }
+            wave_lds_sync();
+            for (uint32_t j = l0; j < l1; j++) {
+                const float2 qa = sa[j - a], qb = sb[j - a], qc = sc[j - a], qd = sd[j - a];
+                const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
+                if (FORCE) {
+                    const float rinv = r2 > 1e-30f ? __builtin_amdgcn_rsqf(r2) : 0.f;
+                    const float rr = r2 * rinv;
+                    const float hr = r2 < ph.h2 ? ph.h - rr : 0.f;
+                    const float s = ph.spiky_half_mass * (dpi.y + qd.x) * qd.y * hr * hr * rinv;
+                    fpx += s * dx; fpy += s * dy; fpz += s * dz;
+                    const float t = ph.visc_coef * qd.y * hr;
+                    fvx += t * ux; fvy += t * uy; fvz += t * uz;
+                }
+                if (COLL) {
+                    const float dot = -(dx * ux + dy * uy + dz * uz);               // r_ij . (v_i - v_j)
+                    const bool hit = (j != i) && (r2 <= ph.coll_dist2) && (dot < 0.f);
+                    const float cfac = hit ? ph.coll_mass * dot * __builtin_amdgcn_rcpf(r2) : 0.f;
+                    cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
+                    ccount += hit ? 1u : 0u;
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+    if (!active) return;
+    float dvx = 0.f, dvy = 0.f, dvz = 0.f;
+    if (COLL) {
+        const float den = ph.mass * (float)(1u + ccount);
+        dvx = -cvx / den; dvy = -cvy / den; dvz = -cvz / den;
+    }
+    if (INTEG) {
+        integrate_one(ph, dt, pi, vi, dpi.x, fpx + fvx, fpy + fvy, fpz + fvz, dvx, dvy, dvz);
+        posi_out[i] = pi;
+        velr_out[i] = vi;
+        pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
+    } else {
+        if (FORCE) {
+            fpress[i] = make_float4(fpx, fpy, fpz, 0.f);
+            fvisc[i] = make_float4(fvx, fvy, fvz, 0.f);
+        }
+        if (COLL) dvel[i] = make_float4(dvx, dvy, dvz, __uint_as_float(ccount));
+    }
+}
+
+int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt) {
+    if (c->n == 0) return SPH_OK;
+    const uint32_t lo = c->own_off, hi = c->own_off + c->n;
+    dim3 grid(ceil_div(c->n, PAIR_THREADS)), block(PAIR_THREADS);
+#define SPH_LAUNCH_FORCE(F, C, I)                                                                              \
+    hipLaunchKernelGGL((k_force<F, C, I>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->keyS, c->cells, \
+                       c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->pos_out, lo, hi, dt, c->grid, c->phys)
+    if (force && collide && integrate) SPH_LAUNCH_FORCE(true, true, true);
+    else if (force && !collide && !integrate) SPH_LAUNCH_FORCE(true, false, false);
+    else if (!force && collide && !integrate) SPH_LAUNCH_FORCE(false, true, false);
+    else {
+        set_error("launch_force: unsupported combination");
+        return SPH_E_INVALID;
+    }
+#undef SPH_LAUNCH_FORCE
+    SPH_HIP(hipGetLastError());
+    if (integrate) {
+        float4* t;
+        t = c->posi; c->posi = c->posi2; c->posi2 = t;
+        t = c->velr; c->velr = c->velr2; c->velr2 = t;
+    }
+    return SPH_OK;
+}
+
+// ---- stand-alone integrate for the phase API --------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_integrate(float4* __restrict__ posi, float4* __restrict__ velr,
+                                                   const float2* __restrict__ dp, const float4* __restrict__ fpress,
+                                                   const float4* __restrict__ fvisc, const float4* __restrict__ dvel,
+                                                   float4* __restrict__ pos_by_index, uint32_t lo, uint32_t hi, float dt,
+                                                   Phys ph) {
+    uint32_t i = lo + blockIdx.x * 256u + threadIdx.x;
+    if (i >= hi) return;
+    float4 pi = posi[i], vi = velr[i];
+    const float4 fp = fpress[i], fv = fvisc[i], dv = dvel[i];
+    integrate_one(ph, dt, pi, vi, dp[i].x, fp.x + fv.x, fp.y + fv.y, fp.z + fv.z, dv.x, dv.y, dv.z);
+    posi[i] = pi;
+    velr[i] = vi;
+    pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
+}
+
+int launch_integrate(sph_ctx* c, float dt) {
+    if (c->n == 0) return SPH_OK;
+    hipLaunchKernelGGL(k_integrate, dim3(ceil_div(c->n, 256)), dim3(256), 0, c->stream, c->posi, c->velr, c->dp,
+                       c->fpress, c->fvisc, c->dvel, c->pos_out, c->own_off, c->own_off + c->n, dt, c->phys);
+    SPH_HIP(hipGetLastError());
+    return SPH_OK;
+}
+
+}  // namespace sph

@@ -1,0 +1,218 @@
+// sph_sort.hip -- cell hash, on-device LSD radix sort of (cell key, slot) pairs, reorder.
+//
+// Replaces cudaMapZIndex + cudaSortParticles (particleSystem.cu:491-501): the reference
+// thrust::sort()s the whole 88-byte AoS array with a comparator (a merge sort moving 88 B per
+// element per level, 90 % of its step at 131k particles).  Here only 8-byte (key, slot) pairs are
+// sorted, 8 bits per pass over the significant key bits, and the SoA payload is gathered once.
+// The sort is stable, so the order of particles inside a cell is deterministic.
+#include "sph_device.hpp"
+
+namespace sph {
+
+constexpr int SORT_THREADS = 256;            // 4 waves
+constexpr int SORT_KPT = 16;                 // keys per thread
+constexpr int SORT_WAVE_TILE = WAVE * SORT_KPT;          // 1024 consecutive keys per wave
+constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;       // 4096 keys per block
+constexpr int RADIX = 256;
+
+// ---- hash: key per owned particle + identity slot -------------------------------------------
+__global__ __launch_bounds__(256) void k_hash(const float4* __restrict__ posi, uint32_t n, GridDesc g,
+                                              uint32_t* __restrict__ keys) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 p = posi[i];
+    keys[i] = cell_key(g, p.x, p.y, p.z);
+}
+
+// ---- pass 1 of 3: per-block digit histogram ----------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys, uint32_t n,
+                                                            uint32_t shift, uint32_t nblocks,
+                                                            uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int t = 0; t < SORT_KPT; t++) {
+        uint32_t i = base + t * SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];   // digit-major
+}
+
+// ---- pass 2 of 3: one block per digit scans its row of per-block counts --------------------------
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                   uint32_t* __restrict__ digit_tot) {
+    __shared__ uint32_t part[256];
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    uint32_t per = (nblocks + 255u) / 256u;
+    uint32_t lo = threadIdx.x * per;
+    uint32_t hi = min(lo + per, nblocks);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += row[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 256 partial sums
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;   // exclusive
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 255) digit_tot[blockIdx.x] = part[255];
+}
+
+// ---- pass 3 of 3: stable scatter -------------------------------------------------------------------
+// Each wave owns 1024 consecutive keys of the block's tile and walks them 64 at a time in order.
+// Rank of a key among equal digits inside one 64-key row: ballot-based match-any + popcount of the
+// lower lanes; running per-wave, per-digit counters live in LDS.
+template <bool FIRST>
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* __restrict__ kin,
+                                                               const uint32_t* __restrict__ vin,
+                                                               uint32_t* __restrict__ kout,
+                                                               uint32_t* __restrict__ vout, uint32_t n,
+                                                               uint32_t shift, uint32_t nblocks,
+                                                               const uint32_t* __restrict__ hist,
+                                                               const uint32_t* __restrict__ digit_tot) {
+    __shared__ uint32_t wh[4][RADIX];     // per-wave digit counters -> running offsets
+    __shared__ uint32_t dbase[RADIX];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (int w = 0; w < 4; w++) wh[w][threadIdx.x] = 0;
+    // exclusive scan of the 256 digit totals (global base of every digit)
+    uint32_t tot = digit_tot[threadIdx.x];
+    dbase[threadIdx.x] = tot;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = threadIdx.x >= (uint32_t)off ? dbase[threadIdx.x - off] : 0u;
+        __syncthreads();
+        dbase[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t my_base = dbase[threadIdx.x] - tot + hist[threadIdx.x * nblocks + blockIdx.x];
+
+    // load this wave's keys (registers) and count digits per wave
+    const uint32_t wbase = blockIdx.x * SORT_TILE + wave * SORT_WAVE_TILE;
+    uint32_t key[SORT_KPT];
+#pragma unroll
+    for (int t = 0; t < SORT_KPT; t++) {
+        uint32_t i = wbase + t * WAVE + lane;
+        key[t] = i < n ? kin[i] : 0xFFFFFFFFu;
+        if (i < n) atomicAdd(&wh[wave][(key[t] >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    // per digit: exclusive scan over the 4 waves, plus the global base
+    {
+        uint32_t o = my_base;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t cnt = wh[w][threadIdx.x];
+            wh[w][threadIdx.x] = o;
+            o += cnt;
+        }
+    }
+    __syncthreads();
+
+    volatile uint32_t* cnt = wh[wave];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int t = 0; t < SORT_KPT; t++) {
+        uint32_t i = wbase + t * WAVE + lane;
+        bool valid = i < n;
+        uint32_t d = (key[t] >> shift) & 0xFFu;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            bool bit = (d >> b) & 1u;
+            uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        uint32_t base = 0;
+        if (valid) base = cnt[d];                       // every peer reads the same word
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) cnt[d] = base + (uint32_t)__popcll(peers);   // LDS is in order per wave
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            uint32_t dst = base + rank;
+            kout[dst] = key[t];
+            vout[dst] = FIRST ? i : vin[i];
+        }
+    }
+}
+
+// ---- reorder: gather the SoA payload into sorted order -------------------------------------------
+__global__ __launch_bounds__(256) void k_reorder(const uint32_t* __restrict__ ks, const uint32_t* __restrict__ vs,
+                                                 uint32_t n, const float4* __restrict__ posi,
+                                                 const float4* __restrict__ velr, float4* __restrict__ posi_out,
+                                                 float4* __restrict__ velr_out, uint32_t* __restrict__ key_out) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t src = vs[i];
+    posi_out[i] = posi[src];
+    velr_out[i] = velr[src];
+    key_out[i] = ks[i];
+}
+
+__global__ __launch_bounds__(256) void k_copy_sorted(uint32_t n, const float4* __restrict__ posi,
+                                                     const float4* __restrict__ velr, const uint32_t* __restrict__ ks,
+                                                     float4* __restrict__ posi_out, float4* __restrict__ velr_out,
+                                                     uint32_t* __restrict__ key_out) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    posi_out[i] = posi[i];
+    velr_out[i] = velr[i];
+    key_out[i] = ks[i];
+}
+
+int launch_hash(sph_ctx* c) {
+    if (c->n == 0) return SPH_OK;
+    hipLaunchKernelGGL(k_hash, dim3(ceil_div(c->n, 256)), dim3(256), 0, c->stream, c->posi + c->own_off, c->n,
+                       c->grid, c->k0);
+    SPH_HIP(hipGetLastError());
+    return SPH_OK;
+}
+
+int launch_sort(sph_ctx* c) {
+    const uint32_t n = c->n;
+    if (n == 0) return SPH_OK;
+    const uint32_t nblocks = ceil_div(n, SORT_TILE);
+    SPH_REQUIRE(nblocks <= c->sort_blocks_cap, SPH_E_CAPACITY, "sort: %u blocks > capacity %u", nblocks,
+                c->sort_blocks_cap);
+    uint32_t* kin = c->k0; uint32_t* vin = c->v0;
+    uint32_t* kout = c->k1; uint32_t* vout = c->v1;
+    const uint32_t passes = (c->key_bits + 7) / 8;
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t shift = p * 8;
+        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, n, shift, nblocks,
+                           c->hist);
+        hipLaunchKernelGGL(k_sort_scan, dim3(RADIX), dim3(256), 0, c->stream, c->hist, nblocks, c->digit_tot);
+        if (p == 0)
+            hipLaunchKernelGGL(k_sort_scatter<true>, dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
+                               vout, n, shift, nblocks, c->hist, c->digit_tot);
+        else
+            hipLaunchKernelGGL(k_sort_scatter<false>, dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
+                               vout, n, shift, nblocks, c->hist, c->digit_tot);
+        uint32_t* t;
+        t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    // (kin, vin) now hold the sorted pairs; gather the payload to the canonical offset gcap
+    hipLaunchKernelGGL(k_reorder, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, kin, vin, n,
+                       c->posi + c->own_off, c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap,
+                       c->keyS + c->gcap);
+    SPH_HIP(hipGetLastError());
+    float4* t4;
+    t4 = c->posi; c->posi = c->posi2; c->posi2 = t4;
+    t4 = c->velr; c->velr = c->velr2; c->velr2 = t4;
+    c->own_off = c->gcap;
+    return SPH_OK;
+}
+
+}  // namespace sph

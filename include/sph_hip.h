@@ -1,0 +1,182 @@
+/* include/sph_hip.h -- C ABI of libsph_hip.so, the MI355X (gfx950) SPH step library.
+ *
+ * This is the drop-in boundary for the hot path of oadrian/GPUFluidSimulator: it
+ * replaces the extern "C" seam between the host class and the CUDA kernels,
+ * /root/reference/SPH/particleSystem.cuh:3-30 (definitions particleSystem.cu:422-535).
+ * The reference seam passes an 88-byte AoS `Particle*` and a device-resident
+ * `SimParams*` to every call; here the device state (sorted SoA arrays, cell table,
+ * sort scratch) lives in an opaque context and parameters travel by value.  A
+ * binary-compatible rendition of the reference's own 19 symbols is declared in
+ * include/sph_compat_seam.h on top of these entry points.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a HOST pointer unless the name ends in
+ *     `_dev` (then it is a device pointer on the context's GPU);
+ *   - every function returns 0 on success or a negative SPH_E* code; the message is
+ *     available from sph_last_error() (thread-local).  The reference's convention is
+ *     abort-on-error (checkCudaErrors -> exit, common/inc/helper_cuda.h:566-579); the
+ *     host class in include/particleSystem.h restores that behaviour on top;
+ *   - all work is enqueued on the context's stream (sph_set_stream; default: the NULL
+ *     stream like the reference) and is asynchronous unless the function returns data
+ *     to the host; one context must not be used from two host threads at once;
+ *   - there is NO CPU fallback: without a gfx950 device sph_create fails.
+ */
+#ifndef SPH_HIP_H
+#define SPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_ABI_VERSION 1
+
+enum {
+    SPH_OK = 0,
+    SPH_E_INVALID = -1,   /* bad argument */
+    SPH_E_DEVICE = -2,    /* HIP runtime error, no device, wrong architecture */
+    SPH_E_NOMEM = -3,     /* device or host allocation failed */
+    SPH_E_CAPACITY = -4,  /* more particles / ghosts than the context was created for */
+    SPH_E_STATE = -5      /* phase called out of order */
+};
+
+typedef struct sph_ctx sph_ctx;
+
+/* Replaces `struct SimParams` (SPH/particles_kernel.cuh:36-50) plus the physics macros of
+ * particles_kernel.cuh:20-33, which the reference bakes in at compile time.  The reference
+ * never reads SimParams.gravity / colliderPos / colliderRadius in any kernel (setGravity is a
+ * physics no-op), so they are not part of the device parameters. */
+typedef struct sph_params {
+    float box_min[3];        /* SimParams.boxMin                                   */
+    float box_max[3];        /* SimParams.boxMax                                   */
+    uint32_t grid[3];        /* cells per axis; the reference uses gridDim for all three */
+    float h;                 /* m_H            0.1                                  */
+    float mass;              /* MASS           65                                   */
+    float rest_density;      /* REST_DENS      1000                                 */
+    float gas_constant;      /* GAS_CONSTANT   2000                                 */
+    float viscosity;         /* VISC           250                                  */
+    float gravity_y;         /* GRAVITY * G_MODIFIER = -9.81f * 11000               */
+    float wall_eps;          /* EPS_F          1e-5                                 */
+    float wall_damping;      /* DAMPING_FACTOR -0.75 (particleSystem.cu:376)        */
+    float restitution;       /* RESTITUTION    0                                    */
+    float collision_param;   /* COLLISION_PARAM 1.0                                 */
+    float particle_radius;   /* SimParams.particleRadius 1/64 (particleSystem.cpp:51) */
+} sph_params;
+
+/* Phases of one step, in the order of ParticleSystem::update's CUDA branch
+ * (SPH/particleSystem.cpp:773-795); names follow dumpBenchmark (:697-716). */
+enum {
+    SPH_PH_ZINDEX = 0,   /* cudaMapZIndex            -> sph_hash            */
+    SPH_PH_SORT,         /* cudaSortParticles        -> sph_sort (radix sort + reorder) */
+    SPH_PH_BGRID,        /* cudaConstructBGrid + cudaConstructGridArray -> sph_build_cells */
+    SPH_PH_DENS,         /* cudaComputeDensities     -> sph_density         */
+    SPH_PH_FORCE,        /* cudaComputeForces        -> sph_force           */
+    SPH_PH_COLLISION,    /* cudaParticleCollisions   -> sph_collide         */
+    SPH_PH_INTEGRATE,    /* cudaIntegrate            -> sph_integrate       */
+    SPH_PH_COUNT
+};
+
+/* ---- library ------------------------------------------------------------------------- */
+int sph_abi_version(void);
+const char* sph_last_error(void);
+/* number of visible HIP devices, or a negative code; *is_gfx950 (optional) tells whether
+ * device 0 is a gfx950.  Replaces cudaInit/findCudaDevice (particleSystem.cu:427-436). */
+int sph_device_count(int* is_gfx950);
+
+/* Fill *p with the reference's constants for a box of dimensions box_dims centred on the
+ * origin (particleSystem.cpp:50-62) and the given grid. */
+void sph_default_params(sph_params* p, const float box_dims[3], const uint32_t grid[3]);
+/* nextPow2((uint)(edge / (0.66666f * h))): the reference's grid formula, particleSystem.cpp:46 */
+uint32_t sph_grid_dim_for_edge(float edge, float h);
+
+/* ---- context ------------------------------------------------------------------------- */
+/* Whole-domain context for up to `capacity` particles on HIP device `device`.
+ * Replaces the allocateArray calls of _initialize (particleSystem.cpp:121-124). */
+int sph_create(sph_ctx** out, int device, uint32_t capacity, const sph_params* p);
+/* z-slab context (multi-GPU): owns the cell layers [z_lo, z_hi) of the global grid and keeps
+ * one ghost layer on either side (up to ghost_capacity particles each). */
+int sph_create_slab(sph_ctx** out, int device, uint32_t capacity, const sph_params* p,
+                    uint32_t z_lo, uint32_t z_hi, uint32_t ghost_capacity);
+void sph_destroy(sph_ctx* c);                       /* freeArray x4, particleSystem.cpp:180-183 */
+int sph_set_stream(sph_ctx* c, void* hip_stream);   /* hipStream_t; NULL = default stream */
+int sph_set_params(sph_ctx* c, const sph_params* p);/* the per-update SimParams upload, :723 */
+int sph_get_params(const sph_ctx* c, sph_params* p);
+int sph_sync(sph_ctx* c);                           /* threadSync, particleSystem.cu:467 */
+uint32_t sph_num_particles(const sph_ctx* c);       /* owned particles */
+uint32_t sph_capacity(const sph_ctx* c);
+
+/* ---- state transfer ------------------------------------------------------------------- */
+/* Replace the particle set: n particles, xyz triples; index[i] is the immutable creation
+ * index (Particle::index), NULL = 0..n-1.  Replaces copyArrayToDevice of the AoS array
+ * (particleSystem.cpp:920,960).  Density/pressure/forces are reset to 0. */
+int sph_upload(sph_ctx* c, uint32_t n, const float* pos_xyz, const float* vel_xyz, const uint32_t* index);
+/* Gather the state BY CREATION INDEX relative to index_base: out[(index-index_base)*3+k].
+ * Any pointer may be NULL.  (The reference never copies particles back in CUDA mode; this is
+ * the additive getArray of the north star.) */
+int sph_download(sph_ctx* c, uint32_t index_base, float* pos_xyz, float* vel_xyz, float* density, float* pressure);
+int sph_download_forces(sph_ctx* c, uint32_t index_base, float* fpress_xyz, float* fvisc_xyz, float* dv_xyz,
+                        int32_t* collision_count);
+/* The `gl_pos` analogue of cudaIntegrate (particleSystem.cu:416-419): float4 (x,y,z,1) per
+ * creation index, written by sph_integrate / sph_step.  Device pointer, n*16 bytes. */
+int sph_positions_dev(sph_ctx* c, void** out_dev);
+int sph_download_positions4(sph_ctx* c, float* pos_xyzw);
+
+/* introspection for per-phase parity tests (sorted order) */
+int sph_get_keys(sph_ctx* c, uint32_t* keys);          /* cell key per slot */
+int sph_get_order(sph_ctx* c, uint32_t* index);        /* creation index per slot */
+int sph_get_cell_range(sph_ctx* c, uint32_t cell, uint32_t* start, uint32_t* end);
+/* occupied cells in ascending key order: {key, start, count}; returns the number written
+ * (<= max_cells) or a negative code */
+int sph_get_cells(sph_ctx* c, uint32_t max_cells, uint32_t* key, uint32_t* start, uint32_t* count);
+/* local cell key of global cell coordinates (x, y, z): (z_local*gy + y)*gx + x */
+uint32_t sph_cell_key(const sph_ctx* c, uint32_t x, uint32_t y, uint32_t z);
+
+/* ---- phases (each replaces one seam call; see the SPH_PH_* table) ------------------------ */
+int sph_hash(sph_ctx* c);
+int sph_sort(sph_ctx* c);
+int sph_build_cells(sph_ctx* c);
+int sph_density(sph_ctx* c);
+int sph_force(sph_ctx* c);
+int sph_collide(sph_ctx* c);
+int sph_integrate(sph_ctx* c, float dt);
+/* n full time steps = n iterations of the loop body of ParticleSystem::update
+ * (particleSystem.cpp:725-811), using the fused kernels (force+collision+integrate in one
+ * neighbour traversal).  Results equal the phase-by-phase sequence to fp32 rounding. */
+int sph_step(sph_ctx* c, float dt, uint32_t n_steps);
+/* same, phase by phase (the exact call sequence of particleSystem.cpp:773-795) */
+int sph_step_phased(sph_ctx* c, float dt, uint32_t n_steps);
+
+/* ---- device timing (replaces the host-side TIME_FUNCTION macros, particleSystem.h:20-24,
+ *      which time launches, not kernels) ------------------------------------------------------ */
+int sph_timing_enable(sph_ctx* c, int on);
+/* sums of per-phase device milliseconds since the last reset, and the number of steps */
+int sph_timing_get(sph_ctx* c, float ms[SPH_PH_COUNT], uint32_t* n_steps);
+int sph_timing_reset(sph_ctx* c);
+
+/* ---- z-slab halo / migration (multi-GPU; no counterpart in the reference) ---------------- */
+/* side: 0 = towards lower z (rank-1), 1 = towards higher z (rank+1).
+ * Records are 8 floats: x, y, z, index bits, vx, vy, vz, 0. */
+#define SPH_HALO_RECORD_FLOATS 8
+/* after sph_hash + sph_sort: number of owned particles that left the slab through `side` */
+int sph_migrants_count(sph_ctx* c, uint32_t count[2]);
+/* pack them into buf_dev[side] (device, capacity records each) and drop them */
+int sph_migrants_pack(sph_ctx* c, void* buf_dev[2], uint32_t capacity);
+/* append n received particles (device records) to the owned set; call sph_hash+sph_sort again */
+int sph_migrants_append(sph_ctx* c, const void* buf_dev, uint32_t n);
+/* number of owned particles in the boundary layers (what the neighbours need as ghosts) */
+int sph_halo_count(sph_ctx* c, uint32_t count[2]);
+int sph_halo_pack(sph_ctx* c, void* buf_dev[2], uint32_t capacity);
+/* install n_lo / n_hi ghost records received from the lower / upper neighbour */
+int sph_halo_unpack(sph_ctx* c, const void* lo_dev, uint32_t n_lo, const void* hi_dev, uint32_t n_hi);
+/* second exchange: (density, pressure) float2 of the same boundary particles, same order */
+int sph_halo_pack_density(sph_ctx* c, void* buf_dev[2], uint32_t capacity);
+int sph_halo_unpack_density(sph_ctx* c, const void* lo_dev, const void* hi_dev);
+/* per z cell layer histogram of owned particles (global layer ids), for count-balanced cuts */
+int sph_layer_histogram(sph_ctx* c, uint32_t* hist, uint32_t n_layers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH_HIP_H */

@@ -1,0 +1,48 @@
+"""CPU: libsph_hip.so builds for gfx950, loads, and exports every symbol include/sph_hip.h
+declares (no compute calls: there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+from gpufluidsimulator_amd import build, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sph_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_the_header():
+    lib_path = build.build()
+    assert os.path.exists(lib_path)
+    lib = capi.load()
+    names = _declared("sph_hip.h")
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sph_hip.h but not exported"
+        assert n in capi.SIGNATURES, f"{n} has no ctypes signature in capi.py"
+    assert lib.sph_abi_version() == 1
+
+
+def test_default_params_are_the_reference_constants():
+    p = capi.default_params((4.0, 4.0, 4.0), (64, 64, 64))
+    assert tuple(p.box_min) == (-2.0, -2.0, -2.0) and tuple(p.box_max) == (2.0, 2.0, 2.0)
+    assert abs(p.h - 0.1) < 1e-8 and p.mass == 65.0 and p.rest_density == 1000.0 and p.gas_constant == 2000.0
+    assert p.viscosity == 250.0 and abs(p.gravity_y - (-9.81 * 11000)) < 1e-1 and p.wall_damping == -0.75
+    assert p.particle_radius == 1.0 / 64.0
+    lib = capi.load()
+    # nextPow2((uint)(edge / (0.66666f * h))), particleSystem.cpp:46
+    assert [lib.sph_grid_dim_for_edge(e, 0.1) for e in (2.0, 4.0, 8.0, 32.0, 64.0)] == [32, 64, 128, 512, 1024]
+
+
+def test_no_cpu_fallback():
+    """Without a gfx950 device the product path must fail loudly, not compute on the CPU."""
+    n, is950 = capi.device_count()
+    if n > 0 and is950:
+        pytest.skip("a gfx950 device is present")
+    with pytest.raises(capi.SphError):
+        capi.Context(64, box=(2, 2, 2), grid=(32, 32, 32))
