@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/sec of the SPH step on MI355X (see BASELINE.json / DESIGN.md).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C1] [--no-cpu]
+
+N = 1: the whole-domain context runs BASELINE config 3 (dam-break, 16,777,216 particles, 512^3
+grid) with the state resident in HBM; K fused steps are timed between two device syncs.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the domain is cut into N z-slabs of
+16,777,216 particles each (weak scaling), ghost layers and migrants travel over RCCL.
+
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the fused
+force+collision+integrate traversal) by its ALGORITHMIC bytes over its mean
+device time measured with HIP events on the library's stream; `cpu_baseline` times the
+reference's own OpenMP code (oracle/_ref, kind "reference") or the C restatement (kind "port") on
+the host cores, on a bounded sample (a 64^3-particle dam break).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from gpufluidsimulator_amd import capi, ic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
+# algorithmic (compulsory) bytes per particle per launch, sorted-SoA, every array streamed once
+# 
+BYTES_PER_PARTICLE = {
+    "dens": 20,                 # R pos 12 ; W rho 4 + p 4
+    "force_fused": 92,          # R pos 12 + vel 12 + rho 4 + p 4 + index 4 ; W pos 12 + vel 12 + index 4 + out float4 16... see DESIGN.md
+}
+# R pos 12 + vel 12 + rho 4 + p 4 + index 4 = 36 ; W pos 12 + vel 12 + index 4 + gl_pos 16 = 44
+BYTES_PER_PARTICLE["force_fused"] = 36 + 44
+FLOP_PER_PARTICLE = {"dens": 216 * 11, "force_fused": 216 * 34}
+
+
+def _dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def cpu_baseline(budget_s=20.0):
+    """Reference CPU path on a bounded sample of the same workload: a 64^3-particle dam break
+    (BASELINE config 2 geometry), as many steps as fit the budget (>= 3)."""
+    sys.path.insert(0, ROOT)
+    from oracle import refio
+    cfg = ic.CONFIGS["C2"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if refio.available():
+        _, probe = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, 2)
+        per_step = probe["seconds"] / 2
+        steps = int(max(3, min(200, budget_s / max(per_step, 1e-3))))
+        _, st = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, steps)
+        return {"value": st["particle_steps_per_s"], "unit": "particle-steps/s", "cores": int(st["threads"]),
+                "kind": "reference",
+                "sample": f"dam-break 64^3 = 262144 particles, 128^3 grid, {steps} steps, the reference's OpenMP "
+                          f"path (SPH/particleSystem.cpp z* methods, g++ -O2 -fopenmp), {st['threads']} threads",
+                "phase_s": st["phase_s"]}
+    from oracle import oracle
+    o = oracle.Oracle(pos, vel, cfg["box"], cfg["grid"], oracle.CELL_MORTON, fast=True)
+    t0 = time.time(); o.step(float(ic.DEFAULT_DT), 2); per_step = (time.time() - t0) / 2
+    steps = int(max(3, min(200, budget_s / max(per_step, 1e-3))))
+    t0 = time.time(); o.step(float(ic.DEFAULT_DT), steps); dt = time.time() - t0
+    return {"value": pos.shape[0] * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"dam-break 64^3 = 262144 particles, 128^3 grid, {steps} steps, oracle/sph_oracle.c "
+                      f"(gcc -O3 -march=native -fopenmp), {cores} threads"}
+
+
+def run_single(args):
+    cfg = ic.CONFIGS[args.workload]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
+    n = pos.shape[0]
+    ctx = capi.Context(n, box=cfg["box"], grid=cfg["grid"], device=0)
+    ctx.upload(pos, vel)
+    del pos, vel
+    dt = float(ic.DEFAULT_DT)
+    ctx.step(dt, args.warmup)
+    ctx.sync()
+    # timed region: K steps, state resident in HBM, one sync on either side
+    t0 = time.perf_counter()
+    ctx.step(dt, args.steps)
+    ctx.sync()
+    wall = time.perf_counter() - t0
+    # per-phase device times (HIP events on the library's stream) from a second, instrumented run
+    ctx.timing(True); ctx.timing_reset()
+    ctx.step(dt, args.steps)
+    ctx.sync()
+    ph, nst = ctx.timing_get()
+    ctx.timing(False)
+    phases_ms = {k: v / max(nst, 1) for k, v in ph.items()}
+    st = ctx.download(want=("density",))
+    ok = bool(np.isfinite(st["density"]).all())
+    ctx.close()
+    return n, wall, phases_ms, ok, cfg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C3", choices=sorted(ic.CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+    rank, world, local = _dist_env()
+    if args.gpus > 1 or world > 1:
+        from gpufluidsimulator_amd import slab
+        return slab.bench_main(args)
+
+    n, wall, phases_ms, ok, cfg = run_single(args)
+    value = n * args.steps / wall
+    t_force = phases_ms["force"] * 1e-3
+    t_dens = phases_ms["dens"] * 1e-3
+    fbytes = BYTES_PER_PARTICLE["force_fused"] * n
+    achieved = fbytes / t_force / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            pj = json.load(open(prof))
+            if pj.get("workload") == args.workload:
+                traffic = pj.get("force_fused_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"dam-break {args.workload}: {cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} "
+                               f"= {n} particles, grid {cfg['grid'][0]}^3, box {cfg['box'][0]}, dt 5e-7, jittered lattice",
+                   "particles": n, "grid": list(cfg["grid"]), "parallelism": "1 GPU, whole domain"},
+        "roofline": {"bound": "hbm", "kernel": "k_force<force+collision+integrate>", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_particle": BYTES_PER_PARTICLE["force_fused"],
+                     "avg_launch_ms": phases_ms["force"],
+                     "valu": {"flop_per_particle": FLOP_PER_PARTICLE["force_fused"],
+                              "achieved_tflops": FLOP_PER_PARTICLE["force_fused"] * n / t_force / 1e12,
+                              "peak_tflops": VALU_PEAK_TFLOPS,
+                              "frac": FLOP_PER_PARTICLE["force_fused"] * n / t_force / 1e12 / VALU_PEAK_TFLOPS},
+                     "density_kernel": {"achieved": BYTES_PER_PARTICLE["dens"] * n / t_dens / 1e9, "unit": "GB/s",
+                                        "avg_launch_ms": phases_ms["dens"],
+                                        "valu_tflops": FLOP_PER_PARTICLE["dens"] * n / t_dens / 1e12}},
+        "phases_ms": phases_ms, "finite": ok,
+    }
+    if not args.no_cpu:
+        cb = cpu_baseline()
+        out["cpu_baseline"] = cb
+        out["gpu_over_cpu"] = value / cb["value"]
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

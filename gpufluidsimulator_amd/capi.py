@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsph_hip.so")
+LIB_PATH = os.environ.get("SPH_HIP_LIB", os.path.join(HERE, "libsph_hip.so"))
 
 PHASES = ("z-index", "sort", "b-grid", "dens", "force", "collision", "integrate")
 HALO_RECORD_FLOATS = 8

@@ -71,8 +71,14 @@ static int derive(sph_ctx* c, const sph_params* p, uint32_t z_lo, uint32_t z_hi)
     ph.gravity_y = p->gravity_y;
     ph.wall_eps = p->wall_eps;
     ph.wall_damping = p->wall_damping;
+    // computeCollision tests (double)sqrtf(r2) <= COLLISION_PARAM * 2 * radius (particleSystem.cu:61).
+    // sqrtf is monotone and correctly rounded, so that is r2 <= the LARGEST float whose square root
+    // rounds to a float <= the threshold: found by walking a few ulps around cd^2.
     const double cd = (double)p->collision_param * 2.0 * (double)p->particle_radius;
-    ph.coll_dist2 = (float)(cd * cd);
+    float r2max = (float)(cd * cd);
+    for (int k = 0; k < 8; k++) r2max = nextafterf(r2max, INFINITY);
+    while ((double)sqrtf(r2max) > cd) r2max = nextafterf(r2max, 0.f);
+    ph.coll_dist2 = r2max;
     ph.coll_mass = p->mass * (1.f + p->restitution);
     for (int a = 0; a < 3; a++) { ph.box_min[a] = p->box_min[a]; ph.box_max[a] = p->box_max[a]; }
     return SPH_OK;
@@ -126,7 +132,8 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     c->own_off = gcap;
     c->sort_blocks_cap = ceil_div(capacity, 4096) + 1;
     c->pos_out_cap = slab ? 0 : capacity;
-    const size_t tot = c->tot;
+    // + 2*PIECE entries: the pair kernels stage whole 128-entry pieces without bounds predicates
+    const size_t tot = (size_t)c->tot + 256;
     rc = dev_alloc(&c->posi, tot);
     if (!rc) rc = dev_alloc(&c->velr, tot);
     if (!rc) rc = dev_alloc(&c->posi2, tot);
@@ -153,7 +160,14 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
         set_error("hipMemset(cells) failed");
         rc = SPH_E_DEVICE;
     }
-    if (!rc && hipMemset(c->dp, 0, tot * sizeof(float2)) != hipSuccess) rc = SPH_E_DEVICE;
+    if (!rc && (hipMemset(c->dp, 0, tot * sizeof(float2)) != hipSuccess ||
+                hipMemset(c->posi, 0, tot * sizeof(float4)) != hipSuccess ||
+                hipMemset(c->velr, 0, tot * sizeof(float4)) != hipSuccess ||
+                hipMemset(c->posi2, 0, tot * sizeof(float4)) != hipSuccess ||
+                hipMemset(c->velr2, 0, tot * sizeof(float4)) != hipSuccess)) {
+        set_error("hipMemset failed");
+        rc = SPH_E_DEVICE;
+    }
     if (rc) { free_all(c); delete c; return rc; }
     *out = c;
     return SPH_OK;

@@ -102,6 +102,18 @@ __device__ __forceinline__ void lane_rows(const uint2* __restrict__ cells, const
     }
 }
 
+#ifndef SPH_COLL_EXACT
+#define SPH_COLL_EXACT 0
+#endif
+#ifndef SPH_DENS_OCC
+#define SPH_DENS_OCC 6      // waves per SIMD asked of the register allocator (<= 80 VGPRs)
+#endif
+#ifndef SPH_FORCE_OCC
+#define SPH_FORCE_OCC 4     // <= 128 VGPRs
+#endif
+
+__device__ __forceinline__ float inv_sqrt(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
+
 __device__ __forceinline__ void wave_lds_sync() {
     // one wave's LDS operations are processed in issue order; only the compiler must not move them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -109,52 +121,116 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// LDS: one PIECE-entry slice per wave plus one spare slice.  The unrolled candidate loop may read up
+// to PIECE+3 entries past the end of a lane's valid range; the spare slice keeps those reads inside
+// the block's allocation.  Such lanes are masked by selecting a zero WEIGHT, and a zero weight times
+// a NaN is a NaN, so everything a lane can over-read must be finite: the arrays are zero-filled once
+// per block, and whatever is staged later comes from the (zero-padded) particle arrays.
+constexpr int LDS_ENT = (PAIR_WAVES + 1) * PIECE + 8;
+constexpr int UNROLL = 4;        // density: candidates per unrolled group
+#ifndef SPH_FORCE_UNROLL
+#define SPH_FORCE_UNROLL 2
+#endif
+
+// Per-row hulls of the wave's candidate ranges (wave-uniform).
+struct Hulls {
+    uint32_t A[9], B[9];
+};
+
+__device__ __forceinline__ void wave_hulls(const Rows& R, Hulls& H) {
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const bool has = R.hi[r] > R.lo[r];
+        H.A[r] = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
+        H.B[r] = wave_max_u32(has ? R.hi[r] : 0u);
+    }
+}
+
+// Walk the 9 rows: stage every piece [a, b) of a row's hull through registers into the wave's LDS
+// slice (`load(a)` issues the global loads, `store()` writes them to LDS) and call `pieces(r, a, b)`
+// for the per-lane work.  The first piece of the NEXT row is requested before the current piece
+// is processed, so its global-memory latency hides behind the pair arithmetic.
+template <class Load, class Store, class Work>
+__device__ __forceinline__ void traverse(const Hulls& H, Load&& load, Store&& store, Work&& work) {
+    bool ready = false;
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        if (H.A[r] >= H.B[r]) continue;          // wave-uniform
+        if (!ready) load(H.A[r]);
+        ready = false;
+        for (uint32_t a = H.A[r]; a < H.B[r]; a += PIECE) {
+            const uint32_t b = min(a + PIECE, H.B[r]);
+            if (a != H.A[r]) load(a);
+            store();
+            if (b >= H.B[r] && r + 1 < 9 && H.A[r + 1] < H.B[r + 1]) {
+                load(H.A[r + 1]);
+                ready = true;
+            }
+            wave_lds_sync();
+            work(r, a, b);
+            wave_lds_sync();
+        }
+    }
+}
+
 // ---- density + pressure (kernelComputeDensities, particleSystem.cu:132-187) ---------------------------
 // rho_i = sum_{j in 27 cells, r2 < h2} m * POLY6 * (h2 - r2)^3   (self included)   (.cu:28-37)
 // p_i   = max(0, k * (rho_i - rho0))                                              (.cu:15-17)
-__global__ __launch_bounds__(PAIR_THREADS) void k_density(const float4* __restrict__ posi,
-                                                          const uint32_t* __restrict__ keyS,
-                                                          const uint2* __restrict__ cells, float2* __restrict__ dp,
-                                                          uint32_t tgt_lo, uint32_t tgt_hi, GridDesc g, Phys ph) {
-    __shared__ float2 s_xy[PAIR_WAVES][PIECE];
-    __shared__ float s_z[PAIR_WAVES][PIECE];
+__global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const float4* __restrict__ posi,
+                                                                        const uint32_t* __restrict__ keyS,
+                                                                        const uint2* __restrict__ cells,
+                                                                        float2* __restrict__ dp, uint32_t tgt_lo,
+                                                                        uint32_t tgt_hi, GridDesc g, Phys ph) {
+    __shared__ float2 s_xy[LDS_ENT];
+    __shared__ float s_z[LDS_ENT];
+    for (uint32_t k = threadIdx.x; k < LDS_ENT; k += PAIR_THREADS) {   // see LDS_ENT: keep over-reads finite
+        s_xy[k] = make_float2(0.f, 0.f);
+        s_z[k] = 0.f;
+    }
+    __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slice = wave * PIECE;
     const uint32_t i = tgt_lo + (blockIdx.x * PAIR_WAVES + wave) * WAVE + lane;
     const bool active = i < tgt_hi;
     const uint32_t ii = active ? i : tgt_hi - 1;
     const float4 pi = posi[ii];
     Rows R;
     lane_rows(cells, g, keyS[ii], active, R);
-    float2* sxy = s_xy[wave];
-    float* sz = s_z[wave];
+    Hulls H;
+    wave_hulls(R, H);
+    float4 q0, q1;
     float acc = 0.f;
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-        const bool has = R.hi[r] > R.lo[r];
-        const uint32_t A = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
-        const uint32_t B = wave_max_u32(has ? R.hi[r] : 0u);
-        for (uint32_t a = A; a < B; a += PIECE) {
-            const uint32_t b = min(a + PIECE, B);
+    traverse(
+        H,
+        [&](uint32_t a) {   // the arrays are padded by 2*PIECE entries: no bounds predicate needed
+            q0 = posi[a + lane];
+            q1 = posi[a + WAVE + lane];
+        },
+        [&]() {
+            s_xy[slice + lane] = make_float2(q0.x, q0.y);
+            s_z[slice + lane] = q0.z;
+            s_xy[slice + WAVE + lane] = make_float2(q1.x, q1.y);
+            s_z[slice + WAVE + lane] = q1.z;
+        },
+        [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
-            if (__ballot(l0 < l1) == 0ull) continue;
-            for (uint32_t k = lane; k < b - a; k += WAVE) {
-                float4 q = posi[a + k];
-                sxy[k] = make_float2(q.x, q.y);
-                sz[k] = q.z;
+            const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
+            const uint32_t T = wave_max_u32(len);
+            uint32_t idx = slice + (len ? l0 - a : 0u);
+            for (uint32_t t = 0; t < T; t += UNROLL) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    const float2 xy = s_xy[idx + u];
+                    const float z = s_z[idx + u];
+                    const float dx = pi.x - xy.x, dy = pi.y - xy.y, dz = pi.z - z;
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    float d = fmaxf(ph.h2 - r2, 0.f);      // r2 < h2
+                    d = (t + u < len) ? d : 0.f;
+                    acc = fmaf(d * d, d, acc);
+                }
+                idx += UNROLL;
             }
-            wave_lds_sync();
-            for (uint32_t j = l0; j < l1; j++) {
-                float2 xy = sxy[j - a];
-                float z = sz[j - a];
-                float dx = pi.x - xy.x, dy = pi.y - xy.y, dz = pi.z - z;
-                float r2 = dx * dx + dy * dy + dz * dz;
-                float d = ph.h2 - r2;
-                d = d > 0.f ? d : 0.f;         // r2 < h2
-                acc += d * d * d;
-            }
-            wave_lds_sync();
-        }
-    }
+        });
     if (active) {
         float rho = acc * ph.poly6_mass;
         float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
@@ -204,20 +280,25 @@ __device__ __forceinline__ void integrate_one(const Phys& ph, float dt, float4& 
 // The reference runs three separate traversals plus an integrate pass; FORCE, COLL and INTEG select
 // what this instantiation does so that the phase API can still run them one at a time.
 template <bool FORCE, bool COLL, bool INTEG>
-__global__ __launch_bounds__(PAIR_THREADS) void k_force(const float4* __restrict__ posi,
-                                                        const float4* __restrict__ velr,
-                                                        const float2* __restrict__ dp,
-                                                        const uint32_t* __restrict__ keyS,
-                                                        const uint2* __restrict__ cells, float4* __restrict__ fpress,
-                                                        float4* __restrict__ fvisc, float4* __restrict__ dvel,
-                                                        float4* __restrict__ posi_out, float4* __restrict__ velr_out,
-                                                        float4* __restrict__ pos_by_index, uint32_t tgt_lo,
-                                                        uint32_t tgt_hi, float dt, GridDesc g, Phys ph) {
-    __shared__ float2 s_a[PAIR_WAVES][PIECE];   // x, y
-    __shared__ float2 s_b[PAIR_WAVES][PIECE];   // z, vx
-    __shared__ float2 s_c[PAIR_WAVES][PIECE];   // vy, vz
-    __shared__ float2 s_d[PAIR_WAVES][PIECE];   // p, 1/rho
+__global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
+    const float4* __restrict__ posi, const float4* __restrict__ velr, const float2* __restrict__ dp,
+    const uint32_t* __restrict__ keyS, const uint2* __restrict__ cells, float4* __restrict__ fpress,
+    float4* __restrict__ fvisc, float4* __restrict__ dvel, float4* __restrict__ posi_out,
+    float4* __restrict__ velr_out, float4* __restrict__ pos_by_index, uint32_t tgt_lo, uint32_t tgt_hi, float dt,
+    GridDesc g, Phys ph) {
+    __shared__ float2 s_a[LDS_ENT];   // x, y
+    __shared__ float2 s_b[LDS_ENT];   // z, vx
+    __shared__ float2 s_c[LDS_ENT];   // vy, vz
+    __shared__ float2 s_d[LDS_ENT];   // p, 1/rho
+    for (uint32_t k = threadIdx.x; k < LDS_ENT; k += PAIR_THREADS) {   // see LDS_ENT: keep over-reads finite
+        s_a[k] = make_float2(0.f, 0.f);
+        s_b[k] = make_float2(0.f, 0.f);
+        s_c[k] = make_float2(0.f, 0.f);
+        s_d[k] = make_float2(0.f, 0.f);
+    }
+    __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slice = wave * PIECE;
     const uint32_t i = tgt_lo + (blockIdx.x * PAIR_WAVES + wave) * WAVE + lane;
     const bool active = i < tgt_hi;
     const uint32_t ii = active ? i : tgt_hi - 1;
@@ -226,57 +307,79 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_force(const float4* __restrict
     const float2 dpi = dp[ii];
     Rows R;
     lane_rows(cells, g, keyS[ii], active, R);
-    float2* sa = s_a[wave];
-    float2* sb = s_b[wave];
-    float2* sc = s_c[wave];
-    float2* sd = s_d[wave];
+    Hulls H;
+    wave_hulls(R, H);
+    float4 q0, q1, w0, w1;
+    float2 e0, e1;
     float fpx = 0.f, fpy = 0.f, fpz = 0.f, fvx = 0.f, fvy = 0.f, fvz = 0.f;
     float cvx = 0.f, cvy = 0.f, cvz = 0.f;
     uint32_t ccount = 0;
-#pragma unroll
-    for (int r = 0; r < 9; r++) {
-        const bool has = R.hi[r] > R.lo[r];
-        const uint32_t A = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
-        const uint32_t B = wave_max_u32(has ? R.hi[r] : 0u);
-        for (uint32_t a = A; a < B; a += PIECE) {
-            const uint32_t b = min(a + PIECE, B);
+    traverse(
+        H,
+        [&](uint32_t a) {
+            q0 = posi[a + lane]; q1 = posi[a + WAVE + lane];
+            w0 = velr[a + lane]; w1 = velr[a + WAVE + lane];
+            if (FORCE) { e0 = dp[a + lane]; e1 = dp[a + WAVE + lane]; }
+        },
+        [&]() {
+            s_a[slice + lane] = make_float2(q0.x, q0.y);
+            s_b[slice + lane] = make_float2(q0.z, w0.x);
+            s_c[slice + lane] = make_float2(w0.y, w0.z);
+            s_a[slice + WAVE + lane] = make_float2(q1.x, q1.y);
+            s_b[slice + WAVE + lane] = make_float2(q1.z, w1.x);
+            s_c[slice + WAVE + lane] = make_float2(w1.y, w1.z);
+            if (FORCE) {   // p_j and 1/rho_j (v_rcp_f32); padding entries have rho = 0
+                s_d[slice + lane] = make_float2(e0.y, e0.x > 0.f ? __builtin_amdgcn_rcpf(e0.x) : 0.f);
+                s_d[slice + WAVE + lane] = make_float2(e1.y, e1.x > 0.f ? __builtin_amdgcn_rcpf(e1.x) : 0.f);
+            }
+        },
+        [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
-            if (__ballot(l0 < l1) == 0ull) continue;
-            for (uint32_t k = lane; k < b - a; k += WAVE) {
-                float4 q = posi[a + k];
-                float4 w = velr[a + k];
-                float2 e = dp[a + k];
-                sa[k] = make_float2(q.x, q.y);
-                sb[k] = make_float2(q.z, w.x);
-                sc[k] = make_float2(w.y, w.z);
-                sd[k] = make_float2(e.y, 1.0f / e.x);
-            }
-            wave_lds_sync();
-            for (uint32_t j = l0; j < l1; j++) {
-                const float2 qa = sa[j - a], qb = sb[j - a], qc = sc[j - a], qd = sd[j - a];
-                const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
-                const float r2 = dx * dx + dy * dy + dz * dz;
-                const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
-                if (FORCE) {
-                    const float rinv = r2 > 1e-30f ? __builtin_amdgcn_rsqf(r2) : 0.f;
-                    const float rr = r2 * rinv;
-                    const float hr = r2 < ph.h2 ? ph.h - rr : 0.f;
-                    const float s = ph.spiky_half_mass * (dpi.y + qd.x) * qd.y * hr * hr * rinv;
-                    fpx += s * dx; fpy += s * dy; fpz += s * dz;
-                    const float t = ph.visc_coef * qd.y * hr;
-                    fvx += t * ux; fvy += t * uy; fvz += t * uz;
+            const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
+            const uint32_t T = wave_max_u32(len);
+            const uint32_t off = len ? l0 - a : 0u;
+            uint32_t idx = slice + off;
+            const uint32_t self = i - a - off;     // t + u == self  <=>  candidate slot == own slot
+            for (uint32_t t = 0; t < T; t += SPH_FORCE_UNROLL) {
+#pragma unroll
+                for (int u = 0; u < SPH_FORCE_UNROLL; u++) {
+                    const float2 qa = s_a[idx + u], qb = s_b[idx + u], qc = s_c[idx + u];
+                    const bool valid = t + u < len;
+                    const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
+                    const float r2 = dx * dx + dy * dy + dz * dz;
+                    const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
+                    if (FORCE) {
+                        const float2 qd = s_d[idx + u];
+                        const bool in = valid && r2 < ph.h2;
+                        const float rinv = r2 > 1e-30f ? inv_sqrt(r2) : 0.f;
+                        const float hr = ph.h - r2 * rinv;
+                        const float k = qd.y * hr;
+                        float s = ph.spiky_half_mass * (dpi.y + qd.x) * k * hr * rinv;
+                        float w = ph.visc_coef * k;
+                        s = in ? s : 0.f;
+                        w = in ? w : 0.f;
+                        fpx += s * dx; fpy += s * dy; fpz += s * dz;
+                        fvx += w * ux; fvy += w * uy; fvz += w * uz;
+                    }
+                    if (COLL) {
+#if SPH_COLL_EXACT
+                        // the reference's own association, one rounding per operation (no FMA):
+                        // x*x + (y*y + z*z), Eigen redux order
+                        const float r2c = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
+                        const float dot = -__fadd_rn(__fmul_rn(dx, ux), __fadd_rn(__fmul_rn(dy, uy), __fmul_rn(dz, uz)));
+#else
+                        const float r2c = r2;
+                        const float dot = -(dx * ux + dy * uy + dz * uz);               // r_ij . (v_i - v_j)
+#endif
+                        const bool hit = valid && (t + u != self) && (r2c <= ph.coll_dist2) && (dot < 0.f);
+                        const float cfac = hit ? ph.coll_mass * dot * __builtin_amdgcn_rcpf(r2c) : 0.f;
+                        cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
+                        ccount += hit ? 1u : 0u;
+                    }
                 }
-                if (COLL) {
-                    const float dot = -(dx * ux + dy * uy + dz * uz);               // r_ij . (v_i - v_j)
-                    const bool hit = (j != i) && (r2 <= ph.coll_dist2) && (dot < 0.f);
-                    const float cfac = hit ? ph.coll_mass * dot * __builtin_amdgcn_rcpf(r2) : 0.f;
-                    cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
-                    ccount += hit ? 1u : 0u;
-                }
+                idx += SPH_FORCE_UNROLL;
             }
-            wave_lds_sync();
-        }
-    }
+        });
     if (!active) return;
     float dvx = 0.f, dvy = 0.f, dvz = 0.f;
     if (COLL) {
@@ -287,7 +390,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_force(const float4* __restrict
         integrate_one(ph, dt, pi, vi, dpi.x, fpx + fvx, fpy + fvy, fpz + fvz, dvx, dvy, dvz);
         posi_out[i] = pi;
         velr_out[i] = vi;
-        pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
+        if (pos_by_index) pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
     } else {
         if (FORCE) {
             fpress[i] = make_float4(fpx, fpy, fpz, 0.f);
@@ -303,7 +406,7 @@ int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt)
     dim3 grid(ceil_div(c->n, PAIR_THREADS)), block(PAIR_THREADS);
 #define SPH_LAUNCH_FORCE(F, C, I)                                                                              \
     hipLaunchKernelGGL((k_force<F, C, I>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->keyS, c->cells, \
-                       c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->pos_out, lo, hi, dt, c->grid, c->phys)
+                       c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, lo, hi, dt, c->grid, c->phys)
     if (force && collide && integrate) SPH_LAUNCH_FORCE(true, true, true);
     else if (force && !collide && !integrate) SPH_LAUNCH_FORCE(true, false, false);
     else if (!force && collide && !integrate) SPH_LAUNCH_FORCE(false, true, false);
@@ -334,13 +437,13 @@ __global__ __launch_bounds__(256) void k_integrate(float4* __restrict__ posi, fl
     integrate_one(ph, dt, pi, vi, dp[i].x, fp.x + fv.x, fp.y + fv.y, fp.z + fv.z, dv.x, dv.y, dv.z);
     posi[i] = pi;
     velr[i] = vi;
-    pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
+    if (pos_by_index) pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
 }
 
 int launch_integrate(sph_ctx* c, float dt) {
     if (c->n == 0) return SPH_OK;
     hipLaunchKernelGGL(k_integrate, dim3(ceil_div(c->n, 256)), dim3(256), 0, c->stream, c->posi, c->velr, c->dp,
-                       c->fpress, c->fvisc, c->dvel, c->pos_out, c->own_off, c->own_off + c->n, dt, c->phys);
+                       c->fpress, c->fvisc, c->dvel, c->slab ? nullptr : c->pos_out, c->own_off, c->own_off + c->n, dt, c->phys);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
 }
