@@ -33,7 +33,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj])
+            if s in CXX_SOURCES:   # plain host C++ (no HIP headers); ICs must match ic.py bit for bit
+                jobs.append([HIPCC, "-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off", "-x", "c++",
+                             "-c", src, "-o", obj])
+            else:
+                jobs.append([HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -44,6 +48,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs)
+    # headless driver with the reference's command line (SPH/particles.cpp)
+    exe, main_src = os.path.join(HERE, "sph_headless"), os.path.join(CSRC, "sph_headless.cpp")
+    if os.path.exists(main_src) and (force or _stale(exe, [main_src, LIB] + headers)):
+        run([HIPCC, "-O2", "-std=c++17", "-x", "c++", main_src, "-x", "none", "-o", exe, "-L" + HERE, "-lsph_hip",
+             "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

@@ -79,6 +79,9 @@ SIGNATURES = {
     "sph_halo_pack_density": (C.c_int, [_P, C.POINTER(_P), _U32]),
     "sph_halo_unpack_density": (C.c_int, [_P, _P, _P]),
     "sph_layer_histogram": (C.c_int, [_P, _P, _U32]),
+    # include/particleSystem.h: host-only twins of ic.py (used by the C++ class's reset())
+    "sph_ic_dam_break": (None, [C.POINTER(_U32), C.POINTER(C.c_float), C.c_int, C.c_uint64, C.c_uint64, _P, _P]),
+    "sph_ic_random_box": (None, [C.c_uint64, C.POINTER(C.c_float), C.c_float, _U32, C.c_float, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,77 @@
+// sph_headless.cpp -- headless driver with the reference's command line
+// (SPH/particles.cpp:676-706: -n= -box= -i= -benchmark -device=) and its runBenchmark()
+// output line (:176-192), on top of include/particleSystem.h.  No GLUT / OpenGL.
+//   sph_headless -benchmark -n=262144 -box=8 -i=100 [-steps=1] [-dump=8] [-log=benchmark.txt]
+#include "../../include/particleSystem.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+static bool flag(int argc, char** argv, const char* name) {   // checkCmdLineFlag, helper_string.h:111
+    for (int i = 1; i < argc; i++) {
+        const char* a = argv[i];
+        while (*a == '-') a++;
+        size_t l = strlen(name);
+        if (!strncmp(a, name, l) && (a[l] == 0 || a[l] == '=')) return true;
+    }
+    return false;
+}
+
+static const char* value(int argc, char** argv, const char* name) {
+    for (int i = 1; i < argc; i++) {
+        const char* a = argv[i];
+        while (*a == '-') a++;
+        size_t l = strlen(name);
+        if (!strncmp(a, name, l) && a[l] == '=') return a + l + 1;
+    }
+    return nullptr;
+}
+
+int main(int argc, char** argv) {
+    uint numParticles = 262144;            // NUM_PARTICLES, particleSystem.h:15
+    float box = 2.0f;                      // BOX_SIZE
+    int iterations = 100, substeps = 1, dump = 0;
+    const float timestep = 0.0000005f;     // particles.cpp:88
+    if (const char* v = value(argc, argv, "n")) numParticles = (uint)strtoul(v, nullptr, 10);
+    if (const char* v = value(argc, argv, "box")) box = (float)atof(v);
+    if (const char* v = value(argc, argv, "i")) iterations = atoi(v);
+    if (const char* v = value(argc, argv, "steps")) substeps = atoi(v);
+    if (const char* v = value(argc, argv, "dump")) dump = atoi(v);
+    const bool benchmark = flag(argc, argv, "benchmark");
+    if (flag(argc, argv, "help")) {
+        printf("usage: sph_headless [-benchmark] [-n=<particles>] [-box=<edge>] [-i=<iterations>] [-steps=<per update>] "
+               "[-dump=<count>] [-log=<file>]\n");
+        return 0;
+    }
+    int is950 = 0;
+    if (sph_device_count(&is950) <= 0 || !is950) {
+        fprintf(stderr, "No gfx950 (MI355X) device found, exiting\n");   // cudaInit, particleSystem.cu:432-435
+        return EXIT_FAILURE;
+    }
+    ParticleSystem* psystem = new ParticleSystem(numParticles, make_float3(box, box, box), ParticleSystem::HIP_PARALLEL);
+    psystem->reset(ParticleSystem::CONFIG_GRID);          // initParticleSystem, particles.cpp:119-132
+    psystem->setIterations(substeps);
+    if (const char* v = value(argc, argv, "log")) psystem->setBenchmarkLog(v);
+    uint3 g = psystem->getGridSize();
+    printf("Run %u particles simulation for %d iterations... (grid %ux%ux%u, box %g)\n\n", numParticles, iterations, g.x, g.y, g.z, box);
+    psystem->update(timestep, 0);                         // warm-up, not timed
+    sph_sync(psystem->context());
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iterations; ++i) psystem->update(timestep, (float)i);
+    sph_sync(psystem->context());
+    auto t1 = std::chrono::steady_clock::now();
+    const double secs = std::chrono::duration<double>(t1 - t0).count();
+    const double avg = secs / (iterations > 0 ? iterations : 1);
+    // the reference's line, particles.cpp:191-192
+    printf("particles, Throughput = %.4f KParticles/s, Time = %.5f s, Size = %u particles, NumDevsUsed = %u, Workgroup = %u\n",
+           (1.0e-3 * numParticles) / avg, avg, numParticles, 1, 0);
+    printf("{\"particle_steps_per_s\": %.1f, \"particles\": %u, \"iterations\": %d, \"steps_per_update\": %d, \"seconds\": %.6f}\n",
+           (double)numParticles * iterations * substeps / secs, numParticles, iterations, substeps, secs);
+    if (dump > 0) psystem->dumpParticles(0, (uint)dump);
+    (void)benchmark;
+    delete psystem;
+    return 0;
+}
