@@ -67,10 +67,12 @@ SIGNATURES = {
     "sph_integrate": (C.c_int, [_P, C.c_float]),
     "sph_step": (C.c_int, [_P, C.c_float, _U32]),
     "sph_step_phased": (C.c_int, [_P, C.c_float, _U32]),
+    "sph_force_collide_integrate": (C.c_int, [_P, C.c_float]),
     "sph_timing_enable": (C.c_int, [_P, C.c_int]),
     "sph_timing_get": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U32)]),
     "sph_timing_reset": (C.c_int, [_P]),
     "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
+    "sph_slab_counts": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_migrants_pack": (C.c_int, [_P, C.POINTER(_P), _U32]),
     "sph_migrants_append": (C.c_int, [_P, _P, _U32]),
     "sph_halo_count": (C.c_int, [_P, C.POINTER(_U32)]),
@@ -266,6 +268,13 @@ class Context:
         cnt = (_U32 * 2)()
         _check(fn(self.h, cnt, *a))
         return int(cnt[0]), int(cnt[1])
+
+    def slab_counts(self):
+        cnt = (_U32 * 4)()
+        _check(self.L.sph_slab_counts(self.h, cnt))
+        return tuple(int(v) for v in cnt)
+
+    def force_collide_integrate(self, dt): _check(self.L.sph_force_collide_integrate(self.h, float(dt)))
 
     def migrants_count(self): return self._pair(self.L.sph_migrants_count)
     def halo_count(self): return self._pair(self.L.sph_halo_count)

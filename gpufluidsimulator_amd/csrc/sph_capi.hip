@@ -590,6 +590,18 @@ int sph_step(sph_ctx* c, float dt, uint32_t n_steps) {
     return SPH_OK;
 }
 
+int sph_force_collide_integrate(sph_ctx* c, float dt) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(c->stage >= sph_ctx::ST_CELLS && c->have_dens, SPH_E_STATE,
+                "sph_force_collide_integrate needs sph_density first");
+    SPH_HIP(hipSetDevice(c->device));
+    PhaseTimer t(c, SPH_PH_FORCE);
+    int rc = launch_force(c, true, true, true, dt);
+    if (rc) return rc;
+    c->have_force = c->have_coll = false;
+    return SPH_OK;
+}
+
 int sph_step_phased(sph_ctx* c, float dt, uint32_t n_steps) {
     for (uint32_t s = 0; s < n_steps; s++) {
         int rc = sph_hash(c);

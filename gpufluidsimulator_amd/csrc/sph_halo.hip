@@ -86,6 +86,20 @@ int sph_migrants_count(sph_ctx* c, uint32_t count[2]) {
     return SPH_OK;
 }
 
+int sph_slab_counts(sph_ctx* c, uint32_t count[4]) {
+    SPH_REQUIRE(c && count, SPH_E_INVALID, "null argument");
+    SPH_REQUIRE(c->stage == sph_ctx::ST_SORTED, SPH_E_STATE, "sph_slab_counts needs sph_sort first");
+    const uint32_t layer = c->grid.g[0] * c->grid.g[1];
+    uint32_t tg[4] = {layer, 2 * layer, (c->grid.zl - 2) * layer, (c->grid.zl - 1) * layer}, lb[4];
+    int rc = lower_bounds(c, tg, 4, lb);
+    if (rc) return rc;
+    count[0] = lb[0];
+    count[1] = lb[1] - lb[0];
+    count[2] = lb[3] - lb[2];
+    count[3] = c->n - lb[3];
+    return SPH_OK;
+}
+
 int sph_migrants_pack(sph_ctx* c, void* buf_dev[2], uint32_t capacity) {
     SPH_REQUIRE(c && buf_dev, SPH_E_INVALID, "null argument");
     uint32_t m[2];

@@ -62,15 +62,19 @@ def uniform01(counter: np.ndarray, stream: int, seed: int = SEED) -> np.ndarray:
     return (k >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
 
 
-def dam_break_lattice(lattice, box, jitter: bool = True, start: int = 0, count: int | None = None):
+def dam_break_lattice(lattice, box, jitter: bool = True, start: int = 0, count: int | None = None,
+                      jitter_dims=None):
     """Positions/velocities of an (nx, ny, nz) lattice in the min corner of a box
     of dimensions ``box`` centred on the origin.
 
     Returns (pos[n,3] float32, vel[n,3] float32) for particle indices
     ``start .. start+count`` (default: all), index = x + nx*(y + ny*z).
+    ``jitter_dims`` replaces the box dimensions in the jitter term only (the reference scales the
+    jitter with the box, which on a box stretched along z for weak scaling would exceed the spacing).
     """
     nx, ny, nz = (int(v) for v in lattice)
     w = np.asarray(box, dtype=np.float32).reshape(3)
+    wj = w if jitter_dims is None else np.asarray(jitter_dims, dtype=np.float32).reshape(3)
     n_total = nx * ny * nz
     if count is None:
         count = n_total - start
@@ -86,7 +90,7 @@ def dam_break_lattice(lattice, box, jitter: bool = True, start: int = 0, count: 
         base = (SPACING * ia + PARTICLE_RADIUS) + box_min[a]
         if jitter:
             u = uniform01(cnt, a)
-            base = base + (w[a] * u - w[a] / np.float32(2.0)) * jit
+            base = base + (wj[a] * u - wj[a] / np.float32(2.0)) * jit
         pos[:, a] = base
     vel = np.zeros((count, 3), dtype=np.float32)
     return pos, vel
@@ -127,4 +131,4 @@ def weak_scaling_config(n_gpus: int, per_gpu=(256, 256, 256)):
     gy = grid_dim_for_box(ny / 8.0)
     gz1 = grid_dim_for_box(nz / 8.0)
     return dict(lattice=(nx, ny, nz * n_gpus), box=(gx / 16.0, gy / 16.0, gz1 * n_gpus / 16.0),
-                grid=(gx, gy, gz1 * n_gpus), steps=20)
+                grid=(gx, gy, gz1 * n_gpus), steps=20, jitter_dims=(gx / 16.0, gy / 16.0, gz1 / 16.0))

@@ -1,0 +1,412 @@
+"""z-slab domain decomposition of the SPH step across the GPUs of one node.
+
+No counterpart in the reference (single GPU): this is new work on top of the
+C ABI's halo entry points (include/sph_hip.h, csrc/sph_halo.hip).
+
+One process per GPU.  Rank r owns the cell layers [cuts[r], cuts[r+1]) of the global grid (cuts are
+count-balanced from a per-layer particle histogram, because a dam break fills only a quarter of
+the box).  Interaction reach is one cell layer (3x3x3 stencil), so per step a rank exchanges with
+its two z-neighbours only, point to point (torch.distributed send/recv = RCCL over the direct xGMI
+link); no collective sits on the data path:
+
+    hash + sort owned particles           (local keys: z slowest, so leavers sit at the array ends)
+    [counts]    one tiny message per neighbour: {#migrants to you, #my boundary-layer particles}
+    [migrants]  particles whose cell left the slab move to the neighbour (8-float records)
+    [halo A]    boundary layers -> neighbour's ghost layers (positions, velocities, indices)
+    cell table over ghosts + owned ; density pass over owned
+    [halo B]    (density, pressure) of the same boundary particles
+    fused force + collision + integrate over owned
+
+The per-rank compute engine is pluggable ONLY so that tests can drive this protocol on CPU ranks
+(gloo) with the oracle behind it; the product engine is `HipEngine` (libsph_hip.so) and nothing
+else is ever chosen implicitly: without a gfx950 device `HipEngine` raises.
+"""
+from __future__ import annotations
+
+import json
+import os
+import queue
+import threading
+import time
+
+import numpy as np
+
+from . import capi, ic
+
+REC = capi.HALO_RECORD_FLOATS
+
+
+# ------------------------------------------------------------------------------------------------
+# partitioning
+# ------------------------------------------------------------------------------------------------
+def cell_layer_of(z, box_z, gz):
+    """Global z cell layer with the device's arithmetic (csrc/sph_device.hpp cell_coord): subtract
+    boxMin, divide by the box dimension, multiply by the grid size, floor, clamp -- all in fp32."""
+    z = np.asarray(z, dtype=np.float32)
+    bmin = np.float32(-np.float32(box_z) / np.float32(2.0))
+    bdim = np.float32(np.float32(box_z) / np.float32(2.0)) - bmin
+    q = ((z - bmin) / bdim) * np.float32(gz)
+    return np.clip(np.floor(q).astype(np.int64), 0, int(gz) - 1)
+
+
+def choose_cuts(hist, world):
+    """Count-balanced slab boundaries: cuts[r] .. cuts[r+1] are rank r's cell layers."""
+    hist = np.asarray(hist, dtype=np.int64)
+    gz, total = hist.shape[0], int(hist.sum())
+    if world > gz:
+        raise ValueError(f"{world} ranks but only {gz} cell layers")
+    prefix = np.concatenate([[0], np.cumsum(hist)])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        z = int(np.searchsorted(prefix, target, side="left"))
+        # the boundary that splits the counts best: z or z-1
+        if z > 0 and abs(prefix[z - 1] - target) <= abs(prefix[min(z, gz)] - target):
+            z -= 1
+        z = max(z, cuts[-1] + 1)              # every slab keeps at least one layer
+        z = min(z, gz - (world - r))
+        cuts.append(z)
+    cuts.append(gz)
+    return [int(c) for c in cuts]
+
+
+# ------------------------------------------------------------------------------------------------
+# communication back ends (same three calls)
+# ------------------------------------------------------------------------------------------------
+class TorchDistComm:
+    """torch.distributed point-to-point; backend "nccl" is RCCL on ROCm (xGMI), "gloo" on CPU."""
+
+    def __init__(self, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device
+
+    def exchange(self, sends, recvs):
+        """sends/recvs: lists of (peer, tensor); returns when all of them have completed."""
+        dist = self.dist
+        ops = [dist.P2POp(dist.irecv, t, p) for p, t in recvs if t.numel()]
+        ops += [dist.P2POp(dist.isend, t, p) for p, t in sends if t.numel()]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def allreduce_sum(self, arr):
+        t = self.torch.as_tensor(np.ascontiguousarray(arr)).to(self.device)
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def allreduce_max(self, x):
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+class LocalComm:
+    """In-process ranks (one thread each): lets several slabs share ONE GPU, or CPU test engines run
+    without a process group.  Same semantics as TorchDistComm."""
+
+    class Hub:
+        def __init__(self, world):
+            self.world = world
+            self.q = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+            self.bar = threading.Barrier(world)
+            self.lock = threading.Lock()
+            self.acc = {}
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank, self.world = hub, rank, hub.world
+
+    def exchange(self, sends, recvs):
+        done = []
+        for p, t in sends:
+            if t.numel():
+                ev = threading.Event()
+                self.hub.q[(self.rank, p)].put((t, ev))
+                done.append(ev)
+        for p, t in recvs:
+            if t.numel():
+                src, ev = self.hub.q[(p, self.rank)].get(timeout=120)
+                assert src.numel() == t.numel(), (src.shape, t.shape)
+                t.copy_(src.reshape(t.shape))
+                ev.set()
+        for ev in done:                        # a sender's buffer stays untouched until it was copied
+            if not ev.wait(timeout=120):
+                raise TimeoutError("LocalComm: a message was never received")
+
+    def _allreduce(self, key, value, fn):
+        with self.hub.lock:
+            self.hub.acc.setdefault(key, []).append(value)
+        self.hub.bar.wait()
+        out = fn(self.hub.acc[key])
+        self.hub.bar.wait()
+        if self.rank == 0:
+            self.hub.acc.pop(key, None)
+        self.hub.bar.wait()
+        return out
+
+    def allreduce_sum(self, arr):
+        return self._allreduce("sum", np.asarray(arr), lambda xs: np.sum(xs, axis=0))
+
+    def allreduce_max(self, x):
+        return self._allreduce("max", float(x), max)
+
+    def barrier(self):
+        self.hub.bar.wait()
+
+
+# ------------------------------------------------------------------------------------------------
+# product engine: libsph_hip.so
+# ------------------------------------------------------------------------------------------------
+class HipEngine:
+    """One z-slab on one MI355X through the C ABI.  Buffers handed to the halo calls are torch
+    CUDA tensors (plumbing: device memory + RCCL); all arithmetic is in the HIP library."""
+
+    def __init__(self, capacity, ghost_capacity, params, z_lo, z_hi, device_index=0):
+        import torch
+        n_dev, is950 = capi.device_count()
+        if n_dev <= 0 or not is950:
+            raise capi.SphError("HipEngine needs a gfx950 (MI355X) device: there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        self.ctx = capi.Context(capacity, params=params, device=device_index, slab=(z_lo, z_hi),
+                                ghost_capacity=ghost_capacity)
+        self.ghost_capacity = ghost_capacity
+
+    def buffer(self, rows, cols):
+        return self.torch.zeros((rows, cols), dtype=self.torch.float32, device=self.device)
+
+    def small(self, values):
+        return self.torch.tensor(values, dtype=self.torch.int64, device=self.device)
+
+    @staticmethod
+    def ptr(t):
+        return t.data_ptr()
+
+    @property
+    def n(self): return self.ctx.n
+    def upload(self, pos, vel, index): self.ctx.upload(pos, vel, index)
+    def hash(self): self.ctx.hash()
+    def sort(self): self.ctx.sort()
+    def build_cells(self): self.ctx.build_cells()
+    def density(self): self.ctx.density()
+    def slab_counts(self): return self.ctx.slab_counts()
+    def migrants_pack(self, lo, hi): self.ctx.migrants_pack(self.ptr(lo), self.ptr(hi), lo.shape[0])
+    def migrants_append(self, buf, n): self.ctx.migrants_append(self.ptr(buf), n)
+    def halo_pack(self, lo, hi): self.ctx.halo_pack(self.ptr(lo), self.ptr(hi), lo.shape[0])
+    def halo_unpack(self, lo, n_lo, hi, n_hi): self.ctx.halo_unpack(self.ptr(lo), n_lo, self.ptr(hi), n_hi)
+    def halo_pack_density(self, lo, hi): self.ctx.halo_pack_density(self.ptr(lo), self.ptr(hi), lo.shape[0])
+    def halo_unpack_density(self, lo, hi): self.ctx.halo_unpack_density(self.ptr(lo), self.ptr(hi))
+
+    def force_collide_integrate(self, dt): self.ctx.force_collide_integrate(dt)
+
+    def sync(self): self.ctx.sync()
+
+    def download(self, total):
+        return self.ctx.download(index_base=0, count=total)
+
+    def close(self): self.ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the per-rank driver
+# ------------------------------------------------------------------------------------------------
+class SlabSimulation:
+    def __init__(self, comm, engine_factory, box, grid, lattice=None, jitter=True, jitter_dims=None,
+                 capacity_factor=1.5, ghost_factor=3.0, particles=None):
+        """comm: TorchDistComm | LocalComm.  engine_factory(capacity, ghost_capacity, params, z_lo, z_hi)
+        builds this rank's engine.  Either `lattice` (dam break generated slab by slab) or
+        `particles` = (pos, vel) of the WHOLE system (small tests)."""
+        self.comm = comm
+        self.rank, self.world = comm.rank, comm.world
+        self.box = tuple(float(b) for b in box)
+        self.grid = tuple(int(g) for g in grid)
+        self.params = capi.default_params(self.box, self.grid)
+        gz = self.grid[2]
+
+        if particles is not None:
+            pos_all, vel_all = particles
+            self.total = int(pos_all.shape[0])
+            layers = cell_layer_of(pos_all[:, 2], self.box[2], gz)
+            hist = np.bincount(layers, minlength=gz)
+            self.cuts = choose_cuts(hist, self.world)
+            z_lo, z_hi = self.cuts[self.rank], self.cuts[self.rank + 1]
+            mine = np.nonzero((layers >= z_lo) & (layers < z_hi))[0]
+            pos, vel, index = pos_all[mine], vel_all[mine], mine.astype(np.uint32)
+        else:
+            nx, ny, nz = (int(v) for v in lattice)
+            self.total = nx * ny * nz
+            jd = jitter_dims if jitter_dims is not None else self.box
+            # per-layer histogram from the z coordinates of one lattice column per z (x,y do not matter
+            # for z jitter? they do: the jitter is per particle) -> exact: every rank hashes its share
+            share = -(-nz // self.world)
+            iz0, iz1 = min(self.rank * share, nz), min((self.rank + 1) * share, nz)
+            hist = np.zeros(gz, dtype=np.int64)
+            for iz in range(iz0, iz1):
+                p, _ = ic.dam_break_lattice((nx, ny, nz), self.box, jitter, start=iz * nx * ny, count=nx * ny,
+                                            jitter_dims=jd)
+                hist += np.bincount(cell_layer_of(p[:, 2], self.box[2], gz), minlength=gz)
+            hist = comm.allreduce_sum(hist).astype(np.int64)
+            self.cuts = choose_cuts(hist, self.world)
+            z_lo, z_hi = self.cuts[self.rank], self.cuts[self.rank + 1]
+            # lattice layers that can reach this slab: every layer whose particles hashed into it
+            spacing, radius = float(ic.SPACING), float(ic.PARTICLE_RADIUS)
+            amp = 0.5 * float(jd[2]) * 0.01 * radius if jitter else 0.0
+            zc = -self.box[2] / 2 + radius + spacing * np.arange(nz)
+            lo_l = cell_layer_of(zc - amp - 1e-4, self.box[2], gz)
+            hi_l = cell_layer_of(zc + amp + 1e-4, self.box[2], gz)
+            cand = np.nonzero((hi_l >= z_lo) & (lo_l < z_hi))[0]
+            chunks_p, chunks_i = [], []
+            for iz in cand:
+                start = int(iz) * nx * ny
+                p, _ = ic.dam_break_lattice((nx, ny, nz), self.box, jitter, start=start, count=nx * ny, jitter_dims=jd)
+                lay = cell_layer_of(p[:, 2], self.box[2], gz)
+                keep = (lay >= z_lo) & (lay < z_hi)
+                chunks_p.append(p[keep])
+                chunks_i.append((start + np.nonzero(keep)[0]).astype(np.uint32))
+            pos = np.concatenate(chunks_p) if chunks_p else np.zeros((0, 3), np.float32)
+            index = np.concatenate(chunks_i) if chunks_i else np.zeros((0,), np.uint32)
+            vel = np.zeros_like(pos)
+        self.z_lo, self.z_hi = z_lo, z_hi
+        n_own = int(pos.shape[0])
+        per_layer = max(int(hist.max()), 1)
+        self.ghost_capacity = int(ghost_factor * per_layer) + 1024
+        self.capacity = int(capacity_factor * max(n_own, self.total // self.world)) + 4096
+        self.engine = engine_factory(self.capacity, self.ghost_capacity, self.params, z_lo, z_hi)
+        self.engine.upload(pos, vel, index)
+        e = self.engine
+        g = self.ghost_capacity
+        self.send_lo, self.send_hi = e.buffer(g, REC), e.buffer(g, REC)
+        self.recv_lo, self.recv_hi = e.buffer(g, REC), e.buffer(g, REC)
+        self.dsend_lo, self.dsend_hi = e.buffer(g, 2), e.buffer(g, 2)
+        self.drecv_lo, self.drecv_hi = e.buffer(g, 2), e.buffer(g, 2)
+        self.cnt_recv_lo, self.cnt_recv_hi = e.small([0, 0]), e.small([0, 0])
+        self.lo_peer = self.rank - 1 if self.rank > 0 else None
+        self.hi_peer = self.rank + 1 if self.rank + 1 < self.world else None
+        self.stats = {"migrants": 0, "resorts": 0, "ghosts": 0}
+
+    # -- one time step ---------------------------------------------------------------------------------
+    def step(self, dt):
+        e, c = self.engine, self.comm
+        lo, hi = self.lo_peer, self.hi_peer
+        e.hash(); e.sort()
+        m_lo, own_lo, own_hi, m_hi = e.slab_counts()
+        if lo is None: assert m_lo == 0, "particles below the box floor"
+        if hi is None: assert m_hi == 0, "particles above the box ceiling"
+        # counts: {migrants towards the peer, my boundary-layer particles that stay}
+        sends, recvs = [], []
+        if lo is not None:
+            sends.append((lo, e.small([m_lo, own_lo]))); recvs.append((lo, self.cnt_recv_lo))
+        if hi is not None:
+            sends.append((hi, e.small([m_hi, own_hi]))); recvs.append((hi, self.cnt_recv_hi))
+        c.exchange(sends, recvs)
+        in_lo, peer_own_lo = (int(v) for v in self.cnt_recv_lo.tolist()) if lo is not None else (0, 0)
+        in_hi, peer_own_hi = (int(v) for v in self.cnt_recv_hi.tolist()) if hi is not None else (0, 0)
+        g = self.ghost_capacity
+        assert max(m_lo, m_hi, in_lo, in_hi) <= g, "migrant burst exceeds the ghost capacity"
+        # migrants
+        if m_lo or m_hi or in_lo or in_hi:
+            e.migrants_pack(self.send_lo, self.send_hi)
+            sends, recvs = [], []
+            if lo is not None:
+                sends.append((lo, self.send_lo[:m_lo])); recvs.append((lo, self.recv_lo[:in_lo]))
+            if hi is not None:
+                sends.append((hi, self.send_hi[:m_hi])); recvs.append((hi, self.recv_hi[:in_hi]))
+            c.exchange(sends, recvs)
+            if in_lo: e.migrants_append(self.recv_lo, in_lo)
+            if in_hi: e.migrants_append(self.recv_hi, in_hi)
+            if in_lo or in_hi:
+                e.hash(); e.sort()               # newcomers are merged by a second sort (rare, small)
+                self.stats["resorts"] += 1
+            self.stats["migrants"] += m_lo + m_hi
+        # halo A: boundary layers.  What I send = what stayed in my boundary layer + what arrived in it;
+        # the peer knows both numbers (it sent me the second one), so no further count message.
+        h_lo, h_hi = own_lo + in_lo, own_hi + in_hi
+        gl, gh = peer_own_lo + m_lo, peer_own_hi + m_hi     # ghosts I receive
+        assert max(h_lo, h_hi, gl, gh) <= g, "boundary layer exceeds the ghost capacity"
+        e.halo_pack(self.send_lo, self.send_hi)
+        sends, recvs = [], []
+        if lo is not None:
+            sends.append((lo, self.send_lo[:h_lo])); recvs.append((lo, self.recv_lo[:gl]))
+        if hi is not None:
+            sends.append((hi, self.send_hi[:h_hi])); recvs.append((hi, self.recv_hi[:gh]))
+        c.exchange(sends, recvs)
+        e.halo_unpack(self.recv_lo, gl if lo is not None else 0, self.recv_hi, gh if hi is not None else 0)
+        self.stats["ghosts"] += gl + gh
+        e.build_cells()
+        e.density()
+        # halo B: density + pressure of the same boundary particles, same order
+        e.halo_pack_density(self.dsend_lo, self.dsend_hi)
+        sends, recvs = [], []
+        if lo is not None:
+            sends.append((lo, self.dsend_lo[:h_lo])); recvs.append((lo, self.drecv_lo[:gl]))
+        if hi is not None:
+            sends.append((hi, self.dsend_hi[:h_hi])); recvs.append((hi, self.drecv_hi[:gh]))
+        c.exchange(sends, recvs)
+        e.halo_unpack_density(self.drecv_lo, self.drecv_hi)
+        e.force_collide_integrate(dt)
+
+    def run(self, dt, steps):
+        for _ in range(steps):
+            self.step(dt)
+
+    def gather_state(self):
+        """Every rank's owned particles by creation index (NaN elsewhere) -> combined on all ranks."""
+        st = self.engine.download(self.total)
+        out = {}
+        for k, v in st.items():
+            filled = np.where(np.isnan(v), 0.0, v).astype(np.float64)
+            have = (~np.isnan(v)).astype(np.float64)
+            s = self.comm.allreduce_sum(filled)
+            h = self.comm.allreduce_sum(have)
+            assert np.all(h == 1.0), f"{k}: {int((h != 1.0).sum())} entries owned by != 1 rank"
+            out[k] = s.astype(np.float32)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# bench entry (bench.py --gpus N, one rank per GPU under torch.distributed.run)
+# ------------------------------------------------------------------------------------------------
+def bench_main(args):
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    comm = TorchDistComm(torch.device("cuda", local))
+    cfg = ic.weak_scaling_config(world)
+    sim = SlabSimulation(comm, lambda cap, gcap, p, z0, z1: HipEngine(cap, gcap, p, z0, z1, local),
+                         cfg["box"], cfg["grid"], lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"])
+    dt = float(ic.DEFAULT_DT)
+    sim.run(dt, args.warmup)
+    sim.engine.sync(); torch.cuda.synchronize(); comm.barrier()
+    t0 = time.perf_counter()
+    sim.run(dt, args.steps)
+    sim.engine.sync(); torch.cuda.synchronize(); comm.barrier()
+    wall = comm.allreduce_max(time.perf_counter() - t0)
+    n_own = sim.engine.n
+    counts = comm.allreduce_sum(np.array([n_own], dtype=np.int64))
+    if rank == 0:
+        total = sim.total
+        out = {
+            "metric": "particle-steps/sec", "value": total * args.steps / wall, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"dam-break, {cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} = {total} "
+                                   f"particles ({total // world} per GPU), grid {cfg['grid']}, z-slabs with ghost layers "
+                                   f"over RCCL send/recv",
+                       "particles": total, "grid": list(cfg["grid"]), "cuts": sim.cuts,
+                       "parallelism": f"{world} z-slabs, one per GPU"},
+            "slab_stats": sim.stats, "owned_sum": int(counts[0]),
+        }
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()

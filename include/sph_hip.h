@@ -147,6 +147,9 @@ int sph_integrate(sph_ctx* c, float dt);
 int sph_step(sph_ctx* c, float dt, uint32_t n_steps);
 /* same, phase by phase (the exact call sequence of particleSystem.cpp:773-795) */
 int sph_step_phased(sph_ctx* c, float dt, uint32_t n_steps);
+/* the fused tail of sph_step on its own: force + collision + integrate in one neighbour traversal
+ * (needs sph_density; slab drivers call it after the density halo exchange) */
+int sph_force_collide_integrate(sph_ctx* c, float dt);
 
 /* ---- device timing (replaces the host-side TIME_FUNCTION macros, particleSystem.h:20-24,
  *      which time launches, not kernels) ------------------------------------------------------ */
@@ -161,6 +164,9 @@ int sph_timing_reset(sph_ctx* c);
 #define SPH_HALO_RECORD_FLOATS 8
 /* after sph_hash + sph_sort: number of owned particles that left the slab through `side` */
 int sph_migrants_count(sph_ctx* c, uint32_t count[2]);
+/* everything a slab driver needs after the sort, in one device round trip:
+ * {migrants down, owned in the lowest layer, owned in the highest layer, migrants up} */
+int sph_slab_counts(sph_ctx* c, uint32_t count[4]);
 /* pack them into buf_dev[side] (device, capacity records each) and drop them */
 int sph_migrants_pack(sph_ctx* c, void* buf_dev[2], uint32_t capacity);
 /* append n received particles (device records) to the owned set; call sph_hash+sph_sort again */

@@ -1,0 +1,192 @@
+"""TEST INFRASTRUCTURE: a CPU stand-in for the per-rank engine of gpufluidsimulator_amd.slab, with the
+oracle behind it, so that the slab PROTOCOL (cuts, counts, migrants, ghost layers, density halo) can be
+driven by CPU ranks (gloo / in-process).  Never imported by the product package."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from gpufluidsimulator_amd import slab  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def _cell(p, bmin, bdim, g):
+    q = ((p.astype(np.float32) - np.float32(bmin)) / np.float32(bdim)) * np.float32(g)
+    return np.clip(np.floor(q).astype(np.int64), 0, int(g) - 1)
+
+
+class OracleEngine:
+    def __init__(self, capacity, ghost_capacity, params, z_lo, z_hi):
+        self.grid = tuple(int(v) for v in params.grid)
+        self.bmin = np.float32(list(params.box_min))
+        self.bdim = np.float32(list(params.box_max)) - self.bmin
+        self.box = tuple(float(v) for v in self.bdim)
+        self.z_lo, self.z_hi, self.zl = int(z_lo), int(z_hi), int(z_hi - z_lo + 2)
+        self.layer = self.grid[0] * self.grid[1]
+        self.capacity, self.ghost_capacity = capacity, ghost_capacity
+        self.pos = np.zeros((0, 3), np.float32); self.vel = np.zeros((0, 3), np.float32)
+        self.idx = np.zeros((0,), np.uint32); self.key = np.zeros((0,), np.int64)
+        self.rho = np.zeros((0,), np.float32); self.prs = np.zeros((0,), np.float32)
+        self._clear_ghosts()
+        self.o = None
+
+    def _clear_ghosts(self):
+        z3, z1 = np.zeros((0, 3), np.float32), np.zeros((0,), np.float32)
+        self.g = [dict(pos=z3, vel=z3, idx=np.zeros((0,), np.uint32), rho=z1, prs=z1) for _ in range(2)]
+
+    # plumbing ------------------------------------------------------------------------------------
+    def buffer(self, rows, cols): return torch.zeros((rows, cols), dtype=torch.float32)
+    def small(self, values): return torch.tensor(values, dtype=torch.int64)
+    @property
+    def n(self): return int(self.pos.shape[0])
+    def sync(self): pass
+    def close(self): pass
+
+    def upload(self, pos, vel, index):
+        self.pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3).copy()
+        self.vel = np.ascontiguousarray(vel, np.float32).reshape(-1, 3).copy()
+        self.idx = np.ascontiguousarray(index, np.uint32).copy()
+        assert self.n <= self.capacity
+        self.rho = np.zeros(self.n, np.float32); self.prs = np.zeros(self.n, np.float32)
+
+    # grid phases -----------------------------------------------------------------------------------
+    def hash(self):
+        c = [_cell(self.pos[:, a], self.bmin[a], self.bdim[a], self.grid[a]) for a in range(3)]
+        lz = np.clip(c[2] - self.z_lo + 1, 0, self.zl - 1)
+        self.key = (lz * self.grid[1] + c[1]) * self.grid[0] + c[0]
+
+    def sort(self):
+        o = np.argsort(self.key, kind="stable")
+        self.pos, self.vel, self.idx, self.key = self.pos[o], self.vel[o], self.idx[o], self.key[o]
+        self.rho, self.prs = self.rho[o] if self.rho.shape[0] == o.shape[0] else np.zeros(self.n, np.float32), \
+            self.prs[o] if self.prs.shape[0] == o.shape[0] else np.zeros(self.n, np.float32)
+        self._clear_ghosts()
+
+    def slab_counts(self):
+        L = self.layer
+        lb = np.searchsorted(self.key, [L, 2 * L, (self.zl - 2) * L, (self.zl - 1) * L], side="left")
+        return int(lb[0]), int(lb[1] - lb[0]), int(lb[3] - lb[2]), int(self.n - lb[3])
+
+    def _records(self, sl):
+        r = np.zeros((self.pos[sl].shape[0], 8), np.float32)
+        r[:, 0:3] = self.pos[sl]
+        r[:, 3] = self.idx[sl].view(np.float32)
+        r[:, 4:7] = self.vel[sl]
+        return r
+
+    def _keep(self, sl):
+        self.pos, self.vel, self.idx, self.key = self.pos[sl], self.vel[sl], self.idx[sl], self.key[sl]
+        self.rho, self.prs = self.rho[sl], self.prs[sl]
+
+    def migrants_pack(self, lo, hi):
+        m_lo, _, _, m_hi = self.slab_counts()
+        lo.numpy()[:m_lo] = self._records(slice(0, m_lo))
+        hi.numpy()[:m_hi] = self._records(slice(self.n - m_hi, self.n))
+        self._keep(slice(m_lo, self.n - m_hi))
+
+    def migrants_append(self, buf, n):
+        r = buf.numpy()[:n]
+        self.pos = np.concatenate([self.pos, r[:, 0:3]]); self.vel = np.concatenate([self.vel, r[:, 4:7]])
+        self.idx = np.concatenate([self.idx, np.ascontiguousarray(r[:, 3]).view(np.uint32)])
+        self.rho = np.zeros(self.n, np.float32); self.prs = np.zeros(self.n, np.float32)
+        assert self.n <= self.capacity
+
+    def _halo_counts(self):
+        L = self.layer
+        return int(np.searchsorted(self.key, 2 * L)), int(self.n - np.searchsorted(self.key, (self.zl - 2) * L))
+
+    def halo_pack(self, lo, hi):
+        h_lo, h_hi = self._halo_counts()
+        lo.numpy()[:h_lo] = self._records(slice(0, h_lo))
+        hi.numpy()[:h_hi] = self._records(slice(self.n - h_hi, self.n))
+
+    def halo_unpack(self, lo, n_lo, hi, n_hi):
+        assert max(n_lo, n_hi) <= self.ghost_capacity
+        for side, (buf, m) in enumerate(((lo, n_lo), (hi, n_hi))):
+            r = buf.numpy()[:m].copy()
+            self.g[side] = dict(pos=r[:, 0:3].copy(), vel=r[:, 4:7].copy(),
+                                idx=np.ascontiguousarray(r[:, 3]).view(np.uint32).copy(),
+                                rho=np.zeros(m, np.float32), prs=np.zeros(m, np.float32))
+
+    # neighbour passes: the oracle over ghosts + owned ------------------------------------------------------
+    def build_cells(self):
+        pos = np.concatenate([self.g[0]["pos"], self.pos, self.g[1]["pos"]])
+        vel = np.concatenate([self.g[0]["vel"], self.vel, self.g[1]["vel"]])
+        self.n_glo = self.g[0]["pos"].shape[0]
+        self.o = oracle.Oracle(pos, vel, self.box, self.grid, oracle.CELL_LINEAR)
+        self.o.map_zindex(); self.o.sort(); self.o.construct_bgrid()
+
+    def density(self):
+        self.o.compute_densities()
+        rho, prs = self.o.by_index("density"), self.o.by_index("pressure")
+        self.rho = rho[self.n_glo:self.n_glo + self.n].copy()
+        self.prs = prs[self.n_glo:self.n_glo + self.n].copy()
+
+    def halo_pack_density(self, lo, hi):
+        h_lo, h_hi = self._halo_counts()
+        lo.numpy()[:h_lo] = np.stack([self.rho[:h_lo], self.prs[:h_lo]], axis=1)
+        hi.numpy()[:h_hi] = np.stack([self.rho[self.n - h_hi:], self.prs[self.n - h_hi:]], axis=1)
+
+    def halo_unpack_density(self, lo, hi):
+        p = self.o.particles
+        slot = np.empty(p.shape[0], np.int64)
+        slot[p["index"]] = np.arange(p.shape[0])
+        n_lo, n_hi = self.n_glo, self.g[1]["pos"].shape[0]
+        for base, buf, m in ((0, lo, n_lo), (self.n_glo + self.n, hi, n_hi)):
+            r = buf.numpy()[:m]
+            s = slot[base:base + m]
+            p["density"][s] = r[:, 0]
+            p["pressure"][s] = r[:, 1]
+
+    def force_collide_integrate(self, dt):
+        self.o.compute_forces(); self.o.particle_collisions(); self.o.integrate(dt)
+        pos, vel = self.o.by_index("position"), self.o.by_index("velocity")
+        self.pos = pos[self.n_glo:self.n_glo + self.n].copy()
+        self.vel = vel[self.n_glo:self.n_glo + self.n].copy()
+        self.o.close(); self.o = None
+
+    def download(self, total):
+        out = dict(pos=np.full((total, 3), np.nan, np.float32), vel=np.full((total, 3), np.nan, np.float32),
+                   density=np.full(total, np.nan, np.float32), pressure=np.full(total, np.nan, np.float32))
+        out["pos"][self.idx] = self.pos; out["vel"][self.idx] = self.vel
+        out["density"][self.idx] = self.rho; out["pressure"][self.idx] = self.prs
+        return out
+
+
+def make_case(name):
+    """Small systems that force particles across slab boundaries within a few steps."""
+    from gpufluidsimulator_amd import ic
+    box, grid = (4.0, 4.0, 4.0), (64, 64, 64)
+    pos, vel = ic.dam_break_lattice((12, 12, 24), box, jitter=True)
+    if name == "up":
+        vel[:, 2] = 4000.0          # 0.002 per step at dt 5e-7: crosses a cell layer every ~8 steps
+    elif name == "down":
+        vel[:, 2] = -4000.0         # into the floor: wall clamp + damping, then back up
+    elif name == "shear":
+        vel[:, 2] = np.where(pos[:, 2] > pos[:, 2].mean(), 4000.0, -2500.0)
+    return pos, vel, box, grid
+
+
+def gloo_worker(rank, world, port, case, steps, out_dir):
+    """Entry of one CPU rank (torch.multiprocessing.spawn): TorchDistComm over gloo."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pos, vel, box, grid = make_case(case)
+        comm = slab.TorchDistComm(torch.device("cpu"))
+        sim = slab.SlabSimulation(comm, OracleEngine, box, grid, particles=(pos, vel))
+        sim.run(5e-7, steps)
+        st = sim.gather_state()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "out.npz"), cuts=np.array(sim.cuts), migrants=sim.stats["migrants"], **st)
+        stats = comm.allreduce_sum(np.array([sim.stats["migrants"], sim.stats["resorts"]], dtype=np.int64))
+        if rank == 0:
+            np.save(os.path.join(out_dir, "stats.npy"), stats)
+    finally:
+        dist.destroy_process_group()

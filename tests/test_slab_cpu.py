@@ -1,0 +1,101 @@
+"""CPU: the multi-GPU z-slab protocol (gpufluidsimulator_amd.slab) with CPU ranks.
+
+The product engine is the HIP library; here a test-only engine with the oracle behind it
+(tests/slab_oracle_engine.py) is injected so that partitioning, count messages, migration, ghost
+layers and the density halo are exercised with world_size > 1 on CPU -- once with in-process ranks
+(LocalComm) and once with real processes over torch.distributed's gloo backend."""
+import os
+import tempfile
+import threading
+
+import numpy as np
+import pytest
+
+from gpufluidsimulator_amd import slab
+from oracle import oracle
+from slab_oracle_engine import OracleEngine, gloo_worker, make_case
+
+DT = 5e-7
+
+
+def _single_domain(case, steps):
+    pos, vel, box, grid = make_case(case)
+    o = oracle.Oracle(pos, vel, box, grid, oracle.CELL_LINEAR)
+    o.step(DT, steps)
+    st = o.state()
+    o.close()
+    return st, box
+
+
+def _check(st, ref, box):
+    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
+    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def test_choose_cuts_balances_counts():
+    hist = np.zeros(64, dtype=np.int64)
+    hist[0:16] = 1000                       # dam break: a quarter of the layers hold everything
+    cuts = slab.choose_cuts(hist, 4)
+    assert cuts == [0, 4, 8, 12, 64]
+    cuts = slab.choose_cuts(hist, 8)
+    assert cuts[0] == 0 and cuts[-1] == 64 and all(b > a for a, b in zip(cuts, cuts[1:]))
+    counts = [hist[a:b].sum() for a, b in zip(cuts, cuts[1:])]
+    assert max(counts) == min(counts) == 2000
+    with pytest.raises(ValueError):
+        slab.choose_cuts(np.ones(3), 4)
+    # degenerate: everything in one layer -> slabs still get >= 1 layer each
+    h = np.zeros(8, dtype=np.int64); h[5] = 10
+    cuts = slab.choose_cuts(h, 3)
+    assert all(b > a for a, b in zip(cuts, cuts[1:])) and cuts[-1] == 8
+
+
+def test_cell_layer_matches_the_oracle_hash():
+    pos, vel, box, grid = make_case("up")
+    o = oracle.Oracle(pos, vel, box, grid, oracle.CELL_LINEAR)
+    o.map_zindex()
+    z = o.particles["zindex"] // (grid[0] * grid[1])
+    assert np.array_equal(slab.cell_layer_of(pos[:, 2], box[2], grid[2]), z)
+    o.close()
+
+
+@pytest.mark.parametrize("case,world", [("up", 3), ("down", 2), ("shear", 4)])
+def test_slabs_in_process_match_single_domain(case, world):
+    steps = 24
+    pos, vel, box, grid = make_case(case)
+    hub = slab.LocalComm.Hub(world)
+    results, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            sim = slab.SlabSimulation(slab.LocalComm(hub, r), OracleEngine, box, grid, particles=(pos, vel))
+            sim.run(DT, steps)
+            results[r] = (sim.gather_state(), dict(sim.stats), sim.cuts)
+        except BaseException as e:     # noqa: BLE001 - surface the failure and release the other ranks
+            errors.append(e)
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=600)
+    assert not errors, errors
+    st, stats, cuts = results[0]
+    ref, _ = _single_domain(case, steps)
+    _check(st, ref, box)
+    total_migrants = sum(res[1]["migrants"] for res in results)
+    assert total_migrants > 0, "the case is meant to push particles across slab boundaries"
+    for other in results[1:]:
+        assert np.array_equal(other[0]["pos"], st["pos"])
+
+
+def test_slabs_over_gloo_world_size_2():
+    import torch.multiprocessing as mp
+    steps = 16
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000)
+        mp.spawn(gloo_worker, args=(2, port, "up", steps, d), nprocs=2, join=True)
+        out = np.load(os.path.join(d, "out.npz"))
+        stats = np.load(os.path.join(d, "stats.npy"))
+    ref, box = _single_domain("up", steps)
+    _check(out, ref, box)
+    assert stats[0] > 0
