@@ -112,9 +112,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=sorted(ic.CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
     args = ap.parse_args()
     rank, world, local = _dist_env()
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_slab:
         from gpufluidsimulator_amd import slab
         return slab.bench_main(args)
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "sph_migrants_append": (C.c_int, [_P, _P, _U32]),
     "sph_halo_count": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_halo_pack": (C.c_int, [_P, C.POINTER(_P), _U32]),
+    "sph_halo_pack_counts": (C.c_int, [_P, C.POINTER(_P), _U32, C.POINTER(_U32)]),
     "sph_halo_unpack": (C.c_int, [_P, _P, _U32, _P, _U32]),
     "sph_halo_pack_density": (C.c_int, [_P, C.POINTER(_P), _U32]),
     "sph_halo_unpack_density": (C.c_int, [_P, _P, _P]),
@@ -285,8 +286,12 @@ class Context:
     def migrants_append(self, buf, n):
         _check(self.L.sph_migrants_append(self.h, _P(buf), int(n)))
 
-    def halo_pack(self, buf_lo, buf_hi, capacity):
-        _check(self.L.sph_halo_pack(self.h, (_P * 2)(buf_lo, buf_hi), int(capacity)))
+    def halo_pack(self, buf_lo, buf_hi, capacity, counts=None):
+        if counts is None:
+            _check(self.L.sph_halo_pack(self.h, (_P * 2)(buf_lo, buf_hi), int(capacity)))
+        else:
+            _check(self.L.sph_halo_pack_counts(self.h, (_P * 2)(buf_lo, buf_hi), int(capacity),
+                                               (_U32 * 2)(int(counts[0]), int(counts[1]))))
 
     def halo_unpack(self, lo, n_lo, hi, n_hi):
         _check(self.L.sph_halo_unpack(self.h, _P(lo), int(n_lo), _P(hi), int(n_hi)))

@@ -219,6 +219,7 @@ static int do_sort(sph_ctx* c) {
     int rc = launch_sort(c);
     if (rc) return rc;
     c->n_glo = c->n_ghi = 0;
+    c->halo_n_valid = false;
     c->stage = sph_ctx::ST_SORTED;
     c->have_dens = c->have_force = c->have_coll = false;
     return SPH_OK;

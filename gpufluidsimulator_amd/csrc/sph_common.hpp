@@ -60,6 +60,8 @@ struct sph_ctx {
     uint32_t n = 0;          // owned particles
     uint32_t own_off = 0;    // offset of the owned range inside posi/velr (gcap after a sort)
     uint32_t n_glo = 0, n_ghi = 0;   // ghosts installed below / above
+    uint32_t halo_n[2] = {0, 0};     // boundary-layer counts of the last halo pack
+    bool halo_n_valid = false;
     uint32_t index_hi = 0;   // max creation index + 1 seen at upload (size of pos_out)
 
     // sorted SoA state, `tot` entries each; the owned range starts at own_off

@@ -141,15 +141,26 @@ int sph_halo_count(sph_ctx* c, uint32_t count[2]) {
     return SPH_OK;
 }
 
-int sph_halo_pack(sph_ctx* c, void* buf_dev[2], uint32_t capacity) {
+int sph_halo_pack_counts(sph_ctx* c, void* buf_dev[2], uint32_t capacity, const uint32_t count[2]) {
     SPH_REQUIRE(c && buf_dev, SPH_E_INVALID, "null argument");
+    SPH_REQUIRE(c->stage >= sph_ctx::ST_SORTED, SPH_E_STATE, "sph_halo_pack needs sph_sort first");
     uint32_t m[2];
-    int rc = sph_halo_count(c, m);
-    if (rc) return rc;
-    rc = pack_slice(c, c->own_off, m[0], buf_dev[0], capacity);
+    if (count) {
+        m[0] = count[0]; m[1] = count[1];
+        SPH_REQUIRE(m[0] <= c->n && m[1] <= c->n, SPH_E_INVALID, "halo counts exceed the owned particles");
+    } else {
+        int rc = sph_halo_count(c, m);
+        if (rc) return rc;
+    }
+    SPH_HIP(hipSetDevice(c->device));
+    int rc = pack_slice(c, c->own_off, m[0], buf_dev[0], capacity);
     if (!rc) rc = pack_slice(c, c->own_off + c->n - m[1], m[1], buf_dev[1], capacity);
-    return rc;
+    if (rc) return rc;
+    c->halo_n[0] = m[0]; c->halo_n[1] = m[1]; c->halo_n_valid = true;
+    return SPH_OK;
 }
+
+int sph_halo_pack(sph_ctx* c, void* buf_dev[2], uint32_t capacity) { return sph_halo_pack_counts(c, buf_dev, capacity, nullptr); }
 
 int sph_halo_unpack(sph_ctx* c, const void* lo_dev, uint32_t n_lo, const void* hi_dev, uint32_t n_hi) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
@@ -182,8 +193,13 @@ int sph_halo_pack_density(sph_ctx* c, void* buf_dev[2], uint32_t capacity) {
     SPH_REQUIRE(c && buf_dev, SPH_E_INVALID, "null argument");
     SPH_REQUIRE(c->have_dens, SPH_E_STATE, "sph_halo_pack_density needs sph_density first");
     uint32_t m[2];
-    int rc = sph_halo_count(c, m);
-    if (rc) return rc;
+    if (c->halo_n_valid) {          // same particles, same order as the position halo of this step
+        m[0] = c->halo_n[0]; m[1] = c->halo_n[1];
+    } else {
+        int rc = sph_halo_count(c, m);
+        if (rc) return rc;
+    }
+    SPH_HIP(hipSetDevice(c->device));
     SPH_REQUIRE(m[0] <= capacity && m[1] <= capacity, SPH_E_CAPACITY, "halo slice > buffer capacity %u", capacity);
     if (m[0]) SPH_HIP(hipMemcpyAsync(buf_dev[0], c->dp + c->own_off, m[0] * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
     if (m[1]) SPH_HIP(hipMemcpyAsync(buf_dev[1], c->dp + c->own_off + c->n - m[1], m[1] * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));

@@ -198,7 +198,7 @@ class HipEngine:
     def slab_counts(self): return self.ctx.slab_counts()
     def migrants_pack(self, lo, hi): self.ctx.migrants_pack(self.ptr(lo), self.ptr(hi), lo.shape[0])
     def migrants_append(self, buf, n): self.ctx.migrants_append(self.ptr(buf), n)
-    def halo_pack(self, lo, hi): self.ctx.halo_pack(self.ptr(lo), self.ptr(hi), lo.shape[0])
+    def halo_pack(self, lo, hi, counts=None): self.ctx.halo_pack(self.ptr(lo), self.ptr(hi), lo.shape[0], counts)
     def halo_unpack(self, lo, n_lo, hi, n_hi): self.ctx.halo_unpack(self.ptr(lo), n_lo, self.ptr(hi), n_hi)
     def halo_pack_density(self, lo, hi): self.ctx.halo_pack_density(self.ptr(lo), self.ptr(hi), lo.shape[0])
     def halo_unpack_density(self, lo, hi): self.ctx.halo_unpack_density(self.ptr(lo), self.ptr(hi))
@@ -329,7 +329,7 @@ class SlabSimulation:
         h_lo, h_hi = own_lo + in_lo, own_hi + in_hi
         gl, gh = peer_own_lo + m_lo, peer_own_hi + m_hi     # ghosts I receive
         assert max(h_lo, h_hi, gl, gh) <= g, "boundary layer exceeds the ghost capacity"
-        e.halo_pack(self.send_lo, self.send_hi)
+        e.halo_pack(self.send_lo, self.send_hi, (h_lo, h_hi))
         sends, recvs = [], []
         if lo is not None:
             sends.append((lo, self.send_lo[:h_lo])); recvs.append((lo, self.recv_lo[:gl]))

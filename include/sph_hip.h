@@ -174,6 +174,9 @@ int sph_migrants_append(sph_ctx* c, const void* buf_dev, uint32_t n);
 /* number of owned particles in the boundary layers (what the neighbours need as ghosts) */
 int sph_halo_count(sph_ctx* c, uint32_t count[2]);
 int sph_halo_pack(sph_ctx* c, void* buf_dev[2], uint32_t capacity);
+/* same with the two counts supplied by the caller (a slab driver knows them from sph_slab_counts and
+ * the migrant counts), which saves a device round trip; they are remembered for the density halo */
+int sph_halo_pack_counts(sph_ctx* c, void* buf_dev[2], uint32_t capacity, const uint32_t count[2]);
 /* install n_lo / n_hi ghost records received from the lower / upper neighbour */
 int sph_halo_unpack(sph_ctx* c, const void* lo_dev, uint32_t n_lo, const void* hi_dev, uint32_t n_hi);
 /* second exchange: (density, pressure) float2 of the same boundary particles, same order */

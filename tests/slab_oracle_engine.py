@@ -99,8 +99,9 @@ class OracleEngine:
         L = self.layer
         return int(np.searchsorted(self.key, 2 * L)), int(self.n - np.searchsorted(self.key, (self.zl - 2) * L))
 
-    def halo_pack(self, lo, hi):
+    def halo_pack(self, lo, hi, counts=None):
         h_lo, h_hi = self._halo_counts()
+        assert counts is None or tuple(counts) == (h_lo, h_hi), (counts, h_lo, h_hi)
         lo.numpy()[:h_lo] = self._records(slice(0, h_lo))
         hi.numpy()[:h_hi] = self._records(slice(self.n - h_hi, self.n))
 
