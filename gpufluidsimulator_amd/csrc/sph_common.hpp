@@ -89,6 +89,7 @@ struct sph_ctx {
     uint32_t* digit_tot = nullptr;  // 256
     uint32_t sort_blocks_cap = 0;
     uint32_t key_bits = 0;
+    const uint32_t* last_perm = nullptr;   // v0 or v1: the permutation of the last sort
     uint32_t* d_scratch = nullptr;  // small device scratch (counts)
     uint32_t* h_scratch = nullptr;  // pinned host mirror
 

@@ -212,7 +212,12 @@ int launch_sort(sph_ctx* c) {
     t4 = c->posi; c->posi = c->posi2; c->posi2 = t4;
     t4 = c->velr; c->velr = c->velr2; c->velr2 = t4;
     c->own_off = c->gcap;
+    c->last_perm = vin;
     return SPH_OK;
 }
+
+// sorted slot -> slot before the sort (valid until the next sph_hash); used by the compat seam to
+// move the caller's AoS structs the way thrust::sort would
+const uint32_t* last_sort_permutation(sph_ctx* c) { return c->last_perm; }
 
 }  // namespace sph

@@ -30,6 +30,9 @@
 // filled by glXGetProcAddress from the image's libGL and never called here.
 #include <helper_gl.h>
 #include "particleSystem.h"
+#ifdef REF_DROPIN
+#include "particleSystem.cuh"     // the reference's declarations of its seam
+#endif
 
 #include <cstdint>
 #include <cstdio>
@@ -165,6 +168,31 @@ public:
         recs.push_back(std::move(r));
     }
 
+#ifdef REF_DROPIN
+    // ---- drop-in mode: the reference's OWN update() in CUDA_PARALLEL mode (particleSystem.cpp:769-801),
+    // with its extern "C" seam (particleSystem.cuh:3-30) served by libsph_hip.so on an MI355X.
+    // What _initialize() does at particleSystem.cpp:121-128, minus the GL calls.
+    void dropin_init() {
+        m_compute_mode = CUDA_PARALLEL;
+        allocateArray((void**)&m_d_params, sizeof(SimParams));
+        allocateArray((void**)&m_d_particles, sizeof(Particle) * m_numParticles);
+        allocateArray((void**)&m_d_B, sizeof(Grid_item) * m_h_B_size);
+        allocateArray((void**)&m_d_B_prime, sizeof(Grid_item) * m_numParticles);
+        m_posVbo = 1;
+        registerGLBufferObject(m_posVbo, &m_cuda_posvbo_resource);
+        copyArrayToDevice((void*)m_d_particles, m_particles.data(), m_numParticles * sizeof(Particle));   // :920
+        m_bInitialized = true;           // update() asserts it; the destructor never runs (_Exit)
+    }
+    void dropin_step(float dt, uint32_t stepno, bool state) {
+        update(dt, 0.f);                 // the reference's code, CUDA branch
+        if (state) {
+            threadSync();
+            copyArrayFromDevice(m_particles.data(), m_d_particles, m_numParticles * sizeof(Particle));
+            rec_particles(TAG_STATE, stepno);
+        }
+    }
+#endif
+
     // one time step: the OMP branch of update(), particleSystem.cpp:743-767
     void step(float dt, uint32_t stepno, bool phases, bool state, double* phase_s) {
         double t0 = omp_get_wtime();
@@ -230,9 +258,21 @@ int main(int argc, char** argv) {
     RefHarness* h = new RefHarness(n, make_float3(box[0], box[1], box[2]), grid);  // never deleted on purpose
     h->load(pos.data(), vel.data());
     double phase_s[8] = { 0 };
+#ifdef REF_DROPIN
+    h->dropin_init();
+    threadSync();
+#endif
     double t0 = omp_get_wtime();
-    for (uint32_t s = 1; s <= steps; s++)
+    for (uint32_t s = 1; s <= steps; s++) {
+#ifdef REF_DROPIN
+        h->dropin_step(dt, s, dump_steps.count(s) != 0 || s == steps);
+#else
         h->step(dt, s, (flags & 1) != 0, dump_steps.count(s) != 0 || s == steps, phase_s);
+#endif
+    }
+#ifdef REF_DROPIN
+    threadSync();
+#endif
     double t1 = omp_get_wtime();
 
     FILE* o = fopen(argv[2], "wb");

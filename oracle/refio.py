@@ -10,6 +10,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_BIN = os.path.join(HERE, "_ref", "sph_ref")
+DROPIN_BIN = os.path.join(HERE, "_ref", "sph_ref_dropin")   # reference host code + libsph_hip seam (GPU)
 
 TAGS = {1: "zindex", 2: "order", 3: "sorted_z", 4: "bcells", 5: "bprime", 6: "dens", 7: "force", 8: "coll",
         9: "state", 10: "hpos"}
@@ -20,7 +21,11 @@ def available() -> bool:
     return os.path.exists(REF_BIN)
 
 
-def run_ref(pos, vel, box, grid, dt, steps, phases=False, dump_steps=(), threads=0, timeout=3600):
+def dropin_available() -> bool:
+    return os.path.exists(DROPIN_BIN)
+
+
+def run_ref(pos, vel, box, grid, dt, steps, phases=False, dump_steps=(), threads=0, timeout=3600, binary=None):
     """Run the reference's OMP-mode step ``steps`` times.  Returns (records, stats):
     records[(name, step)] -> ndarray, stats = the JSON line the binary prints."""
     pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
@@ -38,7 +43,7 @@ def run_ref(pos, vel, box, grid, dt, steps, phases=False, dump_steps=(), threads
             np.array([steps, 1 if phases else 0], dtype=np.uint32).tofile(f)
             pos.tofile(f)
             vel.tofile(f)
-        cmd = [REF_BIN, fin, fout]
+        cmd = [binary or REF_BIN, fin, fout]
         if dump_steps:
             cmd.append("dump_steps=" + ",".join(str(int(s)) for s in dump_steps))
         if threads:
