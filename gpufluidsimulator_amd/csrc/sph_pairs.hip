@@ -311,6 +311,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     wave_hulls(R, H);
     float4 q0, q1, w0, w1;
     float2 e0, e1;
+    const float cps = ph.spiky_half_mass / ph.visc_coef;   // pressure coefficient relative to the viscous one
+    const float cpi = cps * dpi.y;
     float fpx = 0.f, fpy = 0.f, fpz = 0.f, fvx = 0.f, fvy = 0.f, fvz = 0.f;
     float cvx = 0.f, cvy = 0.f, cvz = 0.f;
     uint32_t ccount = 0;
@@ -328,18 +330,19 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             s_a[slice + WAVE + lane] = make_float2(q1.x, q1.y);
             s_b[slice + WAVE + lane] = make_float2(q1.z, w1.x);
             s_c[slice + WAVE + lane] = make_float2(w1.y, w1.z);
-            if (FORCE) {   // p_j and 1/rho_j (v_rcp_f32); padding entries have rho = 0
-                s_d[slice + lane] = make_float2(e0.y, e0.x > 0.f ? __builtin_amdgcn_rcpf(e0.x) : 0.f);
-                s_d[slice + WAVE + lane] = make_float2(e1.y, e1.x > 0.f ? __builtin_amdgcn_rcpf(e1.x) : 0.f);
+            if (FORCE) {
+                // staged per candidate: cp_j = (spiky/visc) * p_j and w_j = visc * 1/rho_j (v_rcp_f32), so
+                // that the pair loop needs w = w_j*(h-r) for viscosity and (cp_i+cp_j)*w*(h-r)/r for pressure.
+                // Padding entries have rho = 0 -> weight 0.
+                s_d[slice + lane] = make_float2(cps * e0.y, e0.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e0.x) : 0.f);
+                s_d[slice + WAVE + lane] = make_float2(cps * e1.y, e1.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e1.x) : 0.f);
             }
         },
         [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
             const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
             const uint32_t T = wave_max_u32(len);
-            const uint32_t off = len ? l0 - a : 0u;
-            uint32_t idx = slice + off;
-            const uint32_t self = i - a - off;     // t + u == self  <=>  candidate slot == own slot
+            uint32_t idx = slice + (len ? l0 - a : 0u);
             for (uint32_t t = 0; t < T; t += SPH_FORCE_UNROLL) {
 #pragma unroll
                 for (int u = 0; u < SPH_FORCE_UNROLL; u++) {
@@ -348,14 +351,17 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                     const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
                     const float r2 = dx * dx + dy * dy + dz * dz;
                     const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
+                    float rinv = 0.f;
                     if (FORCE) {
                         const float2 qd = s_d[idx + u];
                         const bool in = valid && r2 < ph.h2;
-                        const float rinv = r2 > 1e-30f ? inv_sqrt(r2) : 0.f;
+                        // r = 0 (the particle itself, coincident particles): 1/r is clamped to 1e15, r*1/r = 0,
+                        // and the huge but finite pressure weight multiplies r_ij = 0 -- no pressure term, as
+                        // with Eigen's normalized() of a zero vector (Dot.h:124-134); the viscous term is exact.
+                        rinv = inv_sqrt(fmaxf(r2, 1e-30f));
                         const float hr = ph.h - r2 * rinv;
-                        const float k = qd.y * hr;
-                        float s = ph.spiky_half_mass * (dpi.y + qd.x) * k * hr * rinv;
-                        float w = ph.visc_coef * k;
+                        float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
+                        float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
                         s = in ? s : 0.f;
                         w = in ? w : 0.f;
                         fpx += s * dx; fpy += s * dy; fpz += s * dz;
@@ -371,8 +377,12 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                         const float r2c = r2;
                         const float dot = -(dx * ux + dy * uy + dz * uz);               // r_ij . (v_i - v_j)
 #endif
-                        const bool hit = valid && (t + u != self) && (r2c <= ph.coll_dist2) && (dot < 0.f);
-                        const float cfac = hit ? ph.coll_mass * dot * __builtin_amdgcn_rcpf(r2c) : 0.f;
+                        // j == i needs no test: r_ij = 0 gives r.v = -0, which is not < 0 (the reference skips
+                        // the pair by index, particleSystem.cu:54; a coincident pair fails r.v < 0 there too)
+                        const bool hit = valid && (r2c <= ph.coll_dist2) && (dot < 0.f);
+                        // 1/d^2: (1/r)^2 from the force branch when it ran, else v_rcp_f32
+                        const float inv_d2 = FORCE ? rinv * rinv : __builtin_amdgcn_rcpf(r2c);
+                        const float cfac = hit ? ph.coll_mass * dot * inv_d2 : 0.f;
                         cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
                         ccount += hit ? 1u : 0u;
                     }
