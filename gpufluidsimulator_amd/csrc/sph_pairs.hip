@@ -343,51 +343,68 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
             const uint32_t T = wave_max_u32(len);
             uint32_t idx = slice + (len ? l0 - a : 0u);
-            for (uint32_t t = 0; t < T; t += SPH_FORCE_UNROLL) {
+            // Candidates are walked in chunks of 32.  The pressure/viscosity arithmetic runs for every
+            // candidate; the collision test only records "d <= 2R" in a per-lane bit mask (2 VALU per
+            // candidate) and the few close pairs (~4 of ~216 per particle) are worked off after the chunk.
+            for (uint32_t t0 = 0; t0 < T; t0 += 32u) {
+                const uint32_t tend = min(T, t0 + 32u);
+                const uint32_t idx0 = idx;
+                uint32_t near = 0u, done = 0u;
+                for (uint32_t t = t0; t < tend; t += SPH_FORCE_UNROLL) {
 #pragma unroll
-                for (int u = 0; u < SPH_FORCE_UNROLL; u++) {
-                    const float2 qa = s_a[idx + u], qb = s_b[idx + u], qc = s_c[idx + u];
-                    const bool valid = t + u < len;
-                    const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
-                    const float r2 = dx * dx + dy * dy + dz * dz;
-                    const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
-                    float rinv = 0.f;
-                    if (FORCE) {
-                        const float2 qd = s_d[idx + u];
-                        const bool in = valid && r2 < ph.h2;
-                        // r = 0 (the particle itself, coincident particles): 1/r is clamped to 1e15, r*1/r = 0,
-                        // and the huge but finite pressure weight multiplies r_ij = 0 -- no pressure term, as
-                        // with Eigen's normalized() of a zero vector (Dot.h:124-134); the viscous term is exact.
-                        rinv = inv_sqrt(fmaxf(r2, 1e-30f));
-                        const float hr = ph.h - r2 * rinv;
-                        float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
-                        float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
-                        s = in ? s : 0.f;
-                        w = in ? w : 0.f;
-                        fpx += s * dx; fpy += s * dy; fpz += s * dz;
-                        fvx += w * ux; fvy += w * uy; fvz += w * uz;
+                    for (int u = 0; u < SPH_FORCE_UNROLL; u++) {
+                        const float2 qa = s_a[idx + u], qb = s_b[idx + u];
+                        const bool valid = t + u < len;
+                        const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
+                        const float r2 = dx * dx + dy * dy + dz * dz;
+                        if (FORCE) {
+                            const float2 qc = s_c[idx + u], qd = s_d[idx + u];
+                            const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
+                            const bool in = valid && r2 < ph.h2;
+                            // r = 0 (the particle itself, coincident particles): 1/r is clamped to 1e15, r*1/r = 0,
+                            // and the huge but finite pressure weight multiplies r_ij = 0 -- no pressure term, as
+                            // with Eigen's normalized() of a zero vector (Dot.h:124-134); the viscous term is exact.
+                            const float rinv = inv_sqrt(fmaxf(r2, 1e-30f));
+                            const float hr = ph.h - r2 * rinv;
+                            float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
+                            float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
+                            s = in ? s : 0.f;
+                            w = in ? w : 0.f;
+                            fpx += s * dx; fpy += s * dy; fpz += s * dz;
+                            fvx += w * ux; fvy += w * uy; fvz += w * uz;
+                        }
+                        if (COLL) near = (near << 1) | ((valid && r2 <= ph.coll_dist2) ? 1u : 0u);
                     }
-                    if (COLL) {
+                    idx += SPH_FORCE_UNROLL;
+                    done += SPH_FORCE_UNROLL;
+                }
+                if (COLL) {
+                    // bit (done-1-k) of `near` belongs to the k-th candidate of this chunk; highest bit first
+                    // keeps the candidate order of the sums
+                    while (__ballot(near != 0u) != 0ull) {
+                        if (near != 0u) {
+                            const uint32_t hb = 31u - (uint32_t)__clz((int)near);
+                            near &= ~(1u << hb);
+                            const uint32_t ci = idx0 + (done - 1u - hb);
+                            const float2 qa = s_a[ci], qb = s_b[ci], qc = s_c[ci];
+                            const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
+                            const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;
 #if SPH_COLL_EXACT
-                        // the reference's own association, one rounding per operation (no FMA):
-                        // x*x + (y*y + z*z), Eigen redux order
-                        const float r2c = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
-                        const float dot = -__fadd_rn(__fmul_rn(dx, ux), __fadd_rn(__fmul_rn(dy, uy), __fmul_rn(dz, uz)));
+                            const float r2c = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
+                            const float dot = -__fadd_rn(__fmul_rn(dx, ux), __fadd_rn(__fmul_rn(dy, uy), __fmul_rn(dz, uz)));
 #else
-                        const float r2c = r2;
-                        const float dot = -(dx * ux + dy * uy + dz * uz);               // r_ij . (v_i - v_j)
+                            const float r2c = dx * dx + dy * dy + dz * dz;
+                            const float dot = -(dx * ux + dy * uy + dz * uz);           // r_ij . (v_i - v_j)
 #endif
-                        // j == i needs no test: r_ij = 0 gives r.v = -0, which is not < 0 (the reference skips
-                        // the pair by index, particleSystem.cu:54; a coincident pair fails r.v < 0 there too)
-                        const bool hit = valid && (r2c <= ph.coll_dist2) && (dot < 0.f);
-                        // 1/d^2: (1/r)^2 from the force branch when it ran, else v_rcp_f32
-                        const float inv_d2 = FORCE ? rinv * rinv : __builtin_amdgcn_rcpf(r2c);
-                        const float cfac = hit ? ph.coll_mass * dot * inv_d2 : 0.f;
-                        cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
-                        ccount += hit ? 1u : 0u;
+                            // j == i needs no test: r_ij = 0 gives r.v = -0, which is not < 0 (the reference skips
+                            // the pair by index, particleSystem.cu:54; a coincident pair fails r.v < 0 there too)
+                            const bool hit = dot < 0.f;
+                            const float cfac = hit ? ph.coll_mass * dot * __builtin_amdgcn_rcpf(r2c) : 0.f;
+                            cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
+                            ccount += hit ? 1u : 0u;
+                        }
                     }
                 }
-                idx += SPH_FORCE_UNROLL;
             }
         });
     if (!active) return;
