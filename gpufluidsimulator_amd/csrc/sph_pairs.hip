@@ -286,16 +286,13 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     float4* __restrict__ fvisc, float4* __restrict__ dvel, float4* __restrict__ posi_out,
     float4* __restrict__ velr_out, float4* __restrict__ pos_by_index, uint32_t tgt_lo, uint32_t tgt_hi, float dt,
     GridDesc g, Phys ph) {
-    __shared__ float2 s_a[LDS_ENT];   // x, y
-    __shared__ float2 s_b[LDS_ENT];   // z, vx
-    __shared__ float2 s_c[LDS_ENT];   // vy, vz
-    __shared__ float2 s_d[LDS_ENT];   // p, 1/rho
-    for (uint32_t k = threadIdx.x; k < LDS_ENT; k += PAIR_THREADS) {   // see LDS_ENT: keep over-reads finite
-        s_a[k] = make_float2(0.f, 0.f);
-        s_b[k] = make_float2(0.f, 0.f);
-        s_c[k] = make_float2(0.f, 0.f);
-        s_d[k] = make_float2(0.f, 0.f);
-    }
+    // One candidate = 4 float2 {x,y} {z,vx} {vy,vz} {cp,w} at a 40-byte stride (5 float2, the fifth is
+    // padding): one address register serves all four ds_read_b64 through immediate offsets, and the
+    // 8-entry (one cell) distance between the lane groups of a wave is 80 dwords = 16 banks, so the four
+    // distinct addresses of a half-wave never share a bank.
+    __shared__ float2 s_e[LDS_ENT * 5];
+    for (uint32_t k = threadIdx.x; k < LDS_ENT * 5; k += PAIR_THREADS)   // see LDS_ENT: keep over-reads finite
+        s_e[k] = make_float2(0.f, 0.f);
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slice = wave * PIECE;
@@ -324,18 +321,20 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             if (FORCE) { e0 = dp[a + lane]; e1 = dp[a + WAVE + lane]; }
         },
         [&]() {
-            s_a[slice + lane] = make_float2(q0.x, q0.y);
-            s_b[slice + lane] = make_float2(q0.z, w0.x);
-            s_c[slice + lane] = make_float2(w0.y, w0.z);
-            s_a[slice + WAVE + lane] = make_float2(q1.x, q1.y);
-            s_b[slice + WAVE + lane] = make_float2(q1.z, w1.x);
-            s_c[slice + WAVE + lane] = make_float2(w1.y, w1.z);
+            float2* e0p = &s_e[(slice + lane) * 5];
+            float2* e1p = &s_e[(slice + WAVE + lane) * 5];
+            e0p[0] = make_float2(q0.x, q0.y);
+            e0p[1] = make_float2(q0.z, w0.x);
+            e0p[2] = make_float2(w0.y, w0.z);
+            e1p[0] = make_float2(q1.x, q1.y);
+            e1p[1] = make_float2(q1.z, w1.x);
+            e1p[2] = make_float2(w1.y, w1.z);
             if (FORCE) {
                 // staged per candidate: cp_j = (spiky/visc) * p_j and w_j = visc * 1/rho_j (v_rcp_f32), so
                 // that the pair loop needs w = w_j*(h-r) for viscosity and (cp_i+cp_j)*w*(h-r)/r for pressure.
                 // Padding entries have rho = 0 -> weight 0.
-                s_d[slice + lane] = make_float2(cps * e0.y, e0.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e0.x) : 0.f);
-                s_d[slice + WAVE + lane] = make_float2(cps * e1.y, e1.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e1.x) : 0.f);
+                e0p[3] = make_float2(cps * e0.y, e0.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e0.x) : 0.f);
+                e1p[3] = make_float2(cps * e1.y, e1.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e1.x) : 0.f);
             }
         },
         [&](int r, uint32_t a, uint32_t b) {
@@ -353,18 +352,19 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                 for (uint32_t t = t0; t < tend; t += SPH_FORCE_UNROLL) {
 #pragma unroll
                     for (int u = 0; u < SPH_FORCE_UNROLL; u++) {
-                        const float2 qa = s_a[idx + u], qb = s_b[idx + u];
+                        const float2* e = &s_e[(idx + u) * 5];
+                        const float2 qa = e[0], qb = e[1];
                         const bool valid = t + u < len;
                         const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
                         const float r2 = dx * dx + dy * dy + dz * dz;
                         if (FORCE) {
-                            const float2 qc = s_c[idx + u], qd = s_d[idx + u];
+                            const float2 qc = e[2], qd = e[3];
                             const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
                             const bool in = valid && r2 < ph.h2;
-                            // r = 0 (the particle itself, coincident particles): 1/r is clamped to 1e15, r*1/r = 0,
+                            // r = 0 (the particle itself, coincident particles): 1/r is capped at 1e15, r*1/r = 0,
                             // and the huge but finite pressure weight multiplies r_ij = 0 -- no pressure term, as
                             // with Eigen's normalized() of a zero vector (Dot.h:124-134); the viscous term is exact.
-                            const float rinv = inv_sqrt(fmaxf(r2, 1e-30f));
+                            const float rinv = inv_sqrt(r2 + 1e-30f);      // r2 >= 0; an add, not fmaxf (no canonicalise)
                             const float hr = ph.h - r2 * rinv;
                             float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
                             float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
@@ -386,7 +386,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                             const uint32_t hb = 31u - (uint32_t)__clz((int)near);
                             near &= ~(1u << hb);
                             const uint32_t ci = idx0 + (done - 1u - hb);
-                            const float2 qa = s_a[ci], qb = s_b[ci], qc = s_c[ci];
+                            const float2* e = &s_e[ci * 5];
+                            const float2 qa = e[0], qb = e[1], qc = e[2];
                             const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
                             const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;
 #if SPH_COLL_EXACT
