@@ -32,7 +32,7 @@ static uint32_t next_pow2(uint32_t x) {   // nextPow2, SPH/particleSystem.h:34-4
     return x;
 }
 
-static int derive(sph_ctx* c, const sph_params* p, uint32_t z_lo, uint32_t z_hi) {
+static int derive(sph_ctx* c, const sph_params* p, uint32_t z_lo, uint32_t z_hi, bool slab) {
     for (int a = 0; a < 3; a++) {
         SPH_REQUIRE(p->grid[a] >= 1 && p->grid[a] <= 4096, SPH_E_INVALID, "grid[%d] = %u out of range", a, p->grid[a]);
         SPH_REQUIRE(p->box_max[a] > p->box_min[a], SPH_E_INVALID, "empty box on axis %d", a);
@@ -47,8 +47,10 @@ static int derive(sph_ctx* c, const sph_params* p, uint32_t z_lo, uint32_t z_hi)
         g.g[a] = p->grid[a];
         g.gf[a] = (float)p->grid[a];
     }
-    g.z_lo = z_lo;
-    g.zl = z_hi - z_lo + 2;
+    c->z_lo = z_lo; c->z_hi = z_hi;
+    g.z_off = slab ? (int32_t)z_lo - 1 : 0;
+    g.zl = slab ? z_hi - z_lo + 2 : p->grid[2];
+    SPH_REQUIRE(slab || (z_lo == 0 && z_hi == p->grid[2]), SPH_E_INVALID, "a whole-domain context owns every layer");
     uint64_t nc = (uint64_t)g.g[0] * g.g[1] * g.zl;
     SPH_REQUIRE(nc < (1ull << 32), SPH_E_INVALID, "cell table too large (%llu cells)", (unsigned long long)nc);
     g.ncells = (uint32_t)nc;
@@ -126,7 +128,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     sph_ctx* c = new (std::nothrow) sph_ctx();
     SPH_REQUIRE(c, SPH_E_NOMEM, "out of host memory");
     c->device = device;
-    int rc = derive(c, p, z_lo, z_hi);
+    int rc = derive(c, p, z_lo, z_hi, slab);
     if (rc) { delete c; return rc; }
     c->cap = capacity; c->gcap = gcap; c->tot = capacity + 2 * gcap; c->slab = slab;
     c->own_off = gcap;
@@ -149,8 +151,8 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (!rc) rc = dev_alloc(&c->v0, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->k1, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->v1, (size_t)capacity);
-    if (!rc) rc = dev_alloc(&c->hist, (size_t)256 * c->sort_blocks_cap);
-    if (!rc) rc = dev_alloc(&c->digit_tot, (size_t)256);
+    if (!rc) rc = dev_alloc(&c->hist, (size_t)1024 * c->sort_blocks_cap);
+    if (!rc) rc = dev_alloc(&c->digit_tot, (size_t)1024);
     if (!rc) rc = dev_alloc(&c->d_scratch, (size_t)64);
     if (!rc && hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(uint32_t)) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -210,6 +212,7 @@ static int do_hash(sph_ctx* c) {
     if (rc) return rc;
     rc = launch_hash(c);
     if (rc) return rc;
+    c->keys_fresh = false;               // consumed (the sort reorders k0)
     c->stage = sph_ctx::ST_HASHED;
     return SPH_OK;
 }
@@ -227,10 +230,13 @@ static int do_sort(sph_ctx* c) {
 
 static int do_cells(sph_ctx* c) {
     PhaseTimer t(c, SPH_PH_BGRID);
-    int rc = launch_cells_clear(c);      // no-op unless a table is still installed (ghosts re-installed)
-    if (rc) return rc;
-    rc = launch_cells_build(c);
-    if (rc) return rc;
+    const uint32_t lo = c->own_off - c->n_glo, hi = c->own_off + c->n + c->n_ghi;
+    if (!(c->cells_valid && c->cells_lo == lo && c->cells_hi == hi)) {   // whole-domain: built by the sort's reorder pass
+        int rc = launch_cells_clear(c);      // a table over the old ghost set, if any
+        if (rc) return rc;
+        rc = launch_cells_build(c);
+        if (rc) return rc;
+    }
     c->stage = sph_ctx::ST_CELLS;
     return SPH_OK;
 }
@@ -319,8 +325,7 @@ int sph_set_params(sph_ctx* c, const sph_params* p) {
         SPH_REQUIRE(p->grid[a] == c->params.grid[a], SPH_E_INVALID, "the grid cannot change after sph_create");
     sph_ctx tmp;   // validate first
     tmp.params = c->params;
-    uint32_t z_lo = c->grid.z_lo, z_hi = c->grid.z_lo + c->grid.zl - 2;
-    int rc = derive(&tmp, p, z_lo, z_hi);
+    int rc = derive(&tmp, p, c->z_lo, c->z_hi, c->slab);
     if (rc) return rc;
     c->params = tmp.params; c->grid = tmp.grid; c->phys = tmp.phys;
     return SPH_OK;
@@ -377,6 +382,7 @@ int sph_upload(sph_ctx* c, uint32_t n, const float* pos, const float* vel, const
     }
     SPH_HIP(hipStreamSynchronize(c->stream));
     c->stage = sph_ctx::ST_LOADED;
+    c->keys_fresh = false;
     c->have_dens = c->have_force = c->have_coll = false;
     return SPH_OK;
 }
@@ -506,7 +512,7 @@ int sph_get_cells(sph_ctx* c, uint32_t max_cells, uint32_t* key, uint32_t* start
 
 uint32_t sph_cell_key(const sph_ctx* c, uint32_t x, uint32_t y, uint32_t z) {
     if (!c) return 0;
-    return ((z - c->grid.z_lo + 1) * c->grid.g[1] + y) * c->grid.g[0] + x;
+    return ((uint32_t)((int32_t)z - c->grid.z_off) * c->grid.g[1] + y) * c->grid.g[0] + x;
 }
 
 // ---- phases -------------------------------------------------------------------------------------------------------

@@ -22,8 +22,8 @@ struct GridDesc {
     float box_dims[3];     // box_max - box_min
     uint32_t g[3];         // global cells per axis
     float gf[3];           // (float)g
-    uint32_t z_lo;         // first owned global z layer
-    uint32_t zl;           // local z layers = owned + 2 ghost layers
+    int32_t z_off;         // local z layer = global z layer - z_off (slab: z_lo - 1; whole domain: 0)
+    uint32_t zl;           // local z layers (slab: owned + 2 ghost layers; whole domain: g[2])
     uint32_t ncells;       // g[0]*g[1]*zl
 };
 
@@ -55,6 +55,7 @@ struct sph_ctx {
     uint32_t gcap = 0;       // ghost capacity per side (0: whole-domain context)
     uint32_t tot = 0;        // gcap + cap + gcap
     bool slab = false;
+    uint32_t z_lo = 0, z_hi = 0;   // owned global cell layers
 
     // counts
     uint32_t n = 0;          // owned particles
@@ -81,6 +82,7 @@ struct sph_ctx {
     uint2* cells = nullptr;
     uint32_t cells_lo = 0, cells_hi = 0;   // slot range the table was built from
     bool cells_valid = false;
+    bool keys_fresh = false;   // k0 already holds the keys of the current positions (written by the integrate epilogue)
 
     // radix sort scratch
     uint32_t* k0 = nullptr; uint32_t* v0 = nullptr;

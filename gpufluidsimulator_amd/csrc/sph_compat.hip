@@ -183,6 +183,7 @@ void cudaMapZIndex(sph_compat_particle* p, unsigned int n, sph_compat_simparams*
         CKH(hipGetLastError());
     }
     x->stage = sph_ctx::ST_LOADED;
+    x->keys_fresh = false;
     x->have_dens = x->have_force = x->have_coll = false;
     CK(sph_hash(x));
     writeback(c, p, F_ZINDEX);

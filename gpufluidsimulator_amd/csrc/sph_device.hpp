@@ -49,15 +49,15 @@ __device__ __forceinline__ uint32_t cell_coord(float p, float bmin, float bdim, 
     return (uint32_t)c;
 }
 
-// Local cell key: x fastest, then y, then the slab-local z layer (global z - z_lo + 1; layer 0 and
-// layer zl-1 are the ghost layers).  The reference numbers cells in Morton order
+// Local cell key: x fastest, then y, then the local z layer (global z - z_off; in a slab context
+// layer 0 and layer zl-1 are the ghost layers, a whole-domain context has none).  The reference numbers cells in Morton order
 // (particleSystem.cu:68-91); the numbering is internal: results are reported by creation index.
 __device__ __forceinline__ uint32_t cell_key(const GridDesc& g, float x, float y, float z) {
     uint32_t cx = cell_coord(x, g.box_min[0], g.box_dims[0], g.gf[0], g.g[0]);
     uint32_t cy = cell_coord(y, g.box_min[1], g.box_dims[1], g.gf[1], g.g[1]);
     uint32_t cz = cell_coord(z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]);
-    // particles outside [z_lo-1, z_lo+zl-2] cannot be represented: clamp into the ghost layers
-    int lz = (int)cz - (int)g.z_lo + 1;
+    // particles outside the local layers cannot be represented: clamp into the outermost ones
+    int lz = (int)cz - g.z_off;
     lz = lz < 0 ? 0 : lz;
     lz = lz >= (int)g.zl ? (int)g.zl - 1 : lz;
     return ((uint32_t)lz * g.g[1] + cy) * g.g[0] + cx;

@@ -125,6 +125,7 @@ int sph_migrants_append(sph_ctx* c, const void* buf_dev, uint32_t n_in) {
                        c->posi + at, c->velr + at, (uint32_t*)nullptr, c->grid, 0);
     SPH_HIP(hipGetLastError());
     c->n += n_in;
+    c->keys_fresh = false;
     c->stage = sph_ctx::ST_LOADED;   // order destroyed: hash + sort again
     return SPH_OK;
 }
@@ -226,7 +227,7 @@ int sph_layer_histogram(sph_ctx* c, uint32_t* hist, uint32_t n_layers) {
     SPH_REQUIRE(n_layers == c->grid.g[2], SPH_E_INVALID, "n_layers must be the global z grid size %u", c->grid.g[2]);
     const uint32_t layer = c->grid.g[0] * c->grid.g[1];
     for (uint32_t l = 0; l < n_layers; l++) hist[l] = 0;
-    // local layers 0 .. zl-1 hold global layers z_lo-1 .. z_lo+zl-2
+    // local layer l holds global layer l + z_off
     uint32_t prev = 0;
     for (uint32_t ll0 = 0; ll0 < c->grid.zl; ll0 += 30) {
         uint32_t m = c->grid.zl - ll0 < 30 ? c->grid.zl - ll0 : 30, tg[31], lb[31];
@@ -234,7 +235,7 @@ int sph_layer_histogram(sph_ctx* c, uint32_t* hist, uint32_t n_layers) {
         int rc = lower_bounds(c, tg, m, lb);
         if (rc) return rc;
         for (uint32_t k = 0; k < m; k++) {
-            int64_t gl = (int64_t)c->grid.z_lo - 1 + ll0 + k;
+            int64_t gl = (int64_t)c->grid.z_off + ll0 + k;
             if (gl >= 0 && gl < (int64_t)n_layers) hist[gl] = lb[k] - prev;
             prev = lb[k];
         }

@@ -284,8 +284,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     const float4* __restrict__ posi, const float4* __restrict__ velr, const float2* __restrict__ dp,
     const uint32_t* __restrict__ keyS, const uint2* __restrict__ cells, float4* __restrict__ fpress,
     float4* __restrict__ fvisc, float4* __restrict__ dvel, float4* __restrict__ posi_out,
-    float4* __restrict__ velr_out, float4* __restrict__ pos_by_index, uint32_t tgt_lo, uint32_t tgt_hi, float dt,
-    GridDesc g, Phys ph) {
+    float4* __restrict__ velr_out, float4* __restrict__ pos_by_index, uint32_t* __restrict__ keys_out,
+    uint32_t tgt_lo, uint32_t tgt_hi, float dt, GridDesc g, Phys ph) {
     // One candidate = 4 float2 {x,y} {z,vx} {vy,vz} {cp,w} at a 40-byte stride (5 float2, the fifth is
     // padding): one address register serves all four ds_read_b64 through immediate offsets, and the
     // 8-entry (one cell) distance between the lane groups of a wave is 80 dwords = 16 banks, so the four
@@ -419,6 +419,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
         posi_out[i] = pi;
         velr_out[i] = vi;
         if (pos_by_index) pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
+        // the next step's cell hash (kernelGetZIndex) while the new position is still in registers
+        keys_out[i - tgt_lo] = cell_key(g, pi.x, pi.y, pi.z);
     } else {
         if (FORCE) {
             fpress[i] = make_float4(fpx, fpy, fpz, 0.f);
@@ -434,7 +436,8 @@ int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt)
     dim3 grid(ceil_div(c->n, PAIR_THREADS)), block(PAIR_THREADS);
 #define SPH_LAUNCH_FORCE(F, C, I)                                                                              \
     hipLaunchKernelGGL((k_force<F, C, I>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->keyS, c->cells, \
-                       c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, lo, hi, dt, c->grid, c->phys)
+                       c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, c->k0, lo, hi, dt, c->grid,  \
+                       c->phys)
     if (force && collide && integrate) SPH_LAUNCH_FORCE(true, true, true);
     else if (force && !collide && !integrate) SPH_LAUNCH_FORCE(true, false, false);
     else if (!force && collide && !integrate) SPH_LAUNCH_FORCE(false, true, false);
@@ -448,6 +451,7 @@ int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt)
         float4* t;
         t = c->posi; c->posi = c->posi2; c->posi2 = t;
         t = c->velr; c->velr = c->velr2; c->velr2 = t;
+        c->keys_fresh = true;
     }
     return SPH_OK;
 }

@@ -13,9 +13,9 @@ constexpr int SORT_THREADS = 256;            // 4 waves
 constexpr int SORT_KPT = 16;                 // keys per thread
 constexpr int SORT_WAVE_TILE = WAVE * SORT_KPT;          // 1024 consecutive keys per wave
 constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;       // 4096 keys per block
-constexpr int RADIX = 256;
+constexpr int MAX_RADIX = 1024;
 
-// ---- hash: key per owned particle + identity slot -------------------------------------------
+// ---- hash: key per owned particle ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hash(const float4* __restrict__ posi, uint32_t n, GridDesc g,
                                               uint32_t* __restrict__ keys) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -25,20 +25,23 @@ __global__ __launch_bounds__(256) void k_hash(const float4* __restrict__ posi, u
 }
 
 // ---- pass 1 of 3: per-block digit histogram ----------------------------------------------------
+// BITS = 8, 9 or 10 bits per pass: 27 significant key bits (512^3 cells) sort in 3 passes of 9.
+template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys, uint32_t n,
                                                             uint32_t shift, uint32_t nblocks,
                                                             uint32_t* __restrict__ hist) {
+    constexpr int RADIX = 1 << BITS;
     __shared__ uint32_t h[RADIX];
-    h[threadIdx.x] = 0;
+    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
     uint32_t base = blockIdx.x * SORT_TILE;
 #pragma unroll
     for (int t = 0; t < SORT_KPT; t++) {
         uint32_t i = base + t * SORT_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFFu], 1u);
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];   // digit-major
+    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) hist[(size_t)d * nblocks + blockIdx.x] = h[d];   // digit-major
 }
 
 // ---- pass 2 of 3: one block per digit scans its row of per-block counts --------------------------
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t* __restrict__ hist, 
     __shared__ uint32_t part[256];
     uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
     uint32_t per = (nblocks + 255u) / 256u;
-    uint32_t lo = threadIdx.x * per;
+    uint32_t lo = min(threadIdx.x * per, nblocks);
     uint32_t hi = min(lo + per, nblocks);
     uint32_t s = 0;
     for (uint32_t i = lo; i < hi; i++) s += row[i];
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t* __restrict__ hist, 
 // Each wave owns 1024 consecutive keys of the block's tile and walks them 64 at a time in order.
 // Rank of a key among equal digits inside one 64-key row: ballot-based match-any + popcount of the
 // lower lanes; running per-wave, per-digit counters live in LDS.
-template <bool FIRST>
+template <int BITS, bool FIRST>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* __restrict__ kin,
                                                                const uint32_t* __restrict__ vin,
                                                                uint32_t* __restrict__ kout,
@@ -81,21 +84,34 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* _
                                                                uint32_t shift, uint32_t nblocks,
                                                                const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ digit_tot) {
+    constexpr int RADIX = 1 << BITS;
+    constexpr int DPT = RADIX / SORT_THREADS;       // digits per thread: 1, 2 or 4 (consecutive digits)
     __shared__ uint32_t wh[4][RADIX];     // per-wave digit counters -> running offsets
-    __shared__ uint32_t dbase[RADIX];
+    __shared__ uint32_t part[SORT_THREADS];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (int w = 0; w < 4; w++) wh[w][threadIdx.x] = 0;
-    // exclusive scan of the 256 digit totals (global base of every digit)
-    uint32_t tot = digit_tot[threadIdx.x];
-    dbase[threadIdx.x] = tot;
+    for (int w = 0; w < 4; w++)
+        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) wh[w][d] = 0;
+    // exclusive scan of the digit totals (global base of every digit): thread t owns digits t*DPT ..
+    uint32_t tot[DPT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < DPT; k++) { tot[k] = digit_tot[threadIdx.x * DPT + k]; sum += tot[k]; }
+    part[threadIdx.x] = sum;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t v = threadIdx.x >= (uint32_t)off ? dbase[threadIdx.x - off] : 0u;
+    for (int off = 1; off < SORT_THREADS; off <<= 1) {
+        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0u;
         __syncthreads();
-        dbase[threadIdx.x] += v;
+        part[threadIdx.x] += v;
         __syncthreads();
     }
-    uint32_t my_base = dbase[threadIdx.x] - tot + hist[threadIdx.x * nblocks + blockIdx.x];
+    uint32_t my_base[DPT];
+    {
+        uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+            my_base[k] = run + hist[(size_t)(threadIdx.x * DPT + k) * nblocks + blockIdx.x];
+            run += tot[k];
+        }
+    }
 
     // load this wave's keys (registers) and count digits per wave
     const uint32_t wbase = blockIdx.x * SORT_TILE + wave * SORT_WAVE_TILE;
@@ -104,16 +120,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* _
     for (int t = 0; t < SORT_KPT; t++) {
         uint32_t i = wbase + t * WAVE + lane;
         key[t] = i < n ? kin[i] : 0xFFFFFFFFu;
-        if (i < n) atomicAdd(&wh[wave][(key[t] >> shift) & 0xFFu], 1u);
+        if (i < n) atomicAdd(&wh[wave][(key[t] >> shift) & (RADIX - 1)], 1u);
     }
     __syncthreads();
     // per digit: exclusive scan over the 4 waves, plus the global base
-    {
-        uint32_t o = my_base;
+#pragma unroll
+    for (int k = 0; k < DPT; k++) {
+        const uint32_t d = threadIdx.x * DPT + k;
+        uint32_t o = my_base[k];
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            uint32_t cnt = wh[w][threadIdx.x];
-            wh[w][threadIdx.x] = o;
+            uint32_t cnt = wh[w][d];
+            wh[w][d] = o;
             o += cnt;
         }
     }
@@ -125,10 +143,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* _
     for (int t = 0; t < SORT_KPT; t++) {
         uint32_t i = wbase + t * WAVE + lane;
         bool valid = i < n;
-        uint32_t d = (key[t] >> shift) & 0xFFu;
+        uint32_t d = (key[t] >> shift) & (RADIX - 1);
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < BITS; b++) {
             bool bit = (d >> b) & 1u;
             uint64_t m = __ballot(bit);
             peers &= bit ? m : ~m;
@@ -147,36 +165,47 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* _
     }
 }
 
-// ---- reorder: gather the SoA payload into sorted order -------------------------------------------
+// ---- reorder: gather the SoA payload into sorted order; optionally build the cell table ------------
+// CELLS: the {start, end} entries of kernelConstructBGrid (.cu:311-329) fall out of the same pass
+// (boundary flags on the sorted keys, no atomics) when no ghost layers will be added afterwards.
+template <bool CELLS>
 __global__ __launch_bounds__(256) void k_reorder(const uint32_t* __restrict__ ks, const uint32_t* __restrict__ vs,
                                                  uint32_t n, const float4* __restrict__ posi,
                                                  const float4* __restrict__ velr, float4* __restrict__ posi_out,
-                                                 float4* __restrict__ velr_out, uint32_t* __restrict__ key_out) {
+                                                 float4* __restrict__ velr_out, uint32_t* __restrict__ key_out,
+                                                 uint2* __restrict__ cells, uint32_t slot0) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     uint32_t src = vs[i];
+    uint32_t k = ks[i];
     posi_out[i] = posi[src];
     velr_out[i] = velr[src];
-    key_out[i] = ks[i];
-}
-
-__global__ __launch_bounds__(256) void k_copy_sorted(uint32_t n, const float4* __restrict__ posi,
-                                                     const float4* __restrict__ velr, const uint32_t* __restrict__ ks,
-                                                     float4* __restrict__ posi_out, float4* __restrict__ velr_out,
-                                                     uint32_t* __restrict__ key_out) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    posi_out[i] = posi[i];
-    velr_out[i] = velr[i];
-    key_out[i] = ks[i];
+    key_out[i] = k;
+    if (CELLS) {
+        if (i == 0 || ks[i - 1] != k) cells[k].x = slot0 + i;
+        if (i + 1 == n || ks[i + 1] != k) cells[k].y = slot0 + i + 1;
+    }
 }
 
 int launch_hash(sph_ctx* c) {
-    if (c->n == 0) return SPH_OK;
+    if (c->n == 0 || c->keys_fresh) return SPH_OK;    // keys_fresh: the integrate epilogue already hashed
     hipLaunchKernelGGL(k_hash, dim3(ceil_div(c->n, 256)), dim3(256), 0, c->stream, c->posi + c->own_off, c->n,
                        c->grid, c->k0);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
+}
+
+template <int BITS>
+static void sort_pass(sph_ctx* c, uint32_t n, uint32_t nblocks, uint32_t shift, bool first, const uint32_t* kin,
+                      const uint32_t* vin, uint32_t* kout, uint32_t* vout) {
+    hipLaunchKernelGGL(k_sort_hist<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, n, shift, nblocks, c->hist);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1 << BITS), dim3(256), 0, c->stream, c->hist, nblocks, c->digit_tot);
+    if (first)
+        hipLaunchKernelGGL((k_sort_scatter<BITS, true>), dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
+                           vout, n, shift, nblocks, c->hist, c->digit_tot);
+    else
+        hipLaunchKernelGGL((k_sort_scatter<BITS, false>), dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
+                           vout, n, shift, nblocks, c->hist, c->digit_tot);
 }
 
 int launch_sort(sph_ctx* c) {
@@ -187,32 +216,37 @@ int launch_sort(sph_ctx* c) {
                 c->sort_blocks_cap);
     uint32_t* kin = c->k0; uint32_t* vin = c->v0;
     uint32_t* kout = c->k1; uint32_t* vout = c->v1;
-    const uint32_t passes = (c->key_bits + 7) / 8;
+    // fewest passes of at most 10 bits, then the narrowest digit that still covers the key
+    const uint32_t passes = (c->key_bits + 9) / 10;
+    uint32_t bits = (c->key_bits + passes - 1) / passes;
+    if (bits < 8) bits = 8;
     for (uint32_t p = 0; p < passes; p++) {
-        const uint32_t shift = p * 8;
-        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, n, shift, nblocks,
-                           c->hist);
-        hipLaunchKernelGGL(k_sort_scan, dim3(RADIX), dim3(256), 0, c->stream, c->hist, nblocks, c->digit_tot);
-        if (p == 0)
-            hipLaunchKernelGGL(k_sort_scatter<true>, dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
-                               vout, n, shift, nblocks, c->hist, c->digit_tot);
-        else
-            hipLaunchKernelGGL(k_sort_scatter<false>, dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
-                               vout, n, shift, nblocks, c->hist, c->digit_tot);
+        const uint32_t shift = p * bits;
+        if (bits == 8) sort_pass<8>(c, n, nblocks, shift, p == 0, kin, vin, kout, vout);
+        else if (bits == 9) sort_pass<9>(c, n, nblocks, shift, p == 0, kin, vin, kout, vout);
+        else sort_pass<10>(c, n, nblocks, shift, p == 0, kin, vin, kout, vout);
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
     }
-    // (kin, vin) now hold the sorted pairs; gather the payload to the canonical offset gcap
-    hipLaunchKernelGGL(k_reorder, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, kin, vin, n,
-                       c->posi + c->own_off, c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap,
-                       c->keyS + c->gcap);
+    // (kin, vin) now hold the sorted pairs; gather the payload to the canonical offset gcap.  A
+    // whole-domain context gets no ghosts later, so its cell table is built in the same pass.
+    const bool cells = !c->slab;
+    if (cells)
+        hipLaunchKernelGGL(k_reorder<true>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, kin, vin, n,
+                           c->posi + c->own_off, c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap,
+                           c->keyS + c->gcap, c->cells, c->gcap);
+    else
+        hipLaunchKernelGGL(k_reorder<false>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, kin, vin, n,
+                           c->posi + c->own_off, c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap,
+                           c->keyS + c->gcap, c->cells, c->gcap);
     SPH_HIP(hipGetLastError());
     float4* t4;
     t4 = c->posi; c->posi = c->posi2; c->posi2 = t4;
     t4 = c->velr; c->velr = c->velr2; c->velr2 = t4;
     c->own_off = c->gcap;
     c->last_perm = vin;
+    if (cells) { c->cells_lo = c->gcap; c->cells_hi = c->gcap + n; c->cells_valid = true; }
     return SPH_OK;
 }
 

@@ -55,7 +55,8 @@ def test_hash_sort_cells_bit_exact(name):
         c.hash()
         o = _oracle_linear(g)
         o.map_zindex()
-        want = o.particles["zindex"] + np.uint32(gx * gy)        # local z = global z + 1 (ghost layer 0)
+        off = np.uint32(c.cell_key(0, 0, 0))                      # 0 for a whole-domain context (no ghost layer)
+        want = o.particles["zindex"] + off
         assert np.array_equal(c.keys(), want)
         c.sort()
         order = np.argsort(want, kind="stable").astype(np.uint32)
@@ -66,7 +67,7 @@ def test_hash_sort_cells_bit_exact(name):
         o.sort(); o.construct_bgrid()
         B = o.B
         occ = np.nonzero(B["nParticles"])[0].astype(np.uint32)
-        assert np.array_equal(k, occ + np.uint32(gx * gy))
+        assert np.array_equal(k, occ + off)
         assert np.array_equal(s, B["start"][occ]) and np.array_equal(cnt, B["nParticles"][occ])
         o.close()
 
