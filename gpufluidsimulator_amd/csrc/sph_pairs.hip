@@ -84,10 +84,18 @@ __device__ __forceinline__ void row_range(const uint2* __restrict__ cells, uint3
 __device__ __forceinline__ void lane_rows(const uint2* __restrict__ cells, const GridDesc& g, uint32_t key, bool active,
                                           Rows& R) {
     const uint32_t gx = g.g[0], gy = g.g[1];
-    uint32_t cx = key % gx;
-    uint32_t t = key / gx;
-    uint32_t cy = t % gy;
-    uint32_t lz = t / gy;      // owned targets: 1 <= lz <= zl-2, so lz-1 and lz+1 are valid layers
+    uint32_t cx, cy, lz;
+    if (((gx & (gx - 1u)) | (gy & (gy - 1u))) == 0u) {   // the reference's grids are powers of two (nextPow2)
+        const uint32_t sx = 31u - (uint32_t)__clz((int)gx), sy = 31u - (uint32_t)__clz((int)gy);
+        cx = key & (gx - 1u);
+        cy = (key >> sx) & (gy - 1u);
+        lz = key >> (sx + sy);
+    } else {
+        cx = key % gx;
+        const uint32_t t = key / gx;
+        cy = t % gy;
+        lz = t / gy;
+    }
 #pragma unroll
     for (int dz = -1; dz <= 1; dz++) {
 #pragma unroll
@@ -137,12 +145,17 @@ struct Hulls {
     uint32_t A[9], B[9];
 };
 
+// Lanes are in key order and the row offset is the same for every lane, so lo and hi are
+// non-decreasing across the lanes that have a range: the hull is [lo of the first such lane, hi of
+// the last one) -- one ballot and two v_readlane instead of two cross-lane reductions.
 __device__ __forceinline__ void wave_hulls(const Rows& R, Hulls& H) {
 #pragma unroll
     for (int r = 0; r < 9; r++) {
-        const bool has = R.hi[r] > R.lo[r];
-        H.A[r] = wave_min_u32(has ? R.lo[r] : 0xFFFFFFFFu);
-        H.B[r] = wave_max_u32(has ? R.hi[r] : 0u);
+        const uint64_t m = __ballot(R.hi[r] > R.lo[r]);
+        if (m == 0ull) { H.A[r] = 0u; H.B[r] = 0u; continue; }
+        const int first = __builtin_ctzll(m), last = 63 - __builtin_clzll(m);
+        H.A[r] = (uint32_t)__builtin_amdgcn_readlane((int)R.lo[r], first);
+        H.B[r] = (uint32_t)__builtin_amdgcn_readlane((int)R.hi[r], last);
     }
 }
 
@@ -215,9 +228,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
         [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
             const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
-            const uint32_t T = wave_max_u32(len);
             uint32_t idx = slice + (len ? l0 - a : 0u);
-            for (uint32_t t = 0; t < T; t += UNROLL) {
+            for (uint32_t t = 0; __ballot(t < len) != 0ull; t += UNROLL) {   // until every lane is through its range
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
                     const float2 xy = s_xy[idx + u];
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
         [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
             const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
-            const uint32_t T = wave_max_u32(len);
+            const uint32_t T = wave_max_u32(len);      // a known trip count lets hipcc interleave two candidates
             uint32_t idx = slice + (len ? l0 - a : 0u);
             // Candidates are walked in chunks of 32.  The pressure/viscosity arithmetic runs for every
             // candidate; the collision test only records "d <= 2R" in a per-lane bit mask (2 VALU per
