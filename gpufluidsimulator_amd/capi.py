@@ -51,6 +51,9 @@ SIGNATURES = {
     "sph_upload": (C.c_int, [_P, _U32, _P, _P, _P]),
     "sph_download": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
     "sph_download_forces": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
+    "sph_snapshot_save": (C.c_int, [_P, C.c_char_p]),
+    "sph_snapshot_load": (C.c_int, [_P, C.c_char_p]),
+    "sph_snapshot_info": (C.c_int, [C.c_char_p, C.POINTER(_U32), C.POINTER(Params)]),
     "sph_positions_dev": (C.c_int, [_P, C.POINTER(_P)]),
     "sph_download_positions4": (C.c_int, [_P, _P]),
     "sph_get_keys": (C.c_int, [_P, _P]),
@@ -209,6 +212,18 @@ class Context:
         ptr = lambda k: out[k].ctypes.data if k in out else None
         _check(self.L.sph_download_forces(self.h, int(index_base), ptr("fpress"), ptr("fvisc"), ptr("dv"), ptr("count")))
         return out
+
+    def save(self, path):
+        _check(self.L.sph_snapshot_save(self.h, os.fsencode(path)))
+
+    def load_snapshot(self, path):
+        _check(self.L.sph_snapshot_load(self.h, os.fsencode(path)))
+
+    @staticmethod
+    def snapshot_info(path):
+        n, p = _U32(0), Params()
+        _check(load().sph_snapshot_info(os.fsencode(path), C.byref(n), C.byref(p)))
+        return int(n.value), p
 
     def positions4(self):
         out = np.empty((self.capacity, 4), dtype=np.float32)

@@ -86,7 +86,7 @@ extern "C" void sph_ic_random_box(uint64_t n, const float box[3], float speed, u
 // ---- lifetime (particleSystem.cpp:38-71, 108-190) ----------------------------------------------------
 ParticleSystem::ParticleSystem(uint numParticles, float3 boxDims, ParticleComputeMode mode)
     : m_bInitialized(false), m_numParticles(numParticles), m_boxDims(boxDims), m_solverIterations(1),
-      m_compute_mode(mode), m_ctx(nullptr), m_hostStale(false), m_log(nullptr), m_logLastMs(0), m_logGlobalMs(0) {
+      m_compute_mode(mode), m_ctx(nullptr), m_hostStale(false), m_log(nullptr), m_logLastMs(0), m_logGlobalMs(0), m_logFreqMs(2000.0) {
     if (mode != CUDA_PARALLEL) {
         fprintf(stderr, "ParticleSystem: only the GPU compute mode exists in this build "
                         "(SEQUENTIAL / OMP_PARALLEL are the reference's CPU paths; there is no CPU fallback)\n");
@@ -164,7 +164,7 @@ void ParticleSystem::update(float deltaTime, float fps) {
         using clk = std::chrono::steady_clock;
         const double now = std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
         if (m_logLastMs == 0) m_logLastMs = now;
-        if (now - m_logLastMs > 2000.0) {
+        if (now - m_logLastMs > m_logFreqMs) {
             float ms[SPH_PH_COUNT]; uint32_t steps = 0;
             SPH_CHECK(sph_timing_get(m_ctx, ms, &steps));
             SPH_CHECK(sph_timing_reset(m_ctx));
@@ -291,6 +291,16 @@ void* ParticleSystem::getPositionsDevice() {
     return p;
 }
 
+void ParticleSystem::saveState(const std::string& path) { SPH_CHECK(sph_snapshot_save(m_ctx, path.c_str())); }
+
+void ParticleSystem::loadState(const std::string& path) {
+    SPH_CHECK(sph_snapshot_load(m_ctx, path.c_str()));
+    m_numParticles = sph_num_particles(m_ctx);
+    m_hPos.assign((size_t)m_numParticles * 4, 0.f);
+    m_hVel.assign((size_t)m_numParticles * 4, 0.f);
+    m_hostStale = true;
+}
+
 void ParticleSystem::enablePhaseTimings(bool on) { SPH_CHECK(sph_timing_enable(m_ctx, on ? 1 : 0)); }
 
 bool ParticleSystem::phaseTimings(float ms[SPH_PH_COUNT], uint* steps) {
@@ -301,7 +311,8 @@ bool ParticleSystem::phaseTimings(float ms[SPH_PH_COUNT], uint* steps) {
     return s > 0;
 }
 
-void ParticleSystem::setBenchmarkLog(const std::string& path) {
+void ParticleSystem::setBenchmarkLog(const std::string& path, double min_interval_ms) {
+    m_logFreqMs = min_interval_ms;
     if (m_log) { fclose((FILE*)m_log); m_log = nullptr; }
     m_logPath = path;
     if (path.empty()) { SPH_CHECK(sph_timing_enable(m_ctx, 0)); return; }

@@ -439,6 +439,69 @@ int sph_download_forces(sph_ctx* c, uint32_t base, float* fp, float* fv, float* 
     return SPH_OK;
 }
 
+// ---- snapshots --------------------------------------------------------------------------------------------
+// layout: u32 magic 'SPHS', u32 version, u32 n, u32 sizeof(sph_params), sph_params, then n float4 posi
+// (x, y, z, creation index bits) and n float4 velr, both in slot order.
+static const uint32_t kSnapMagic = 0x53485053u, kSnapVersion = 1u;
+
+int sph_snapshot_save(sph_ctx* c, const char* path) {
+    SPH_REQUIRE(c && path, SPH_E_INVALID, "null argument");
+    std::vector<float4> hp, hv;
+    int rc = fetch_sorted(c, &hp, &hv, nullptr);
+    if (rc) return rc;
+    FILE* f = fopen(path, "wb");
+    SPH_REQUIRE(f, SPH_E_INVALID, "cannot open %s for writing", path);
+    const uint32_t hdr[4] = {kSnapMagic, kSnapVersion, c->n, (uint32_t)sizeof(sph_params)};
+    bool ok = fwrite(hdr, sizeof(hdr), 1, f) == 1 && fwrite(&c->params, sizeof(sph_params), 1, f) == 1;
+    if (c->n) ok = ok && fwrite(hp.data(), sizeof(float4), c->n, f) == c->n && fwrite(hv.data(), sizeof(float4), c->n, f) == c->n;
+    ok = (fclose(f) == 0) && ok;
+    SPH_REQUIRE(ok, SPH_E_INVALID, "short write to %s", path);
+    return SPH_OK;
+}
+
+static int snap_header(FILE* f, const char* path, uint32_t* n, sph_params* p) {
+    uint32_t hdr[4];
+    SPH_REQUIRE(fread(hdr, sizeof(hdr), 1, f) == 1 && hdr[0] == kSnapMagic, SPH_E_INVALID, "%s is not an SPH snapshot", path);
+    SPH_REQUIRE(hdr[1] == kSnapVersion && hdr[3] == sizeof(sph_params), SPH_E_INVALID, "%s: unsupported snapshot version", path);
+    SPH_REQUIRE(fread(p, sizeof(sph_params), 1, f) == 1, SPH_E_INVALID, "%s: truncated", path);
+    *n = hdr[2];
+    return SPH_OK;
+}
+
+int sph_snapshot_info(const char* path, uint32_t* n, sph_params* p) {
+    SPH_REQUIRE(path && n && p, SPH_E_INVALID, "null argument");
+    FILE* f = fopen(path, "rb");
+    SPH_REQUIRE(f, SPH_E_INVALID, "cannot open %s", path);
+    int rc = snap_header(f, path, n, p);
+    fclose(f);
+    return rc;
+}
+
+int sph_snapshot_load(sph_ctx* c, const char* path) {
+    SPH_REQUIRE(c && path, SPH_E_INVALID, "null argument");
+    FILE* f = fopen(path, "rb");
+    SPH_REQUIRE(f, SPH_E_INVALID, "cannot open %s", path);
+    uint32_t n = 0;
+    sph_params p;
+    int rc = snap_header(f, path, &n, &p);
+    if (rc) { fclose(f); return rc; }
+    if (n > c->cap) { fclose(f); set_error("snapshot holds %u particles, context capacity is %u", n, c->cap); return SPH_E_CAPACITY; }
+    std::vector<float4> hp(n), hv(n);
+    bool ok = n == 0 || (fread(hp.data(), sizeof(float4), n, f) == n && fread(hv.data(), sizeof(float4), n, f) == n);
+    fclose(f);
+    SPH_REQUIRE(ok, SPH_E_INVALID, "%s: truncated", path);
+    rc = sph_set_params(c, &p);            // rejects a different grid
+    if (rc) return rc;
+    std::vector<float> pos((size_t)n * 3), vel((size_t)n * 3);
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; i++) {
+        pos[3 * i] = hp[i].x; pos[3 * i + 1] = hp[i].y; pos[3 * i + 2] = hp[i].z;
+        vel[3 * i] = hv[i].x; vel[3 * i + 1] = hv[i].y; vel[3 * i + 2] = hv[i].z;
+        idx[i] = idx_of(hp[i]);
+    }
+    return sph_upload(c, n, pos.data(), vel.data(), idx.data());
+}
+
 int sph_positions_dev(sph_ctx* c, void** out) {
     SPH_REQUIRE(c && out, SPH_E_INVALID, "null argument");
     SPH_REQUIRE(!c->slab, SPH_E_STATE, "slab contexts keep no by-index position buffer");

@@ -53,11 +53,15 @@ int main(int argc, char** argv) {
     }
     ParticleSystem* psystem = new ParticleSystem(numParticles, make_float3(box, box, box), ParticleSystem::HIP_PARALLEL);
     psystem->reset(ParticleSystem::CONFIG_GRID);          // initParticleSystem, particles.cpp:119-132
+    if (const char* v = value(argc, argv, "load")) psystem->loadState(v);
     psystem->setIterations(substeps);
-    if (const char* v = value(argc, argv, "log")) psystem->setBenchmarkLog(v);
+    if (const char* v = value(argc, argv, "log")) {
+        const char* fq = value(argc, argv, "logfreq");
+        psystem->setBenchmarkLog(v, fq ? atof(fq) : 2000.0);
+    }
     uint3 g = psystem->getGridSize();
     printf("Run %u particles simulation for %d iterations... (grid %ux%ux%u, box %g)\n\n", numParticles, iterations, g.x, g.y, g.z, box);
-    psystem->update(timestep, 0);                         // warm-up, not timed
+    if (!flag(argc, argv, "nowarmup")) psystem->update(timestep, 0);   // warm-up step, not timed
     sph_sync(psystem->context());
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < iterations; ++i) psystem->update(timestep, (float)i);
@@ -71,6 +75,14 @@ int main(int argc, char** argv) {
     printf("{\"particle_steps_per_s\": %.1f, \"particles\": %u, \"iterations\": %d, \"steps_per_update\": %d, \"seconds\": %.6f}\n",
            (double)numParticles * iterations * substeps / secs, numParticles, iterations, substeps, secs);
     if (dump > 0) psystem->dumpParticles(0, (uint)dump);
+    if (const char* v = value(argc, argv, "out")) {      // xyzw per creation index, then vxyz0, raw fp32
+        FILE* f = fopen(v, "wb");
+        if (!f) { fprintf(stderr, "cannot open %s\n", v); return EXIT_FAILURE; }
+        fwrite(psystem->getArray(ParticleSystem::POSITION), sizeof(float) * 4, numParticles, f);
+        fwrite(psystem->getArray(ParticleSystem::VELOCITY), sizeof(float) * 4, numParticles, f);
+        fclose(f);
+    }
+    if (const char* v = value(argc, argv, "save")) psystem->saveState(v);
     (void)benchmark;
     delete psystem;
     return 0;

@@ -13,7 +13,7 @@
 //   * reset(CONFIG_GRID) builds an exact lattice with a counter-based jitter (see
 //     gpufluidsimulator_amd/ic.py); the reference's ceil(powf(N,1/3)) + rand() is not portable.
 //   * additive API named by the north star: getArray / setArray / setSimParams, plus
-//     getDensities(), setGrid(), stepTimings().
+//     getDensities(), getPositionsDevice(), phaseTimings(), saveState()/loadState().
 //   * errors abort the process like checkCudaErrors (common/inc/helper_cuda.h:566-579).
 #ifndef SPH_PARTICLESYSTEM_H
 #define SPH_PARTICLESYSTEM_H
@@ -97,8 +97,11 @@ public:
     // device-accurate per-phase times in ms since the last call (names as in dumpBenchmark)
     void enablePhaseTimings(bool on);
     bool phaseTimings(float ms[SPH_PH_COUNT], uint* steps);
+    // checkpoint / resume (sph_snapshot_save / sph_snapshot_load); a resumed run is bit-identical
+    void saveState(const std::string& path);
+    void loadState(const std::string& path);
     // opt-in text log in the reference's dumpBenchmark format (particleSystem.cpp:697-716)
-    void setBenchmarkLog(const std::string& path);
+    void setBenchmarkLog(const std::string& path, double min_interval_ms = 2000.0 /* BENCHMARK_FREQ */);
 
 protected:
     void _initialize(int numParticles);
@@ -119,7 +122,7 @@ protected:
     bool m_hostStale;
     std::string m_logPath;
     void* m_log;
-    double m_logLastMs, m_logGlobalMs;
+    double m_logLastMs, m_logGlobalMs, m_logFreqMs;
 };
 
 extern "C" {

@@ -123,6 +123,16 @@ int sph_download_forces(sph_ctx* c, uint32_t index_base, float* fpress_xyz, floa
 int sph_positions_dev(sph_ctx* c, void** out_dev);
 int sph_download_positions4(sph_ctx* c, float* pos_xyzw);
 
+/* State snapshot (checkpoint / resume; absent in the reference, whose device state is never
+ * serialised -- SURVEY.md section 5).  The file holds the parameters and, IN SLOT ORDER, position,
+ * velocity and creation index of every owned particle, so that a resumed run repeats the
+ * original one bit for bit (the sort is stable).  Little-endian, see csrc/sph_capi.hip. */
+int sph_snapshot_save(sph_ctx* c, const char* path);
+/* Load into an existing context (same grid; capacity >= the stored particle count). */
+int sph_snapshot_load(sph_ctx* c, const char* path);
+/* Number of particles and the parameters stored in a snapshot (to size a context for it). */
+int sph_snapshot_info(const char* path, uint32_t* n, sph_params* p);
+
 /* introspection for per-phase parity tests (sorted order) */
 int sph_get_keys(sph_ctx* c, uint32_t* keys);          /* cell key per slot */
 int sph_get_order(sph_ctx* c, uint32_t* index);        /* creation index per slot */

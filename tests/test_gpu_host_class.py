@@ -1,0 +1,78 @@
+"""GPU: the host C++ class (include/particleSystem.h) through the headless driver that mirrors the
+reference's main program, state snapshots, and the reference's benchmark log format."""
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from gpufluidsimulator_amd import capi, ic
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "gpufluidsimulator_amd", "sph_headless")
+DT = float(ic.DEFAULT_DT)
+
+
+def _run(*args):
+    out = subprocess.run([EXE] + list(args), check=True, capture_output=True, text=True, timeout=300)
+    return out.stdout
+
+
+def test_headless_driver_equals_c_abi_path():
+    """ParticleSystem(4096, box 4) + reset(CONFIG_GRID) + 5 x update()  ==  capi.Context + ic lattice."""
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "state.bin")
+        text = _run("-benchmark", "-n=4096", "-box=4", "-i=5", "-nowarmup", f"-out={f}")
+        raw = np.fromfile(f, dtype=np.float32).reshape(2, 4096, 4)
+    assert "Throughput = " in text and "KParticles/s" in text          # the reference's runBenchmark line
+    pos, vel = ic.dam_break_lattice((16, 16, 16), (4.0, 4.0, 4.0), jitter=True)
+    with capi.Context(4096, box=(4.0,) * 3, grid=(64,) * 3) as c:
+        c.upload(pos, vel)
+        c.step(DT, 5)
+        st = c.download()
+    assert np.array_equal(raw[0, :, :3].view(np.uint32), st["pos"].view(np.uint32))
+    assert np.array_equal(raw[1, :, :3].view(np.uint32), st["vel"].view(np.uint32))
+    assert np.all(raw[0, :, 3] == 1.0)
+
+
+def test_snapshot_resume_is_bit_identical():
+    pos, vel = ic.dam_break_lattice((20, 20, 20), (4.0, 4.0, 4.0), jitter=True)
+    pos[:, 1] += np.float32(0.5)
+    vel[:, 0] = 300.0                               # particles change cells, so the sort really permutes
+    with tempfile.TemporaryDirectory() as d, capi.Context(8000, box=(4.0,) * 3, grid=(64,) * 3) as a:
+        snap = os.path.join(d, "state.sph")
+        a.upload(pos, vel)
+        a.step(DT, 7)
+        a.save(snap)
+        a.step(DT, 9)
+        want = a.download()
+        n, p = capi.Context.snapshot_info(snap)
+        assert n == 8000 and tuple(p.grid) == (64, 64, 64)
+        with capi.Context(n, params=p) as b:
+            b.load_snapshot(snap)
+            b.step(DT, 9)
+            got = b.download()
+        with capi.Context(8000, box=(2.0,) * 3, grid=(32,) * 3) as wrong, pytest.raises(capi.SphError):
+            wrong.load_snapshot(snap)               # different grid
+    for k in ("pos", "vel", "density", "pressure"):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+
+
+def test_benchmark_log_has_the_reference_format():
+    """dumpBenchmark's line (SPH/particleSystem.cpp:703-714), now with device-accurate phase times."""
+    line = re.compile(r"^(\S+)sec\ttotal:(\d+)ns,\t\tcopying:(\d+)ns,\t\tz-index:(\d+)ns,\t\tsort:(\d+)ns,\t\tb-grid:(\d+)ns,"
+                      r"\t\tb'-grid:(\d+)ns,\t\tdens:(\d+)ns,\t\tforce:(\d+)ns,\t\tcollision:(\d+)ns,\t\tintegrate:(\d+)ns,"
+                      r"\t\tframes:(\d+)frames$")
+    with tempfile.TemporaryDirectory() as d:
+        log = os.path.join(d, "benchmark_HIP.txt")
+        _run("-benchmark", "-n=32768", "-box=4", "-i=40", f"-log={log}", "-logfreq=0")
+        lines = open(log).read().splitlines()
+    assert lines[0] == "SPH Particle Simulation Benchmark" and lines[1].startswith("Compute mode:")
+    body = [line.match(x) for x in lines[2:]]
+    assert len(body) >= 10 and all(body)
+    m = body[-1]
+    total, dens, force = int(m.group(2)), int(m.group(8)), int(m.group(9))
+    assert total > 0 and dens > 0 and force > 0 and dens + force <= total
