@@ -1,0 +1,98 @@
+"""GPU: inputs off the beaten path -- grids that are not powers of two and not cubic (the generic key
+decode), boxes with three different edges, fewer particles than one wave, everything in ONE cell
+(candidate hulls far longer than one staged piece), shuffled creation indices, a box change through
+sph_set_params, and particles faster than one cell per step."""
+import numpy as np
+import pytest
+
+from gpufluidsimulator_amd import capi, ic
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+def _compare(pos, vel, box, grid, dt, steps, index=None, rel=REL):
+    n = pos.shape[0]
+    with capi.Context(max(n, 1), box=box, grid=grid) as c:
+        c.upload(pos, vel, index)
+        c.step(dt, steps)
+        st = c.download(count=n)
+    o = oracle.Oracle(pos, vel, box, grid, oracle.CELL_LINEAR)
+    o.step(dt, steps)
+    so = o.state()
+    o.close()
+    if index is not None:                      # the context reports by the caller's creation index
+        inv = np.empty(n, dtype=np.int64); inv[index] = np.arange(n)
+        so = {k: v[inv] for k, v in so.items()}
+    assert np.abs(st["pos"] - so["pos"]).max() <= 1e-6 * max(box)
+    vs = max(np.abs(so["vel"]).max(), 1e-30)
+    bad = np.abs(st["vel"] - so["vel"]).max(axis=1) > rel * vs
+    assert bad.mean() <= 5e-3 and np.abs(st["vel"] - so["vel"]).max() <= 10 * rel * vs
+    assert np.abs(st["density"] / so["density"] - 1).max() <= rel
+    return st
+
+
+def test_non_power_of_two_non_cubic_grid():
+    box, grid = (3.0, 2.5, 3.5), (48, 40, 56)          # cell edge 0.0625 on every axis, nothing a power of two
+    pos, vel = ic.dam_break_lattice((20, 14, 24), box, jitter=True)
+    _compare(pos, vel, box, grid, 5e-7, 6)
+
+
+def test_anisotropic_cells():
+    box, grid = (2.0, 4.0, 8.0), (32, 32, 32)          # cells 0.0625 x 0.125 x 0.25
+    pos, vel = ic.random_box(3000, box, speed=10.0, fill=0.35)
+    _compare(pos, vel, box, grid, 1e-6, 4)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 65, 130])
+def test_fewer_particles_than_a_wave(n):
+    pos, vel = ic.random_box(n, (2.0, 2.0, 2.0), speed=3.0, fill=0.2)
+    _compare(pos, vel, (2.0, 2.0, 2.0), (32, 32, 32), 1e-6, 3)
+
+
+def test_everything_in_one_cell():
+    """600 particles in a single cell: every lane's range is longer than a 128-entry piece."""
+    rng = np.random.default_rng(3)
+    pos = (np.float32([0.1, -0.4, 0.3]) + rng.uniform(0.001, 0.061, (600, 3))).astype(np.float32)
+    pos = (np.floor((pos + 1.0) / 0.0625)[0] * 0.0625 - 1.0 + rng.uniform(0.002, 0.060, (600, 3))).astype(np.float32)
+    vel = rng.uniform(-5, 5, (600, 3)).astype(np.float32)
+    with capi.Context(600, box=(2.0,) * 3, grid=(32,) * 3) as c:
+        c.upload(pos, vel)
+        c.hash(); c.sort(); c.build_cells()
+        k, s, cnt = c.cells()
+        assert len(k) == 1 and cnt[0] == 600
+    _compare(pos, vel, (2.0,) * 3, (32,) * 3, 2e-7, 2, rel=4e-5)
+
+
+def test_shuffled_creation_indices():
+    pos, vel = ic.dam_break_lattice((12, 12, 12), (2.0, 2.0, 2.0), jitter=True)
+    rng = np.random.default_rng(11)
+    index = rng.permutation(pos.shape[0]).astype(np.uint32)
+    _compare(pos, vel, (2.0,) * 3, (32,) * 3, 5e-7, 5, index=index)
+
+
+def test_set_params_moves_the_walls():
+    """setSimParams analogue: shrink the box in y at run time; the clamp follows the new wall."""
+    pos, vel = ic.dam_break_lattice((10, 10, 10), (2.0, 2.0, 2.0), jitter=True)
+    with capi.Context(1000, box=(2.0,) * 3, grid=(32,) * 3) as c:
+        c.upload(pos, vel)
+        c.step(5e-7, 2)
+        p = c.params
+        p.box_min[1] = -0.9                               # floor up by 0.1: above the lowest lattice layers
+        c.set_params(p)
+        c.step(5e-7, 1)
+        st = c.download(count=1000)
+        assert st["pos"][:, 1].min() >= -0.9 + 0.9e-5
+        q = capi.Params()
+        capi._check(c.L.sph_get_params(c.h, q))
+        assert abs(q.box_min[1] + 0.9) < 1e-7
+        bad = capi.default_params((2.0,) * 3, (64,) * 3)
+        with pytest.raises(capi.SphError):
+            c.set_params(bad)                             # the grid cannot change
+
+
+def test_faster_than_one_cell_per_step():
+    pos, vel = ic.random_box(2000, (2.0, 2.0, 2.0), speed=0.0, fill=0.4)
+    vel[:, 0] = 3.0e5                                     # 0.15 per step at dt 5e-7: more than two cells
+    _compare(pos, vel, (2.0,) * 3, (32,) * 3, 5e-7, 3, rel=4e-5)
