@@ -96,3 +96,34 @@ def test_faster_than_one_cell_per_step():
     pos, vel = ic.random_box(2000, (2.0, 2.0, 2.0), speed=0.0, fill=0.4)
     vel[:, 0] = 3.0e5                                     # 0.15 per step at dt 5e-7: more than two cells
     _compare(pos, vel, (2.0,) * 3, (32,) * 3, 5e-7, 3, rel=4e-5)
+
+
+def _np_cell(p, bmin, bdim, g):
+    q = ((p.astype(np.float32) - np.float32(bmin)) / np.float32(bdim)) * np.float32(g)
+    return np.clip(np.floor(q).astype(np.int64), 0, int(g) - 1)
+
+
+@pytest.mark.parametrize("grid,bits", [((1024, 1024, 512), 10), ((512, 512, 512), 9), ((128, 64, 32), 8)])
+def test_every_radix_width(grid, bits):
+    """The sort picks 8-, 9- or 10-bit digits from the number of cells (3 passes of 10 bits on the
+    huge table a last z-slab owns); hash, stable order and cell table are checked against numpy."""
+    box = tuple(g / 16.0 for g in grid)
+    n = 200_000
+    pos, vel = ic.random_box(n, box, speed=0.0, fill=1.0)
+    pos *= np.float32(0.999)
+    with capi.Context(n, box=box, grid=grid) as c:
+        c.upload(pos, vel)
+        c.hash()
+        cx, cy, cz = (_np_cell(pos[:, a], -box[a] / 2, box[a], grid[a]) for a in range(3))
+        want = ((cz * grid[1] + cy) * grid[0] + cx).astype(np.uint32)
+        assert np.array_equal(c.keys(), want)
+        c.sort()
+        order = np.argsort(want, kind="stable").astype(np.uint32)
+        assert np.array_equal(c.order(), order) and np.array_equal(c.keys(), want[order])
+        c.build_cells()
+        k, s, cnt = c.cells()
+        uk, ucnt = np.unique(want, return_counts=True)
+        assert np.array_equal(k, uk) and np.array_equal(cnt, ucnt.astype(np.uint32))
+        c.density()                                   # isolated particles: self term only
+        rho = c.download(count=n, want=("density",))["density"]
+        assert np.all(rho >= 0.999 * 315.0 / (np.pi * 1e-3))

@@ -69,3 +69,38 @@ def test_c2_in_four_slabs_matches_whole_domain():
     assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * 8.0
     assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
     assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def test_weak_scaling_geometry_in_four_slabs():
+    """The bench's N-GPU layout in small: a lattice stretched along z in a box stretched along z
+    (ic.weak_scaling_config), jitter scaled by the per-GPU box, count-balanced cuts with the last slab
+    owning the empty three quarters of the box."""
+    cfg = ic.weak_scaling_config(4, per_gpu=(32, 32, 32))
+    hub_world, steps = 4, 3
+    hub = slab.LocalComm.Hub(hub_world)
+    results, errors = [None] * hub_world, []
+
+    def rank_main(r):
+        try:
+            sim = slab.SlabSimulation(slab.LocalComm(hub, r), lambda cap, gcap, p, z0, z1: slab.HipEngine(cap, gcap, p, z0, z1, 0),
+                                      cfg["box"], cfg["grid"], lattice=cfg["lattice"], jitter=True,
+                                      jitter_dims=cfg["jitter_dims"])
+            sim.run(DT, steps)
+            results[r] = (sim.gather_state(), sim.cuts, sim.engine.n)
+            sim.engine.close()
+        except BaseException as e:     # noqa: BLE001
+            errors.append(e)
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(hub_world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=900)
+    assert not errors, errors
+    st, cuts, _ = results[0]
+    assert cuts == [0, 16, 32, 48, cfg["grid"][2]]
+    assert [r[2] for r in results] == [32 * 32 * 32] * 4
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True, jitter_dims=cfg["jitter_dims"])
+    ref = _whole_domain(pos, vel, cfg["box"], cfg["grid"], steps)
+    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(cfg["box"])
+    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
