@@ -63,7 +63,6 @@ struct sph_ctx {
     uint32_t n_glo = 0, n_ghi = 0;   // ghosts installed below / above
     uint32_t halo_n[2] = {0, 0};     // boundary-layer counts of the last halo pack
     bool halo_n_valid = false;
-    uint32_t index_hi = 0;   // max creation index + 1 seen at upload (size of pos_out)
 
     // sorted SoA state, `tot` entries each; the owned range starts at own_off
     float4* posi = nullptr;   // x, y, z, creation index (bits)
@@ -96,14 +95,12 @@ struct sph_ctx {
     uint32_t* h_scratch = nullptr;  // pinned host mirror
 
     // state machine for the phase API
-    enum Stage { ST_LOADED = 0, ST_HASHED, ST_SORTED, ST_CELLS, ST_DENS, ST_FORCE, ST_COLL } stage = ST_LOADED;
+    enum Stage { ST_LOADED = 0, ST_HASHED, ST_SORTED, ST_CELLS } stage = ST_LOADED;
     bool have_force = false, have_coll = false, have_dens = false;
 
     // device timing
     bool timing = false;
-    static constexpr int EV_STEPS = 128;
-    std::vector<hipEvent_t> events;   // EV_STEPS * (SPH_PH_COUNT + 1)
-    uint32_t ev_steps_pending = 0;
+    std::vector<hipEvent_t> events;   // triples: start event, stop event, phase id (see PhaseTimer)
     double ph_ms[SPH_PH_COUNT] = {0};
     uint32_t timed_steps = 0;
 };
@@ -135,7 +132,6 @@ int launch_cells_build(sph_ctx* c);
 int launch_density(sph_ctx* c);
 int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt);
 int launch_integrate(sph_ctx* c, float dt);
-int launch_halo(sph_ctx* c);
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
