@@ -28,6 +28,31 @@ def test_library_builds_and_exports_the_header():
     assert lib.sph_abi_version() == 1
 
 
+def test_reference_seam_symbols_are_exported():
+    """include/sph_compat_seam.h: the reference's own 19 extern "C" names (SPH/particleSystem.cuh:3-30)
+    plus the two helpers, and the two IC twins of include/particleSystem.h."""
+    import ctypes as C
+    lib = C.CDLL(build.build())
+    seam = ["iceildiv", "cudaInit", "allocateArray", "freeArray", "registerGLBufferObject", "unregisterGLBufferObject",
+            "mapGLBufferObject", "unmapGLBufferObject", "threadSync", "copyArrayFromDevice", "copyArrayToDevice",
+            "cudaComputeDensities", "cudaComputeForces", "cudaParticleCollisions", "cudaMapZIndex", "cudaSortParticles",
+            "cudaConstructBGrid", "cudaConstructGridArray", "cudaIntegrate"]
+    src = open(os.path.join(ROOT, "include", "sph_compat_seam.h")).read()
+    ref = open("/root/reference/SPH/particleSystem.cuh").read() if os.path.exists("/root/reference/SPH/particleSystem.cuh") else None
+    for n in seam + ["sph_compat_context", "sph_compat_vbo_dev", "sph_ic_dam_break", "sph_ic_random_box"]:
+        assert hasattr(lib, n), f"{n} not exported"
+        if n in seam:
+            assert re.search(r"\b%s\s*\(" % n, src), f"{n} not declared in sph_compat_seam.h"
+            if ref is not None:
+                assert re.search(r"\b%s\s*\(" % n, ref), f"{n} is not a name of the reference seam"
+    lib.iceildiv.restype = C.c_uint
+    assert lib.iceildiv(10, 32) == 1 and lib.iceildiv(64, 32) == 2 and lib.iceildiv(65, 32) == 3   # .cu:423-425
+    if ref is not None:     # the reference declares exactly these 19 functions
+        body = re.sub(r"//.*", "", ref)
+        names = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", body)) - {"C"}
+        assert names == set(seam), names ^ set(seam)
+
+
 def test_default_params_are_the_reference_constants():
     p = capi.default_params((4.0, 4.0, 4.0), (64, 64, 64))
     assert tuple(p.box_min) == (-2.0, -2.0, -2.0) and tuple(p.box_max) == (2.0, 2.0, 2.0)
