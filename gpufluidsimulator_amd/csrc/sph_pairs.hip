@@ -229,17 +229,26 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
             const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
             uint32_t idx = slice + (len ? l0 - a : 0u);
-            for (uint32_t t = 0; __ballot(t < len) != 0ull; t += UNROLL) {   // until every lane is through its range
+            // every lane has at least tmin candidates: that part of the walk needs no per-lane range test
+            const uint32_t tmin = wave_min_u32(len) & ~(uint32_t)(UNROLL - 1);
+            auto pair = [&](int u, bool valid) {
+                const float2 xy = s_xy[idx + u];
+                const float z = s_z[idx + u];
+                const float dx = pi.x - xy.x, dy = pi.y - xy.y, dz = pi.z - z;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                float d = fmaxf(ph.h2 - r2, 0.f);      // r2 < h2
+                d = valid ? d : 0.f;
+                acc = fmaf(d * d, d, acc);
+            };
+            uint32_t t = 0;
+            for (; t < tmin; t += UNROLL) {
 #pragma unroll
-                for (int u = 0; u < UNROLL; u++) {
-                    const float2 xy = s_xy[idx + u];
-                    const float z = s_z[idx + u];
-                    const float dx = pi.x - xy.x, dy = pi.y - xy.y, dz = pi.z - z;
-                    const float r2 = dx * dx + dy * dy + dz * dz;
-                    float d = fmaxf(ph.h2 - r2, 0.f);      // r2 < h2
-                    d = (t + u < len) ? d : 0.f;
-                    acc = fmaf(d * d, d, acc);
-                }
+                for (int u = 0; u < UNROLL; u++) pair(u, true);
+                idx += UNROLL;
+            }
+            for (; __ballot(t < len) != 0ull; t += UNROLL) {   // until every lane is through its range
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) pair(u, t + u < len);
                 idx += UNROLL;
             }
         });
@@ -357,36 +366,48 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             // Candidates are walked in chunks of 32.  The pressure/viscosity arithmetic runs for every
             // candidate; the collision test only records "d <= 2R" in a per-lane bit mask (2 VALU per
             // candidate) and the few close pairs (~4 of ~216 per particle) are worked off after the chunk.
+            // every lane has at least tmin candidates: that part of the walk needs no per-lane range test
+            const uint32_t tmin = wave_min_u32(len) & ~(uint32_t)(SPH_FORCE_UNROLL - 1);
+            uint32_t near = 0u;
+            auto pair = [&](int u, bool valid) {
+                const float2* e = &s_e[(idx + u) * 5];
+                const float2 qa = e[0], qb = e[1];
+                const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
+                const float r2 = dx * dx + dy * dy + dz * dz;
+                if (FORCE) {
+                    const float2 qc = e[2], qd = e[3];
+                    const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
+                    const bool in = valid && r2 < ph.h2;
+                    // r = 0 (the particle itself, coincident particles): 1/r is capped at 1e15, r*1/r = 0,
+                    // and the huge but finite pressure weight multiplies r_ij = 0 -- no pressure term, as
+                    // with Eigen's normalized() of a zero vector (Dot.h:124-134); the viscous term is exact.
+                    const float rinv = inv_sqrt(r2 + 1e-30f);      // r2 >= 0; an add, not fmaxf (no canonicalise)
+                    const float hr = ph.h - r2 * rinv;
+                    float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
+                    float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
+                    s = in ? s : 0.f;
+                    w = in ? w : 0.f;
+                    fpx += s * dx; fpy += s * dy; fpz += s * dz;
+                    fvx += w * ux; fvy += w * uy; fvz += w * uz;
+                }
+                if (COLL) near = (near << 1) | ((valid && r2 <= ph.coll_dist2) ? 1u : 0u);
+            };
             for (uint32_t t0 = 0; t0 < T; t0 += 32u) {
                 const uint32_t tend = min(T, t0 + 32u);
+                const uint32_t tsafe = min(tend, max(tmin, t0));      // [t0, tsafe): no range test needed
                 const uint32_t idx0 = idx;
-                uint32_t near = 0u, done = 0u;
-                for (uint32_t t = t0; t < tend; t += SPH_FORCE_UNROLL) {
+                uint32_t done = 0u;
+                near = 0u;
+                uint32_t t = t0;
+                for (; t < tsafe; t += SPH_FORCE_UNROLL) {
 #pragma unroll
-                    for (int u = 0; u < SPH_FORCE_UNROLL; u++) {
-                        const float2* e = &s_e[(idx + u) * 5];
-                        const float2 qa = e[0], qb = e[1];
-                        const bool valid = t + u < len;
-                        const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
-                        const float r2 = dx * dx + dy * dy + dz * dz;
-                        if (FORCE) {
-                            const float2 qc = e[2], qd = e[3];
-                            const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
-                            const bool in = valid && r2 < ph.h2;
-                            // r = 0 (the particle itself, coincident particles): 1/r is capped at 1e15, r*1/r = 0,
-                            // and the huge but finite pressure weight multiplies r_ij = 0 -- no pressure term, as
-                            // with Eigen's normalized() of a zero vector (Dot.h:124-134); the viscous term is exact.
-                            const float rinv = inv_sqrt(r2 + 1e-30f);      // r2 >= 0; an add, not fmaxf (no canonicalise)
-                            const float hr = ph.h - r2 * rinv;
-                            float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
-                            float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
-                            s = in ? s : 0.f;
-                            w = in ? w : 0.f;
-                            fpx += s * dx; fpy += s * dy; fpz += s * dz;
-                            fvx += w * ux; fvy += w * uy; fvz += w * uz;
-                        }
-                        if (COLL) near = (near << 1) | ((valid && r2 <= ph.coll_dist2) ? 1u : 0u);
-                    }
+                    for (int u = 0; u < SPH_FORCE_UNROLL; u++) pair(u, true);
+                    idx += SPH_FORCE_UNROLL;
+                    done += SPH_FORCE_UNROLL;
+                }
+                for (; t < tend; t += SPH_FORCE_UNROLL) {
+#pragma unroll
+                    for (int u = 0; u < SPH_FORCE_UNROLL; u++) pair(u, t + u < len);
                     idx += SPH_FORCE_UNROLL;
                     done += SPH_FORCE_UNROLL;
                 }
