@@ -79,15 +79,15 @@ def gen_random():
 
 
 def gen_c2():
-    """BASELINE config 2: 64^3 lattice, box 8, grid 128^3.  3 steps; stores every
-    61st particle plus float64 checksums of the full arrays."""
+    """BASELINE config 2: 64^3 lattice, box 8, grid 128^3.  States after 1, 2, 3 and 30 steps;
+    stores every 61st particle plus float64 checksums of the full arrays."""
     cfg = ic.CONFIGS["C2"]
     pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
-    recs, stats = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, 3, dump_steps=(1, 2, 3))
+    recs, stats = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, 30, dump_steps=(1, 2, 3, 30))
     print("c2 reference timing:", stats)
     sample = np.arange(0, pos.shape[0], 61, dtype=np.int64)
     arrs = {}
-    for s in (1, 2, 3):
+    for s in (1, 2, 3, 30):
         st = recs[("state", s)]
         arrs[f"state_{s}_sample"] = st[sample]
         arrs[f"state_{s}_sum"] = st.astype(np.float64).sum(axis=0)

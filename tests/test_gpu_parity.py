@@ -161,20 +161,23 @@ def test_fused_step_equals_phased_step():
 
 
 def test_c2_sample_vs_reference_golden():
-    """BASELINE config 2: 262144 particles (64^3 lattice), 128^3 grid, 3 steps; every 61st
-    particle plus checksums of the full arrays from the reference run."""
+    """BASELINE config 2: 262144 particles (64^3 lattice), 128^3 grid, states after 1, 2, 3 and 30
+    steps; every 61st particle plus checksums of the full arrays from the reference run."""
     g = load_golden("c2_sample")
     lattice = tuple(int(v) for v in g["lattice"])
     pos, vel = ic.dam_break_lattice(lattice, g["box"], jitter=True)
     sample = g["sample"]
     with capi.Context(pos.shape[0], box=g["box"], grid=g["grid"]) as c:
         c.upload(pos, vel)
-        for s in (1, 2, 3):
-            c.step(float(g["dt"]), 1)
+        done = 0
+        for s in (1, 2, 3, 30):
+            c.step(float(g["dt"]), s - done)
+            done = s
             st = c.download()
             ref = g[f"state_{s}_sample"]
             assert np.abs(st["pos"][sample] - ref[:, 0:3]).max() <= POS_TOL_PER_BOX * 8.0
-            _assert_close(f"step {s} velocity", st["vel"][sample], ref[:, 3:6], REL_TOL)
+            ev = np.abs(st["vel"][sample] - ref[:, 3:6]).max(axis=1) / np.abs(ref[:, 3:6]).max()
+            assert ev.max() <= OUTLIER_REL_TOL and (ev > REL_TOL).mean() <= OUTLIER_FRACTION, f"step {s} velocity"
             assert np.abs(st["density"][sample] / ref[:, 6] - 1).max() <= REL_TOL
             full = np.concatenate([st["pos"], st["vel"], st["density"][:, None], st["pressure"][:, None]], axis=1)
             got_abs = np.abs(full.astype(np.float64)).sum(axis=0)
