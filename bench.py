@@ -124,6 +124,13 @@ def main():
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
     args = ap.parse_args()
     rank, world, local = _dist_env()
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        # called without a launcher: start one rank per GPU as child processes (nothing has touched the GPU yet)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     if args.gpus > 1 or world > 1 or args.force_slab:
         from gpufluidsimulator_amd import slab
         return slab.bench_main(args)
