@@ -91,12 +91,20 @@ SIGNATURES = {
 }
 
 _lib = None
+_torch_first = None     # was torch already imported when libsph_hip.so (and with it /opt/rocm's HIP runtime) was loaded?
 
 
 def load():
-    """dlopen libsph_hip.so (building it first if it is missing) and type its entry points."""
-    global _lib
+    """dlopen libsph_hip.so (building it first if it is missing) and type its entry points.
+
+    Library order matters in a process that also uses PyTorch: the torch wheel bundles its own HIP/HSA
+    runtime and loads it by path.  If libsph_hip.so (linked against /opt/rocm) comes first, torch later
+    brings up a second runtime, which finds no device.  Import torch BEFORE the first call of this
+    function; then libsph_hip.so binds to the runtime torch has already loaded (same SONAMEs)."""
+    global _lib, _torch_first
     if _lib is None:
+        import sys
+        _torch_first = "torch" in sys.modules
         if not os.path.exists(LIB_PATH):
             from . import build as _b
             _b.build()

@@ -151,8 +151,8 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (!rc) rc = dev_alloc(&c->v0, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->k1, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->v1, (size_t)capacity);
-    if (!rc) rc = dev_alloc(&c->hist, (size_t)1024 * c->sort_blocks_cap);
-    if (!rc) rc = dev_alloc(&c->digit_tot, (size_t)1024);
+    if (!rc) rc = dev_alloc(&c->hist, (size_t)512 * c->sort_blocks_cap);
+    if (!rc) rc = dev_alloc(&c->digit_tot, (size_t)512);
     if (!rc) rc = dev_alloc(&c->d_scratch, (size_t)64);
     if (!rc && hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(uint32_t)) != hipSuccess) {
         set_error("hipHostMalloc failed");

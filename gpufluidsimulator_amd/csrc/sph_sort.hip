@@ -13,7 +13,7 @@ constexpr int SORT_THREADS = 256;            // 4 waves
 constexpr int SORT_KPT = 16;                 // keys per thread
 constexpr int SORT_WAVE_TILE = WAVE * SORT_KPT;          // 1024 consecutive keys per wave
 constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;       // 4096 keys per block
-constexpr int MAX_RADIX = 1024;
+constexpr int MAX_RADIX = 512;
 
 // ---- hash: key per owned particle ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hash(const float4* __restrict__ posi, uint32_t n, GridDesc g,
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_hash(const float4* __restrict__ posi, u
 }
 
 // ---- pass 1 of 3: per-block digit histogram ----------------------------------------------------
-// BITS = 8, 9 or 10 bits per pass: 27 significant key bits (512^3 cells) sort in 3 passes of 9.
+// BITS = 8 or 9 bits per pass: 27 significant key bits (512^3 cells) sort in 3 passes of 9.
 template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys, uint32_t n,
                                                             uint32_t shift, uint32_t nblocks,
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* _
                                                                const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ digit_tot) {
     constexpr int RADIX = 1 << BITS;
-    constexpr int DPT = RADIX / SORT_THREADS;       // digits per thread: 1, 2 or 4 (consecutive digits)
+    constexpr int DPT = RADIX / SORT_THREADS;       // digits per thread: 1 or 2 (consecutive digits)
     __shared__ uint32_t wh[4][RADIX];     // per-wave digit counters -> running offsets
     __shared__ uint32_t part[SORT_THREADS];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -216,15 +216,15 @@ int launch_sort(sph_ctx* c) {
                 c->sort_blocks_cap);
     uint32_t* kin = c->k0; uint32_t* vin = c->v0;
     uint32_t* kout = c->k1; uint32_t* vout = c->v1;
-    // fewest passes of at most 10 bits, then the narrowest digit that still covers the key
-    const uint32_t passes = (c->key_bits + 9) / 10;
-    uint32_t bits = (c->key_bits + passes - 1) / passes;
-    if (bits < 8) bits = 8;
+    // 9-bit digits when they save a pass over 8-bit ones (27 bits: 3 x 9), else 8-bit digits.  Measured
+    // per pass at 16.7 M keys: 124 us (8 bits), 150 us (9 bits), 220 us (10 bits: never worth it).
+    const uint32_t p8 = (c->key_bits + 7) / 8, p9 = (c->key_bits + 8) / 9;
+    const uint32_t bits = p9 < p8 ? 9u : 8u;
+    const uint32_t passes = bits == 9u ? p9 : p8;
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t shift = p * bits;
         if (bits == 8) sort_pass<8>(c, n, nblocks, shift, p == 0, kin, vin, kout, vout);
-        else if (bits == 9) sort_pass<9>(c, n, nblocks, shift, p == 0, kin, vin, kout, vout);
-        else sort_pass<10>(c, n, nblocks, shift, p == 0, kin, vin, kout, vout);
+        else sort_pass<9>(c, n, nblocks, shift, p == 0, kin, vin, kout, vout);
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;

@@ -167,6 +167,10 @@ class HipEngine:
     CUDA tensors (plumbing: device memory + RCCL); all arithmetic is in the HIP library."""
 
     def __init__(self, capacity, ghost_capacity, params, z_lo, z_hi, device_index=0):
+        import sys
+        if capi._lib is not None and not capi._torch_first and "torch" not in sys.modules:
+            raise capi.SphError("libsph_hip.so was loaded before torch was imported: import torch first "
+                                "(see gpufluidsimulator_amd.capi.load)")
         import torch
         n_dev, is950 = capi.device_count()
         if n_dev <= 0 or not is950:
@@ -224,6 +228,10 @@ class SlabSimulation:
         `particles` = (pos, vel) of the WHOLE system (small tests)."""
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world
+        try:                       # torch before libsph_hip.so (capi.load): one HIP runtime per process
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.box = tuple(float(b) for b in box)
         self.grid = tuple(int(g) for g in grid)
         self.params = capi.default_params(self.box, self.grid)
@@ -395,8 +403,23 @@ def bench_main(args):
     wall = comm.allreduce_max(time.perf_counter() - t0)
     n_own = sim.engine.n
     counts = comm.allreduce_sum(np.array([n_own], dtype=np.int64))
+    # per-phase device times of this rank's kernels (HIP events on the library's stream), outside the timed region
+    ctx = sim.engine.ctx
+    ctx.timing(True); ctx.timing_reset()
+    probe = max(2, min(args.steps, 5))
+    sim.run(dt, probe)
+    sim.engine.sync(); comm.barrier()
+    ph, _ = ctx.timing_get()
+    ctx.timing(False)
+    phases_ms = {k: v / probe for k, v in ph.items()}
     if rank == 0:
         total = sim.total
+        fbytes, t_force = 84 * n_own, max(phases_ms["force"], 1e-9) * 1e-3
+        roofline = {"bound": "hbm", "kernel": "k_force<force+collision+integrate> (rank 0)",
+                    "achieved": fbytes / t_force / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": fbytes / t_force / 1e9 / 8000.0, "traffic": None,
+                    "algorithmic_bytes_per_particle": 84, "avg_launch_ms": phases_ms["force"],
+                    "valu": {"achieved_tflops": 216 * 34 * n_own / t_force / 1e12, "peak_tflops": 157.3}}
         out = {
             "metric": "particle-steps/sec", "value": total * args.steps / wall, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -406,6 +429,7 @@ def bench_main(args):
                                    f"over RCCL send/recv",
                        "particles": total, "grid": list(cfg["grid"]), "cuts": sim.cuts,
                        "parallelism": f"{world} z-slabs, one per GPU"},
+            "roofline": roofline, "phases_ms_rank0": phases_ms,
             "slab_stats": sim.stats, "owned_sum": int(counts[0]),
         }
         print(json.dumps(out), flush=True)

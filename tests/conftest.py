@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # GPU runs use torch (streams, slab buffers) next to libsph_hip.so: torch's bundled HIP runtime must be
+    # the one that gets loaded, i.e. torch first (gpufluidsimulator_amd.capi.load explains why)
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        import torch  # noqa: F401
 
 
 def load_golden(name):

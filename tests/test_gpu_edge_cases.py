@@ -4,6 +4,7 @@ decode), boxes with three different edges, fewer particles than one wave, everyt
 sph_set_params, and particles faster than one cell per step."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before libsph_hip.so is loaded: one HIP runtime per process (capi.load)
 
 from gpufluidsimulator_amd import capi, ic
 from oracle import oracle
@@ -103,10 +104,12 @@ def _np_cell(p, bmin, bdim, g):
     return np.clip(np.floor(q).astype(np.int64), 0, int(g) - 1)
 
 
-@pytest.mark.parametrize("grid,bits", [((1024, 1024, 512), 10), ((512, 512, 512), 9), ((128, 64, 32), 8)])
-def test_every_radix_width(grid, bits):
-    """The sort picks 8-, 9- or 10-bit digits from the number of cells (3 passes of 10 bits on the
-    huge table a last z-slab owns); hash, stable order and cell table are checked against numpy."""
+@pytest.mark.parametrize("grid,passes", [((1024, 1024, 512), "4x8"), ((512, 512, 512), "3x9"), ((128, 64, 32), "2x9"),
+                                         ((64, 64, 16), "2x8")])
+def test_every_radix_plan(grid, passes):
+    """The sort picks 9-bit digits when they save a pass over 8-bit ones (29 key bits: 4 x 8, as on the
+    huge table a last z-slab owns; 27: 3 x 9; 18: 2 x 9; 16: 2 x 8); hash, stable order and cell table
+    are checked against numpy."""
     box = tuple(g / 16.0 for g in grid)
     n = 200_000
     pos, vel = ic.random_box(n, box, speed=0.0, fill=1.0)
