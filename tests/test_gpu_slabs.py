@@ -104,3 +104,43 @@ def test_weak_scaling_geometry_in_four_slabs():
     assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(cfg["box"])
     assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
     assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def test_slab_entry_points_directly():
+    """sph_slab_counts / sph_migrants_* / sph_halo_* / sph_layer_histogram on one slab context, against
+    numpy on the same particles (no communication involved)."""
+    import torch
+    pos, vel, box, grid = make_case("shear")
+    gz = grid[2]
+    layers = slab.cell_layer_of(pos[:, 2], box[2], gz)
+    z_lo, z_hi = 3, 9                                   # owns layers 3..8; the case fills layers 0..11
+    mine = np.nonzero((layers >= z_lo - 1) & (layers <= z_hi))[0]       # include both would-be ghost layers
+    p = capi.default_params(box, grid)
+    with capi.Context(len(mine) + 100, params=p, slab=(z_lo, z_hi), ghost_capacity=4096) as c:
+        c.upload(pos[mine], vel[mine], mine.astype(np.uint32))
+        c.hash(); c.sort()
+        lay = layers[mine]
+        want = (int((lay == z_lo - 1).sum()), int((lay == z_lo).sum()), int((lay == z_hi - 1).sum()), int((lay == z_hi).sum()))
+        assert c.slab_counts() == want
+        assert c.migrants_count() == (want[0], want[3])
+        hist = c.layer_histogram()
+        assert np.array_equal(hist, np.bincount(lay, minlength=gz).astype(np.uint32))
+        dev = torch.device("cuda", 0)
+        lo = torch.zeros((4096, 8), dtype=torch.float32, device=dev); hi = torch.zeros_like(lo)
+        c.migrants_pack(lo.data_ptr(), hi.data_ptr(), 4096)
+        assert c.n == len(mine) - want[0] - want[3]
+        rec_lo, rec_hi = lo[:want[0]].cpu().numpy(), hi[:want[3]].cpu().numpy()
+        idx_lo = np.ascontiguousarray(rec_lo[:, 3]).view(np.uint32)
+        assert set(idx_lo.tolist()) == set(mine[lay == z_lo - 1].tolist())
+        assert np.array_equal(rec_lo[:, 0:3], pos[idx_lo]) and np.array_equal(rec_hi[:, 4:7], vel[np.ascontiguousarray(rec_hi[:, 3]).view(np.uint32)])
+        assert c.halo_count() == (want[1], want[2])
+        # ghosts: give the departed particles back as ghost layers, the table must then cover everything
+        c.halo_unpack(lo.data_ptr(), want[0], hi.data_ptr(), want[3])
+        c.build_cells()
+        k, s, cnt = c.cells()
+        assert int(cnt.sum()) == len(mine)
+        c.density()
+        # appended migrants are owned again after hash + sort
+        c.migrants_append(lo.data_ptr(), want[0])
+        c.hash(); c.sort()
+        assert c.n == len(mine) - want[3] and c.slab_counts()[0] == want[0]
