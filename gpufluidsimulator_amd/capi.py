@@ -50,6 +50,7 @@ SIGNATURES = {
     "sph_capacity": (_U32, [_P]),
     "sph_upload": (C.c_int, [_P, _U32, _P, _P, _P]),
     "sph_download": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
+    "sph_download_owned": (C.c_int, [_P, _P, _P, _P]),
     "sph_download_forces": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
     "sph_snapshot_save": (C.c_int, [_P, C.c_char_p]),
     "sph_snapshot_load": (C.c_int, [_P, C.c_char_p]),
@@ -207,6 +208,13 @@ class Context:
         ptr = lambda k: out[k].ctypes.data if k in out else None
         _check(self.L.sph_download(self.h, int(index_base), ptr("pos"), ptr("vel"), ptr("density"), ptr("pressure")))
         return out
+
+    def download_owned(self):
+        """(pos[n,3], vel[n,3], index[n]) of the owned particles in slot order."""
+        n = self.n
+        pos, vel, idx = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty(n, np.uint32)
+        _check(self.L.sph_download_owned(self.h, pos.ctypes.data, vel.ctypes.data, idx.ctypes.data))
+        return pos, vel, idx
 
     def download_forces(self, index_base=0, count=None, force=True, collision=True):
         count = self.index_count if count is None else count

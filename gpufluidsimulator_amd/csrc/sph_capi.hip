@@ -415,6 +415,19 @@ int sph_download(sph_ctx* c, uint32_t base, float* pos, float* vel, float* densi
     return SPH_OK;
 }
 
+int sph_download_owned(sph_ctx* c, float* pos, float* vel, uint32_t* index) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    std::vector<float4> hp, hv;
+    int rc = fetch_sorted(c, &hp, vel ? &hv : nullptr, nullptr);
+    if (rc) return rc;
+    for (uint32_t s = 0; s < c->n; s++) {
+        if (pos) { pos[3 * s] = hp[s].x; pos[3 * s + 1] = hp[s].y; pos[3 * s + 2] = hp[s].z; }
+        if (vel) { vel[3 * s] = hv[s].x; vel[3 * s + 1] = hv[s].y; vel[3 * s + 2] = hv[s].z; }
+        if (index) index[s] = idx_of(hp[s]);
+    }
+    return SPH_OK;
+}
+
 int sph_download_forces(sph_ctx* c, uint32_t base, float* fp, float* fv, float* dv, int32_t* count) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     SPH_REQUIRE((!fp && !fv) || c->have_force, SPH_E_STATE, "sph_force has not run for this particle order");

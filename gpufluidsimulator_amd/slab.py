@@ -214,6 +214,11 @@ class HipEngine:
     def download(self, total):
         return self.ctx.download(index_base=0, count=total)
 
+    def download_owned(self): return self.ctx.download_owned()
+
+    def to_device(self, arr):
+        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+
     def close(self): self.ctx.close()
 
 
@@ -285,18 +290,21 @@ class SlabSimulation:
         per_layer = max(int(hist.max()), 1)
         self.ghost_capacity = int(ghost_factor * per_layer) + 1024
         self.capacity = int(capacity_factor * max(n_own, self.total // self.world)) + 4096
+        self._factory = engine_factory
         self.engine = engine_factory(self.capacity, self.ghost_capacity, self.params, z_lo, z_hi)
         self.engine.upload(pos, vel, index)
-        e = self.engine
-        g = self.ghost_capacity
+        self._alloc_buffers()
+        self.lo_peer = self.rank - 1 if self.rank > 0 else None
+        self.hi_peer = self.rank + 1 if self.rank + 1 < self.world else None
+        self.stats = {"migrants": 0, "resorts": 0, "ghosts": 0}
+
+    def _alloc_buffers(self):
+        e, g = self.engine, self.ghost_capacity
         self.send_lo, self.send_hi = e.buffer(g, REC), e.buffer(g, REC)
         self.recv_lo, self.recv_hi = e.buffer(g, REC), e.buffer(g, REC)
         self.dsend_lo, self.dsend_hi = e.buffer(g, 2), e.buffer(g, 2)
         self.drecv_lo, self.drecv_hi = e.buffer(g, 2), e.buffer(g, 2)
         self.cnt_recv_lo, self.cnt_recv_hi = e.small([0, 0]), e.small([0, 0])
-        self.lo_peer = self.rank - 1 if self.rank > 0 else None
-        self.hi_peer = self.rank + 1 if self.rank + 1 < self.world else None
-        self.stats = {"migrants": 0, "resorts": 0, "ghosts": 0}
 
     # -- one time step ---------------------------------------------------------------------------------
     def step(self, dt):
@@ -359,9 +367,59 @@ class SlabSimulation:
         e.halo_unpack_density(self.drecv_lo, self.drecv_hi)
         e.force_collide_integrate(dt)
 
-    def run(self, dt, steps):
-        for _ in range(steps):
+    def run(self, dt, steps, rebalance_every=0):
+        for k in range(steps):
             self.step(dt)
+            if rebalance_every and (k + 1) % rebalance_every == 0:
+                self.rebalance()
+
+    # -- re-cut the slabs ("cuts chosen so particle counts are equal ... re-cut every K steps") --
+    def rebalance(self, tolerance=0.02):
+        """New count-balanced cuts from the current particle distribution; particles whose layer changed
+        owner travel point to point.  Collective: every rank must call it.  Returns True if the cuts moved."""
+        e, c = self.engine, self.comm
+        gz = self.grid[2]
+        pos, vel, idx = e.download_owned()
+        layers = cell_layer_of(pos[:, 2], self.box[2], gz) if pos.shape[0] else np.zeros(0, np.int64)
+        hist = c.allreduce_sum(np.bincount(layers, minlength=gz).astype(np.int64)).astype(np.int64)
+        counts = [int(hist[a:b].sum()) for a, b in zip(self.cuts, self.cuts[1:])]
+        if max(counts) <= (1.0 + tolerance) * self.total / self.world:
+            return False                                   # still balanced: keep the cuts
+        cuts = choose_cuts(hist, self.world)
+        if cuts == self.cuts:
+            return False
+        dest = np.searchsorted(np.asarray(cuts[1:-1]), layers, side="right")    # rank that owns each layer now
+        rec = np.zeros((pos.shape[0], REC), np.float32)
+        rec[:, 0:3] = pos; rec[:, 3] = idx.view(np.float32); rec[:, 4:7] = vel
+        # who sends how many to whom: one world x world matrix, every rank fills its row
+        m = np.zeros((self.world, self.world), np.int64)
+        m[self.rank] = np.bincount(dest, minlength=self.world)
+        m = c.allreduce_sum(m).astype(np.int64)
+        sends, recvs, inbox = [], [], {}
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            if m[self.rank, peer]:
+                sends.append((peer, e.to_device(rec[dest == peer])))
+            if m[peer, self.rank]:
+                inbox[peer] = e.buffer(int(m[peer, self.rank]), REC)
+                recvs.append((peer, inbox[peer]))
+        c.exchange(sends, recvs)
+        parts = [rec[dest == self.rank]] + [inbox[p].cpu().numpy() for p in sorted(inbox)]
+        rec = np.concatenate(parts) if parts else np.zeros((0, REC), np.float32)
+        order = np.argsort(np.ascontiguousarray(rec[:, 3]).view(np.uint32), kind="stable")   # deterministic upload order
+        rec = rec[order]
+        # a fresh engine for the new layer range (cell table, key width and capacities depend on it)
+        e.close()
+        self.cuts = cuts
+        self.z_lo, self.z_hi = cuts[self.rank], cuts[self.rank + 1]
+        n_own = rec.shape[0]
+        self.capacity = max(self.capacity, int(1.5 * n_own) + 4096)
+        self.engine = self._factory(self.capacity, self.ghost_capacity, self.params, self.z_lo, self.z_hi)
+        self.engine.upload(rec[:, 0:3].copy(), rec[:, 4:7].copy(), np.ascontiguousarray(rec[:, 3]).view(np.uint32).copy())
+        self._alloc_buffers()
+        self.stats["rebalances"] = self.stats.get("rebalances", 0) + 1
+        return True
 
     def gather_state(self):
         """Every rank's owned particles by creation index (NaN elsewhere) -> combined on all ranks."""

@@ -116,6 +116,9 @@ int sph_upload(sph_ctx* c, uint32_t n, const float* pos_xyz, const float* vel_xy
  * Any pointer may be NULL.  (The reference never copies particles back in CUDA mode; this is
  * the additive getArray of the north star.) */
 int sph_download(sph_ctx* c, uint32_t index_base, float* pos_xyz, float* vel_xyz, float* density, float* pressure);
+/* The owned particles compactly, in slot order: n x xyz, n x xyz, n creation indices (any may be NULL).
+ * What a slab driver needs to move whole particles between ranks (re-balancing). */
+int sph_download_owned(sph_ctx* c, float* pos_xyz, float* vel_xyz, uint32_t* index);
 int sph_download_forces(sph_ctx* c, uint32_t index_base, float* fpress_xyz, float* fvisc_xyz, float* dv_xyz,
                         int32_t* collision_count);
 /* The `gl_pos` analogue of cudaIntegrate (particleSystem.cu:416-419): float4 (x,y,z,1) per

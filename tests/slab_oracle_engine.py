@@ -150,6 +150,12 @@ class OracleEngine:
         self.vel = vel[self.n_glo:self.n_glo + self.n].copy()
         self.o.close(); self.o = None
 
+    def download_owned(self):
+        return self.pos.copy(), self.vel.copy(), self.idx.copy()
+
+    def to_device(self, arr):
+        return torch.from_numpy(np.ascontiguousarray(arr))
+
     def download(self, total):
         out = dict(pos=np.full((total, 3), np.nan, np.float32), vel=np.full((total, 3), np.nan, np.float32),
                    density=np.full(total, np.nan, np.float32), pressure=np.full(total, np.nan, np.float32))

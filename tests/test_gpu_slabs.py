@@ -144,3 +144,38 @@ def test_slab_entry_points_directly():
         c.migrants_append(lo.data_ptr(), want[0])
         c.hash(); c.sort()
         assert c.n == len(mine) - want[3] and c.slab_counts()[0] == want[0]
+
+
+def test_rebalance_on_gpu_engines():
+    """slab.SlabSimulation.rebalance() with the product engine: the fluid drifts out of its slabs, the
+    cuts follow, whole layers change owner, the physics matches the whole-domain context."""
+    pos, vel, box, grid = make_case("up")
+    vel[:, 2] = 12000.0
+    world, steps = 3, 65
+    hub = slab.LocalComm.Hub(world)
+    results, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            sim = slab.SlabSimulation(slab.LocalComm(hub, r), lambda cap, gcap, p, z0, z1: slab.HipEngine(cap, gcap, p, z0, z1, 0),
+                                      box, grid, particles=(pos, vel))
+            cuts0 = list(sim.cuts)
+            sim.run(DT, steps, rebalance_every=20)
+            results[r] = (sim.gather_state(), dict(sim.stats), cuts0, list(sim.cuts), sim.engine.n)
+            sim.engine.close()
+        except BaseException as e:     # noqa: BLE001
+            errors.append(e)
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=900)
+    assert not errors, errors
+    st, stats, cuts0, cuts1, _ = results[0]
+    assert stats.get("rebalances", 0) >= 1 and cuts1 != cuts0
+    owned = [r[4] for r in results]
+    assert sum(owned) == pos.shape[0] and max(owned) <= 1.35 * pos.shape[0] / world, owned
+    ref = _whole_domain(pos, vel, box, grid, steps)
+    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
+    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5

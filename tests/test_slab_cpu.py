@@ -99,3 +99,37 @@ def test_slabs_over_gloo_world_size_2():
     ref, box = _single_domain("up", steps)
     _check(out, ref, box)
     assert stats[0] > 0
+
+
+def test_rebalance_moves_the_cuts_and_keeps_the_physics():
+    """A column of fluid leaves its slabs (uniform upward drift): static cuts end up with one rank holding
+    most particles; rebalance() re-cuts by count, ships whole layers point to point, and the run goes on
+    matching the single-domain oracle."""
+    case, world, steps = "up", 3, 65      # re-cuts after steps 20, 40, 60; densities are those of the last step
+    pos, vel, box, grid = make_case(case)
+    vel[:, 2] = 12000.0                         # 0.006 per step: about six cell layers over the run
+    hub = slab.LocalComm.Hub(world)
+    results, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            sim = slab.SlabSimulation(slab.LocalComm(hub, r), OracleEngine, box, grid, particles=(pos, vel))
+            cuts0 = list(sim.cuts)
+            sim.run(DT, steps, rebalance_every=20)
+            results[r] = (sim.gather_state(), dict(sim.stats), cuts0, list(sim.cuts), sim.engine.n)
+        except BaseException as e:     # noqa: BLE001
+            errors.append(e)
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=900)
+    assert not errors, errors
+    st, stats, cuts0, cuts1, _ = results[0]
+    assert stats.get("rebalances", 0) >= 1 and cuts1 != cuts0
+    owned = [r[4] for r in results]
+    assert sum(owned) == pos.shape[0] and max(owned) <= 1.35 * pos.shape[0] / world, owned
+    o = oracle.Oracle(pos, vel, box, grid, oracle.CELL_LINEAR)
+    o.step(DT, steps)
+    ref = o.state(); o.close()
+    _check(st, ref, box)
