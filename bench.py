@@ -88,11 +88,9 @@ def cpu_baseline(budget_s=20.0):
 
 def run_single(args):
     cfg = ic.CONFIGS[args.workload]
-    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
-    n = pos.shape[0]
+    n = cfg["lattice"][0] * cfg["lattice"][1] * cfg["lattice"][2]
     ctx = capi.Context(n, box=cfg["box"], grid=cfg["grid"], device=0)
-    ctx.upload(pos, vel)
-    del pos, vel
+    ctx.reset_lattice(cfg["lattice"], jitter=True)        # synthetic data generated in HBM (== ic.dam_break_lattice)
     dt = float(ic.DEFAULT_DT)
     ctx.step(dt, args.warmup)
     ctx.sync()

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sph_num_particles": (_U32, [_P]),
     "sph_capacity": (_U32, [_P]),
     "sph_upload": (C.c_int, [_P, _U32, _P, _P, _P]),
+    "sph_reset_lattice": (C.c_int, [_P, C.POINTER(_U32), C.c_int, C.POINTER(C.c_float), C.c_uint64, _U32]),
     "sph_download": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
     "sph_download_owned": (C.c_int, [_P, _P, _P, _P]),
     "sph_download_forces": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
@@ -198,6 +199,14 @@ class Context:
         idx = np.ascontiguousarray(index, dtype=np.uint32) if index is not None else None
         _check(self.L.sph_upload(self.h, n, pos.ctypes.data, vel.ctypes.data if vel is not None else None,
                                  idx.ctypes.data if idx is not None else None))
+
+    def reset_lattice(self, lattice, jitter=True, jitter_dims=None, start=0, count=None):
+        """Dam-break lattice generated on the device (bit-identical to ic.dam_break_lattice)."""
+        lat = (_U32 * 3)(*[int(v) for v in lattice])
+        total = int(lattice[0]) * int(lattice[1]) * int(lattice[2])
+        count = total - start if count is None else count
+        jd = (C.c_float * 3)(*[float(v) for v in jitter_dims]) if jitter_dims is not None else None
+        _check(self.L.sph_reset_lattice(self.h, lat, 1 if jitter else 0, jd, int(start), int(count)))
 
     def download(self, index_base=0, count=None, want=("pos", "vel", "density", "pressure")):
         """State by creation index; rows of particles this context does not own stay NaN."""

@@ -202,8 +202,12 @@ void ParticleSystem::reset(ParticleConfig config) {
             uint32_t s = (uint32_t)std::floor(std::cbrt((double)n));
             while ((uint64_t)s * s * s < n) s++;
             const uint32_t lattice[3] = {s, s, s};
-            sph_ic_dam_break(lattice, box, 1, 0, n, m_xyz.data(), m_vxyz.data());
-        } break;
+            // generated on the device (bit-identical to the host twin sph_ic_dam_break); the host mirror is
+            // refreshed lazily by getArray()/dumpParticles()
+            SPH_CHECK(sph_reset_lattice(m_ctx, lattice, 1, nullptr, 0, (uint32_t)n));
+            m_hostStale = true;
+            return;
+        }
     }
     for (size_t i = 0; i < n; i++) {
         for (int a = 0; a < 3; a++) { m_hPos[4 * i + a] = m_xyz[3 * i + a]; m_hVel[4 * i + a] = 0.f; }

@@ -387,6 +387,30 @@ int sph_upload(sph_ctx* c, uint32_t n, const float* pos, const float* vel, const
     return SPH_OK;
 }
 
+int sph_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, const float jitter_dims[3], uint64_t start,
+                      uint32_t count) {
+    SPH_REQUIRE(c && lattice, SPH_E_INVALID, "null argument");
+    SPH_REQUIRE(count <= c->cap, SPH_E_CAPACITY, "%u particles > capacity %u", count, c->cap);
+    const uint64_t total = (uint64_t)lattice[0] * lattice[1] * lattice[2];
+    SPH_REQUIRE(lattice[0] && lattice[1] && lattice[2] && start + count <= total, SPH_E_INVALID,
+                "index range [%llu, +%u) outside the %llu-particle lattice", (unsigned long long)start, count,
+                (unsigned long long)total);
+    SPH_REQUIRE(c->slab || start + count <= c->pos_out_cap, SPH_E_INVALID, "creation indices exceed the capacity %u",
+                c->pos_out_cap);
+    SPH_REQUIRE(total <= 0xFFFFFFFFull, SPH_E_INVALID, "creation indices are 32-bit");
+    SPH_HIP(hipSetDevice(c->device));
+    int rc = launch_cells_clear(c);
+    if (rc) return rc;
+    c->own_off = c->gcap;
+    c->n = count; c->n_glo = c->n_ghi = 0;
+    rc = launch_reset_lattice(c, lattice, jitter, jitter_dims, start, count);
+    if (rc) return rc;
+    c->stage = sph_ctx::ST_LOADED;
+    c->keys_fresh = false;
+    c->have_dens = c->have_force = c->have_coll = false;
+    return SPH_OK;
+}
+
 static int fetch_sorted(sph_ctx* c, std::vector<float4>* hp, std::vector<float4>* hv, std::vector<float2>* hd) {
     SPH_HIP(hipSetDevice(c->device));
     const uint32_t n = c->n;

@@ -126,6 +126,8 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // kernel launchers (defined in the .hip files)
 int launch_hash(sph_ctx* c);
+int launch_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, const float jitter_dims[3], uint64_t start,
+                         uint32_t count);
 int launch_sort(sph_ctx* c);          // radix sort of (k0,v0)[0,n) + reorder into posi2/velr2/keyS
 int launch_cells_clear(sph_ctx* c);
 int launch_cells_build(sph_ctx* c);

@@ -110,9 +110,6 @@ __device__ __forceinline__ void lane_rows(const uint2* __restrict__ cells, const
     }
 }
 
-#ifndef SPH_COLL_EXACT
-#define SPH_COLL_EXACT 0
-#endif
 #ifndef SPH_DENS_OCC
 #define SPH_DENS_OCC 6      // waves per SIMD asked of the register allocator (<= 80 VGPRs)
 #endif
@@ -423,13 +420,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                             const float2 qa = e[0], qb = e[1], qc = e[2];
                             const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
                             const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;
-#if SPH_COLL_EXACT
-                            const float r2c = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
-                            const float dot = -__fadd_rn(__fmul_rn(dx, ux), __fadd_rn(__fmul_rn(dy, uy), __fmul_rn(dz, uz)));
-#else
                             const float r2c = dx * dx + dy * dy + dz * dz;
                             const float dot = -(dx * ux + dy * uy + dz * uz);           // r_ij . (v_i - v_j)
-#endif
                             // j == i needs no test: r_ij = 0 gives r.v = -0, which is not < 0 (the reference skips
                             // the pair by index, particleSystem.cu:54; a coincident pair fails r.v < 0 there too)
                             const bool hit = dot < 0.f;

@@ -13,7 +13,6 @@ constexpr int SORT_THREADS = 256;            // 4 waves
 constexpr int SORT_KPT = 16;                 // keys per thread
 constexpr int SORT_WAVE_TILE = WAVE * SORT_KPT;          // 1024 consecutive keys per wave
 constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;       // 4096 keys per block
-constexpr int MAX_RADIX = 512;
 
 // ---- hash: key per owned particle ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hash(const float4* __restrict__ posi, uint32_t n, GridDesc g,
@@ -185,6 +184,69 @@ __global__ __launch_bounds__(256) void k_reorder(const uint32_t* __restrict__ ks
         if (i == 0 || ks[i - 1] != k) cells[k].x = slot0 + i;
         if (i + 1 == n || ks[i + 1] != k) cells[k].y = slot0 + i + 1;
     }
+}
+
+// ---- initial conditions on the device: twin of sph_ic_dam_break (csrc/particleSystem.cpp) ------------------
+__device__ __forceinline__ uint32_t ic_hash(uint32_t x) {   // lowbias32
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+struct LatticeDesc {
+    uint32_t nx, ny;
+    float box[3], jdim[3];
+    float spacing, radius, jit;
+    uint32_t seed;
+    int jitter;
+};
+
+__global__ __launch_bounds__(256) void k_reset_lattice(float4* __restrict__ posi, float4* __restrict__ velr,
+                                                       float2* __restrict__ dp, float4* __restrict__ pos_by_index,
+                                                       uint64_t start, uint32_t count, LatticeDesc L) {
+#pragma clang fp contract(off)      // one rounding per operation: no multiply-add fusion in this kernel
+    uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= count) return;
+    const uint64_t idx = start + k;
+    const float ia[3] = {(float)(idx % L.nx), (float)((idx / L.nx) % L.ny), (float)(idx / ((uint64_t)L.nx * L.ny))};
+    float p[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        // one rounding per operation, in the host twin's order
+        const float bmin = -L.box[a] / 2.0f;
+        float base = (L.spacing * ia[a] + L.radius) + bmin;
+        if (L.jitter) {
+            uint32_t h = ic_hash((uint32_t)idx * 3u + (uint32_t)a + L.seed * 0x9E3779B9u);
+            h = ic_hash(h ^ 0x85EBCA6Bu);
+            const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+            const float w = L.jdim[a];
+            base = base + (w * u - w / 2.0f) * L.jit;
+        }
+        p[a] = base;
+    }
+    posi[k] = make_float4(p[0], p[1], p[2], __uint_as_float((uint32_t)idx));
+    velr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dp[k] = make_float2(0.f, 0.f);
+    if (pos_by_index) pos_by_index[idx] = make_float4(p[0], p[1], p[2], 1.0f);
+}
+
+int launch_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, const float jitter_dims[3], uint64_t start,
+                         uint32_t count) {
+    LatticeDesc L;
+    L.nx = lattice[0]; L.ny = lattice[1];
+    for (int a = 0; a < 3; a++) {
+        L.box[a] = c->params.box_max[a] - c->params.box_min[a];
+        L.jdim[a] = jitter_dims ? jitter_dims[a] : L.box[a];
+    }
+    L.radius = c->params.particle_radius;
+    L.spacing = 2.0f * L.radius;
+    L.jit = L.radius * 0.01f;
+    L.seed = 1973u;
+    L.jitter = jitter;
+    if (count)
+        hipLaunchKernelGGL(k_reset_lattice, dim3(ceil_div(count, 256)), dim3(256), 0, c->stream, c->posi + c->own_off,
+                           c->velr + c->own_off, c->dp + c->own_off, c->slab ? nullptr : c->pos_out, start, count, L);
+    SPH_HIP(hipGetLastError());
+    return SPH_OK;
 }
 
 int launch_hash(sph_ctx* c) {

@@ -112,6 +112,13 @@ uint32_t sph_capacity(const sph_ctx* c);
  * index (Particle::index), NULL = 0..n-1.  Replaces copyArrayToDevice of the AoS array
  * (particleSystem.cpp:920,960).  Density/pressure/forces are reset to 0. */
 int sph_upload(sph_ctx* c, uint32_t n, const float* pos_xyz, const float* vel_xyz, const uint32_t* index);
+/* Generate the dam-break lattice ON THE DEVICE (no host arrays, no PCIe): particles with creation index
+ * index_start .. index_start+count of an (nx, ny, nz) lattice in the min corner of the box, spacing 2R,
+ * zero velocity, counter-based jitter (amplitude from jitter_dims, NULL = the box; jitter = 0 switches it
+ * off).  Bit-identical to sph_ic_dam_break / gpufluidsimulator_amd.ic.dam_break_lattice.  Replaces
+ * initGrid + the AoS upload of reset(CONFIG_GRID) (SPH/particleSystem.cpp:839-874, 909-920). */
+int sph_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, const float jitter_dims[3],
+                      uint64_t index_start, uint32_t count);
 /* Gather the state BY CREATION INDEX relative to index_base: out[(index-index_base)*3+k].
  * Any pointer may be NULL.  (The reference never copies particles back in CUDA mode; this is
  * the additive getArray of the north star.) */

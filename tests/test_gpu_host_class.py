@@ -76,3 +76,23 @@ def test_benchmark_log_has_the_reference_format():
     m = body[-1]
     total, dens, force = int(m.group(2)), int(m.group(8)), int(m.group(9))
     assert total > 0 and dens > 0 and force > 0 and dens + force <= total
+
+
+def test_device_lattice_generator_is_bit_identical_to_numpy():
+    cases = [((16, 16, 16), (4.0, 4.0, 4.0), (64,) * 3, True, None, 0, None),
+             ((7, 5, 9), (2.0, 4.0, 8.0), (32, 64, 128), True, None, 0, None),
+             ((12, 12, 12), (2.0, 2.0, 2.0), (32,) * 3, False, None, 0, None),
+             ((32, 32, 128), (4.0, 4.0, 16.0), (64, 64, 256), True, (4.0, 4.0, 4.0), 0, None),
+             ((64, 64, 64), (8.0, 8.0, 8.0), (128,) * 3, True, None, 123456, 5000)]
+    for lattice, box, grid, jitter, jd, start, count in cases:
+        total = lattice[0] * lattice[1] * lattice[2]
+        cnt = total - start if count is None else count
+        with capi.Context(total, box=box, grid=grid) as c:
+            c.reset_lattice(lattice, jitter=jitter, jitter_dims=jd, start=start, count=cnt)
+            pos, vel, idx = c.download_owned()
+            want, _ = ic.dam_break_lattice(lattice, box, jitter=jitter, start=start, count=cnt, jitter_dims=jd)
+            assert np.array_equal(idx, np.arange(start, start + cnt, dtype=np.uint32))
+            assert np.array_equal(pos.view(np.uint32), want.view(np.uint32)), (lattice, jitter)
+            assert not vel.any()
+            c.step(DT, 2)                                   # and the step runs from it
+            assert np.isfinite(c.download(count=total, want=("density",))["density"][start:start + cnt]).all()
