@@ -7,6 +7,25 @@ namespace sph {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2.
+// Map the hardware block id to a logical one so that every XCD walks ONE contiguous eighth of the
+// sorted particles: neighbouring rows are then re-used out of that XCD's L2 instead of being
+// fetched through the fabric by all eight.  A bijection on [0, nb) for any nb.
+// Measured at C3 (round 1): no gain -- k_force 2.67 vs 2.63 ms, FETCH_SIZE 2.9 vs 2.6 GB; the three
+// z-layers a sweep re-uses (9.8 MB) exceed one XCD's 4 MB L2 either way, and the kernel is VALU-bound.
+// Off by default; -DSPH_XCD_SWIZZLE=1 to re-measure after a layout change.
+#ifndef SPH_XCD_SWIZZLE
+#define SPH_XCD_SWIZZLE 0
+#endif
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
+#if SPH_XCD_SWIZZLE
+    const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u;
+    return xcd * q + (xcd < r ? xcd : r) + (b >> 3);
+#else
+    return b;
+#endif
+}
+
 // ---- wave64 reductions over DPP (no LDS): row reductions by quad_perm / mirrors, then
 //      row_bcast15 / row_bcast31 carry the partial results to lane 63 (gfx9 DPP controls).
 template <int CTRL, int ROW_MASK = 0xF>

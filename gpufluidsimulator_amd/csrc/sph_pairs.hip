@@ -200,7 +200,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slice = wave * PIECE;
-    const uint32_t i = tgt_lo + (blockIdx.x * PAIR_WAVES + wave) * WAVE + lane;
+    const uint32_t i = tgt_lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE + lane;
     const bool active = i < tgt_hi;
     const uint32_t ii = active ? i : tgt_hi - 1;
     const float4 pi = posi[ii];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slice = wave * PIECE;
-    const uint32_t i = tgt_lo + (blockIdx.x * PAIR_WAVES + wave) * WAVE + lane;
+    const uint32_t i = tgt_lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE + lane;
     const bool active = i < tgt_hi;
     const uint32_t ii = active ? i : tgt_hi - 1;
     float4 pi = posi[ii];
