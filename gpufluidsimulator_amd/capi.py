@@ -76,6 +76,7 @@ SIGNATURES = {
     "sph_timing_enable": (C.c_int, [_P, C.c_int]),
     "sph_timing_get": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U32)]),
     "sph_timing_reset": (C.c_int, [_P]),
+    "sph_sort_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_slab_counts": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_migrants_pack": (C.c_int, [_P, C.POINTER(_P), _U32]),
@@ -297,6 +298,12 @@ class Context:
     # -- timing ---------------------------------------------------------------------------------
     def timing(self, on=True): _check(self.L.sph_timing_enable(self.h, 1 if on else 0))
     def timing_reset(self): _check(self.L.sph_timing_reset(self.h))
+
+    def sort_stats(self):
+        """{'sorts', 'merges', 'last_movers'}: how often the sort took the merge path (see sph_hip.h)."""
+        a, b, m = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        _check(self.L.sph_sort_stats(self.h, C.byref(a), C.byref(b), C.byref(m)))
+        return {"sorts": a.value, "merges": b.value, "last_movers": m.value}
 
     def timing_get(self):
         ms = (C.c_float * len(PHASES))()

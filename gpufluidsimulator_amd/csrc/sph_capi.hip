@@ -103,6 +103,9 @@ static void free_all(sph_ctx* c) {
     hipFree(c->fpress); hipFree(c->fvisc); hipFree(c->dvel); hipFree(c->pos_out); hipFree(c->cells);
     hipFree(c->k0); hipFree(c->v0); hipFree(c->k1); hipFree(c->v1); hipFree(c->hist); hipFree(c->digit_tot);
     hipFree(c->d_scratch);
+    hipFree(c->mm_mask); hipFree(c->mm_M64); hipFree(c->mm_tile_cnt); hipFree(c->mm_tile_off);
+    hipFree(c->mm_k0); hipFree(c->mm_k1); hipFree(c->mm_v1); hipFree(c->mm_count);
+    if (c->mm_count_host) hipHostFree(c->mm_count_host);
     if (c->h_scratch) hipHostFree(c->h_scratch);
 }
 
@@ -157,6 +160,32 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (!rc && hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(uint32_t)) != hipSuccess) {
         set_error("hipHostMalloc failed");
         rc = SPH_E_NOMEM;
+    }
+    {   // merge sort scratch
+        const char* env = getenv("SPH_SORT_MERGE");
+        c->sort_merge = !(env && env[0] == '0');
+        const size_t nchunks = (size_t)ceil_div(capacity, 64u) + 1, ntiles = nchunks / 256 + 2;
+        if (!rc) rc = dev_alloc(&c->mm_mask, nchunks);
+        if (!rc) rc = dev_alloc(&c->mm_M64, nchunks);
+        if (!rc) rc = dev_alloc(&c->mm_tile_cnt, ntiles);
+        if (!rc) rc = dev_alloc(&c->mm_tile_off, ntiles);
+        if (!rc) rc = dev_alloc(&c->mm_k0, (size_t)capacity);
+        if (!rc) rc = dev_alloc(&c->mm_k1, (size_t)capacity);
+        if (!rc) rc = dev_alloc(&c->mm_v1, (size_t)capacity);
+        if (!rc) rc = dev_alloc(&c->mm_count, (size_t)1);
+        if (!rc && (hipHostMalloc((void**)&c->mm_count_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+                    hipHostGetDevicePointer((void**)&c->mm_count_host_dev, c->mm_count_host, 0) != hipSuccess)) {
+            set_error("hipHostMalloc(mapped) failed");
+            rc = SPH_E_NOMEM;
+        }
+        if (!rc) {
+            *c->mm_count_host = 0;
+            if (hipMemset(c->mm_tile_cnt, 0, ntiles * sizeof(uint32_t)) != hipSuccess ||
+                hipMemset(c->mm_count, 0, sizeof(uint32_t)) != hipSuccess) {
+                set_error("hipMemset failed");
+                rc = SPH_E_DEVICE;
+            }
+        }
     }
     if (!rc && hipMemset(c->cells, 0, (size_t)c->grid.ncells * sizeof(uint2)) != hipSuccess) {
         set_error("hipMemset(cells) failed");
@@ -328,6 +357,8 @@ int sph_set_params(sph_ctx* c, const sph_params* p) {
     int rc = derive(&tmp, p, c->z_lo, c->z_hi, c->slab);
     if (rc) return rc;
     c->params = tmp.params; c->grid = tmp.grid; c->phys = tmp.phys;
+    c->keys_fresh = false;      // the box may have moved: keys of the old box are stale
+    c->order_valid = false;
     return SPH_OK;
 }
 
@@ -383,6 +414,7 @@ int sph_upload(sph_ctx* c, uint32_t n, const float* pos, const float* vel, const
     SPH_HIP(hipStreamSynchronize(c->stream));
     c->stage = sph_ctx::ST_LOADED;
     c->keys_fresh = false;
+    c->order_valid = false;     // the slots no longer follow the last sort
     c->have_dens = c->have_force = c->have_coll = false;
     return SPH_OK;
 }
@@ -407,6 +439,7 @@ int sph_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, const f
     if (rc) return rc;
     c->stage = sph_ctx::ST_LOADED;
     c->keys_fresh = false;
+    c->order_valid = false;     // the slots no longer follow the last sort
     c->have_dens = c->have_force = c->have_coll = false;
     return SPH_OK;
 }
@@ -745,6 +778,16 @@ int sph_timing_reset(sph_ctx* c) {
     timing_collect(c);
     for (int k = 0; k < SPH_PH_COUNT; k++) c->ph_ms[k] = 0;
     c->timed_steps = 0;
+    return SPH_OK;
+}
+
+int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint32_t* last_movers) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_HIP(hipSetDevice(c->device));
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    if (sorts) *sorts = c->sort_calls;
+    if (merges) *merges = c->sort_merges;
+    if (last_movers) *last_movers = *c->mm_count_host;
     return SPH_OK;
 }
 

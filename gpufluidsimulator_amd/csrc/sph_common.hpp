@@ -14,6 +14,7 @@
 namespace sph {
 
 constexpr int WAVE = 64;
+constexpr uint32_t MM_TILE_CHUNKS = 256;   // merge sort: 64-slot chunks per scan tile (sph_sort.hip)
 
 // Grid description passed by value to kernels (replaces the device-resident SimParams*
 // every reference kernel dereferences, particleSystem.cu:93-103,127-130).
@@ -91,6 +92,20 @@ struct sph_ctx {
     uint32_t sort_blocks_cap = 0;
     uint32_t key_bits = 0;
     const uint32_t* last_perm = nullptr;   // v0 or v1: the permutation of the last sort
+    // the sort as a merge (sph_sort.hip: launch_sort_merge)
+    bool sort_merge = true;         // SPH_SORT_MERGE=0 in the environment at create time turns it off
+    bool order_valid = false;       // [own_off, own_off+n) is still in the order of the last sort, keyS = its keys
+    uint64_t sort_merges = 0, sort_calls = 0;
+    uint64_t* mm_mask = nullptr;    // one bit per slot: key changed since the last sort
+    uint32_t* mm_M64 = nullptr;     // movers before each 64-slot chunk
+    uint32_t* mm_tile_cnt = nullptr; uint32_t* mm_tile_off = nullptr;
+    uint32_t* mm_k0 = nullptr; uint32_t* mm_k1 = nullptr; uint32_t* mm_v1 = nullptr;   // mover (key, slot) ping-pong (+ v0)
+    uint32_t* mm_count = nullptr;           // movers of the current sort (device)
+    uint32_t* mm_count_host = nullptr;      // pinned, written by the device: last known count (a hint)
+    uint32_t* mm_count_host_dev = nullptr;  // device view of the same word
+    // the fused integrate epilogue already wrote mm_mask / mm_tile_cnt for the range it was launched on
+    bool mm_marked = false;
+    uint32_t mm_marked_off = 0, mm_marked_n = 0;
     uint32_t* d_scratch = nullptr;  // small device scratch (counts)
     uint32_t* h_scratch = nullptr;  // pinned host mirror
 
@@ -108,6 +123,7 @@ struct sph_ctx {
 namespace sph {
 
 void set_error(const char* fmt, ...);
+void mm_drop_marks(sph_ctx* c);     // sph_sort.hip
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define SPH_HIP(call)                                                        \

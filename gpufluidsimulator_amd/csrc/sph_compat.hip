@@ -184,6 +184,7 @@ void cudaMapZIndex(sph_compat_particle* p, unsigned int n, sph_compat_simparams*
     }
     x->stage = sph_ctx::ST_LOADED;
     x->keys_fresh = false;
+    x->order_valid = false;     // the slots no longer follow the last sort
     x->have_dens = x->have_force = x->have_coll = false;
     CK(sph_hash(x));
     writeback(c, p, F_ZINDEX);

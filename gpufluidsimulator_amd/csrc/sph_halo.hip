@@ -126,6 +126,7 @@ int sph_migrants_append(sph_ctx* c, const void* buf_dev, uint32_t n_in) {
     SPH_HIP(hipGetLastError());
     c->n += n_in;
     c->keys_fresh = false;
+    c->order_valid = false;     // the slots no longer follow the last sort
     c->stage = sph_ctx::ST_LOADED;   // order destroyed: hash + sort again
     return SPH_OK;
 }

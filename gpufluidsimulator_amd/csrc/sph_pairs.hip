@@ -303,7 +303,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     const uint32_t* __restrict__ keyS, const uint2* __restrict__ cells, float4* __restrict__ fpress,
     float4* __restrict__ fvisc, float4* __restrict__ dvel, float4* __restrict__ posi_out,
     float4* __restrict__ velr_out, float4* __restrict__ pos_by_index, uint32_t* __restrict__ keys_out,
-    uint32_t tgt_lo, uint32_t tgt_hi, float dt, GridDesc g, Phys ph) {
+    uint64_t* __restrict__ mm_mask, uint32_t* __restrict__ mm_tile_cnt, uint32_t tgt_lo, uint32_t tgt_hi, float dt,
+    GridDesc g, Phys ph) {
     // One candidate = 4 float2 {x,y} {z,vx} {vy,vz} {cp,w} at a 40-byte stride (5 float2, the fifth is
     // padding): one address register serves all four ds_read_b64 through immediate offsets, and the
     // 8-entry (one cell) distance between the lane groups of a wave is 80 dwords = 16 banks, so the four
@@ -433,25 +434,38 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                 }
             }
         });
-    if (!active) return;
-    float dvx = 0.f, dvy = 0.f, dvz = 0.f;
-    if (COLL) {
-        const float den = ph.mass * (float)(1u + ccount);
-        dvx = -cvx / den; dvy = -cvy / den; dvz = -cvz / den;
-    }
-    if (INTEG) {
-        integrate_one(ph, dt, pi, vi, dpi.x, fpx + fvx, fpy + fvy, fpz + fvz, dvx, dvy, dvz);
-        posi_out[i] = pi;
-        velr_out[i] = vi;
-        if (pos_by_index) pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
-        // the next step's cell hash (kernelGetZIndex) while the new position is still in registers
-        keys_out[i - tgt_lo] = cell_key(g, pi.x, pi.y, pi.z);
-    } else {
-        if (FORCE) {
-            fpress[i] = make_float4(fpx, fpy, fpz, 0.f);
-            fvisc[i] = make_float4(fvx, fvy, fvz, 0.f);
+    bool moved = false;
+    if (active) {
+        float dvx = 0.f, dvy = 0.f, dvz = 0.f;
+        if (COLL) {
+            const float den = ph.mass * (float)(1u + ccount);
+            dvx = -cvx / den; dvy = -cvy / den; dvz = -cvz / den;
         }
-        if (COLL) dvel[i] = make_float4(dvx, dvy, dvz, __uint_as_float(ccount));
+        if (INTEG) {
+            integrate_one(ph, dt, pi, vi, dpi.x, fpx + fvx, fpy + fvy, fpz + fvz, dvx, dvy, dvz);
+            posi_out[i] = pi;
+            velr_out[i] = vi;
+            if (pos_by_index) pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
+            // the next step's cell hash (kernelGetZIndex) while the new position is still in registers
+            const uint32_t key = cell_key(g, pi.x, pi.y, pi.z);
+            keys_out[i - tgt_lo] = key;
+            if (mm_mask) moved = key != keyS[i];
+        } else {
+            if (FORCE) {
+                fpress[i] = make_float4(fpx, fpy, fpz, 0.f);
+                fvisc[i] = make_float4(fvx, fvy, fvz, 0.f);
+            }
+            if (COLL) dvel[i] = make_float4(dvx, dvy, dvz, __uint_as_float(ccount));
+        }
+    }
+    if (INTEG && mm_mask) {
+        // movers of the next sort (sph_sort.hip: the merge path), one bit per slot: this wave IS one 64-slot chunk
+        const uint64_t m = __ballot(moved);
+        const uint32_t chunk = xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave;
+        if (lane == 0 && chunk * WAVE < tgt_hi - tgt_lo) {
+            mm_mask[chunk] = m;
+            if (m) atomicAdd(&mm_tile_cnt[chunk / MM_TILE_CHUNKS], (uint32_t)__popcll(m));
+        }
     }
 }
 
@@ -459,10 +473,14 @@ int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt)
     if (c->n == 0) return SPH_OK;
     const uint32_t lo = c->own_off, hi = c->own_off + c->n;
     dim3 grid(ceil_div(c->n, PAIR_THREADS)), block(PAIR_THREADS);
+    // the integrate epilogue marks the movers of the next sort; marks of an earlier launch that no sort
+    // consumed are dropped first (they would be counted twice)
+    if (integrate) mm_drop_marks(c);
+    const bool mark = integrate && c->sort_merge && c->order_valid;
 #define SPH_LAUNCH_FORCE(F, C, I)                                                                              \
     hipLaunchKernelGGL((k_force<F, C, I>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->keyS, c->cells, \
-                       c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, c->k0, lo, hi, dt, c->grid,  \
-                       c->phys)
+                       c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, c->k0,              \
+                       mark ? c->mm_mask : nullptr, c->mm_tile_cnt, lo, hi, dt, c->grid, c->phys)
     if (force && collide && integrate) SPH_LAUNCH_FORCE(true, true, true);
     else if (force && !collide && !integrate) SPH_LAUNCH_FORCE(true, false, false);
     else if (!force && collide && !integrate) SPH_LAUNCH_FORCE(false, true, false);
@@ -477,6 +495,7 @@ int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt)
         t = c->posi; c->posi = c->posi2; c->posi2 = t;
         t = c->velr; c->velr = c->velr2; c->velr2 = t;
         c->keys_fresh = true;
+        if (mark) { c->mm_marked = true; c->mm_marked_off = lo; c->mm_marked_n = c->n; }
     }
     return SPH_OK;
 }

@@ -25,32 +25,48 @@ __global__ __launch_bounds__(256) void k_hash(const float4* __restrict__ posi, u
 
 // ---- pass 1 of 3: per-block digit histogram ----------------------------------------------------
 // BITS = 8 or 9 bits per pass: 27 significant key bits (512^3 cells) sort in 3 passes of 9.
+// All three kernels walk "virtual blocks" (tiles of SORT_TILE keys) grid-stride, and take the element
+// count either by value or from device memory (n_dev, clamped to n): the main sort launches one block
+// per tile; the sort of the movers (see launch_sort_merge) is sized from a stale estimate and is
+// correct for any count.
+__device__ __forceinline__ uint32_t sort_count(uint32_t n, const uint32_t* __restrict__ n_dev) {
+    return n_dev ? min(*n_dev, n) : n;
+}
+
 template <int BITS>
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys, uint32_t n,
-                                                            uint32_t shift, uint32_t nblocks,
-                                                            uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys, uint32_t n_arg,
+                                                            const uint32_t* __restrict__ n_dev, uint32_t shift,
+                                                            uint32_t nblocks, uint32_t* __restrict__ hist) {
     constexpr int RADIX = 1 << BITS;
     __shared__ uint32_t h[RADIX];
-    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) h[d] = 0;
-    __syncthreads();
-    uint32_t base = blockIdx.x * SORT_TILE;
+    const uint32_t n = sort_count(n_arg, n_dev);
+    const uint32_t nvb = (n + SORT_TILE - 1) / SORT_TILE;
+    for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) h[d] = 0;
+        __syncthreads();
+        uint32_t base = vb * SORT_TILE;
 #pragma unroll
-    for (int t = 0; t < SORT_KPT; t++) {
-        uint32_t i = base + t * SORT_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
+        for (int t = 0; t < SORT_KPT; t++) {
+            uint32_t i = base + t * SORT_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) hist[(size_t)d * nblocks + vb] = h[d];   // digit-major
+        __syncthreads();
     }
-    __syncthreads();
-    for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) hist[(size_t)d * nblocks + blockIdx.x] = h[d];   // digit-major
 }
 
 // ---- pass 2 of 3: one block per digit scans its row of per-block counts --------------------------
-__global__ __launch_bounds__(256) void k_sort_scan(uint32_t* __restrict__ hist, uint32_t nblocks,
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t n_arg,
+                                                   const uint32_t* __restrict__ n_dev,
                                                    uint32_t* __restrict__ digit_tot) {
     __shared__ uint32_t part[256];
+    const uint32_t n = sort_count(n_arg, n_dev);
+    const uint32_t nvb = (n + SORT_TILE - 1) / SORT_TILE;      // entries of the row in use (<= nblocks, the stride)
     uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
-    uint32_t per = (nblocks + 255u) / 256u;
-    uint32_t lo = min(threadIdx.x * per, nblocks);
-    uint32_t hi = min(lo + per, nblocks);
+    uint32_t per = (nvb + 255u) / 256u;
+    uint32_t lo = min(threadIdx.x * per, nvb);
+    uint32_t hi = min(lo + per, nvb);
     uint32_t s = 0;
     for (uint32_t i = lo; i < hi; i++) s += row[i];
     part[threadIdx.x] = s;
@@ -79,7 +95,8 @@ template <int BITS, bool FIRST>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* __restrict__ kin,
                                                                const uint32_t* __restrict__ vin,
                                                                uint32_t* __restrict__ kout,
-                                                               uint32_t* __restrict__ vout, uint32_t n,
+                                                               uint32_t* __restrict__ vout, uint32_t n_arg,
+                                                               const uint32_t* __restrict__ n_dev,
                                                                uint32_t shift, uint32_t nblocks,
                                                                const uint32_t* __restrict__ hist,
                                                                const uint32_t* __restrict__ digit_tot) {
@@ -87,9 +104,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* _
     constexpr int DPT = RADIX / SORT_THREADS;       // digits per thread: 1 or 2 (consecutive digits)
     __shared__ uint32_t wh[4][RADIX];     // per-wave digit counters -> running offsets
     __shared__ uint32_t part[SORT_THREADS];
+    const uint32_t n = sort_count(n_arg, n_dev);
+    const uint32_t nvb = (n + SORT_TILE - 1) / SORT_TILE;
+    if (blockIdx.x >= nvb) return;                  // block-uniform
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (int w = 0; w < 4; w++)
-        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) wh[w][d] = 0;
     // exclusive scan of the digit totals (global base of every digit): thread t owns digits t*DPT ..
     uint32_t tot[DPT], sum = 0;
 #pragma unroll
@@ -102,65 +120,73 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* _
         part[threadIdx.x] += v;
         __syncthreads();
     }
-    uint32_t my_base[DPT];
-    {
-        uint32_t run = part[threadIdx.x] - sum;
+    const uint32_t digit_base = part[threadIdx.x] - sum;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        for (int w = 0; w < 4; w++)
+            for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) wh[w][d] = 0;
+        uint32_t my_base[DPT];
+        {
+            uint32_t run = digit_base;
+#pragma unroll
+            for (int k = 0; k < DPT; k++) {
+                my_base[k] = run + hist[(size_t)(threadIdx.x * DPT + k) * nblocks + vb];
+                run += tot[k];
+            }
+        }
+        __syncthreads();
+
+        // load this wave's keys (registers) and count digits per wave
+        const uint32_t wbase = vb * SORT_TILE + wave * SORT_WAVE_TILE;
+        uint32_t key[SORT_KPT];
+#pragma unroll
+        for (int t = 0; t < SORT_KPT; t++) {
+            uint32_t i = wbase + t * WAVE + lane;
+            key[t] = i < n ? kin[i] : 0xFFFFFFFFu;
+            if (i < n) atomicAdd(&wh[wave][(key[t] >> shift) & (RADIX - 1)], 1u);
+        }
+        __syncthreads();
+        // per digit: exclusive scan over the 4 waves, plus the global base
 #pragma unroll
         for (int k = 0; k < DPT; k++) {
-            my_base[k] = run + hist[(size_t)(threadIdx.x * DPT + k) * nblocks + blockIdx.x];
-            run += tot[k];
+            const uint32_t d = threadIdx.x * DPT + k;
+            uint32_t o = my_base[k];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                uint32_t cnt = wh[w][d];
+                wh[w][d] = o;
+                o += cnt;
+            }
         }
-    }
+        __syncthreads();
 
-    // load this wave's keys (registers) and count digits per wave
-    const uint32_t wbase = blockIdx.x * SORT_TILE + wave * SORT_WAVE_TILE;
-    uint32_t key[SORT_KPT];
+        volatile uint32_t* cnt = wh[wave];
 #pragma unroll
-    for (int t = 0; t < SORT_KPT; t++) {
-        uint32_t i = wbase + t * WAVE + lane;
-        key[t] = i < n ? kin[i] : 0xFFFFFFFFu;
-        if (i < n) atomicAdd(&wh[wave][(key[t] >> shift) & (RADIX - 1)], 1u);
-    }
-    __syncthreads();
-    // per digit: exclusive scan over the 4 waves, plus the global base
+        for (int t = 0; t < SORT_KPT; t++) {
+            uint32_t i = wbase + t * WAVE + lane;
+            bool valid = i < n;
+            uint32_t d = (key[t] >> shift) & (RADIX - 1);
+            uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int k = 0; k < DPT; k++) {
-        const uint32_t d = threadIdx.x * DPT + k;
-        uint32_t o = my_base[k];
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            uint32_t cnt = wh[w][d];
-            wh[w][d] = o;
-            o += cnt;
+            for (int b = 0; b < BITS; b++) {
+                bool bit = (d >> b) & 1u;
+                uint64_t m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            uint32_t base = 0;
+            if (valid) base = cnt[d];                       // every peer reads the same word
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) cnt[d] = base + (uint32_t)__popcll(peers);   // LDS is in order per wave
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                uint32_t dst = base + rank;
+                kout[dst] = key[t];
+                vout[dst] = FIRST ? i : vin[i];
+            }
         }
-    }
-    __syncthreads();
-
-    volatile uint32_t* cnt = wh[wave];
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int t = 0; t < SORT_KPT; t++) {
-        uint32_t i = wbase + t * WAVE + lane;
-        bool valid = i < n;
-        uint32_t d = (key[t] >> shift) & (RADIX - 1);
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < BITS; b++) {
-            bool bit = (d >> b) & 1u;
-            uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-        uint32_t base = 0;
-        if (valid) base = cnt[d];                       // every peer reads the same word
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) cnt[d] = base + (uint32_t)__popcll(peers);   // LDS is in order per wave
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            uint32_t dst = base + rank;
-            kout[dst] = key[t];
-            vout[dst] = FIRST ? i : vin[i];
-        }
+        __syncthreads();                                    // wh is re-zeroed by the next tile
     }
 }
 
@@ -258,16 +284,222 @@ int launch_hash(sph_ctx* c) {
 }
 
 template <int BITS>
-static void sort_pass(sph_ctx* c, uint32_t n, uint32_t nblocks, uint32_t shift, bool first, const uint32_t* kin,
-                      const uint32_t* vin, uint32_t* kout, uint32_t* vout) {
-    hipLaunchKernelGGL(k_sort_hist<BITS>, dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, n, shift, nblocks, c->hist);
-    hipLaunchKernelGGL(k_sort_scan, dim3(1 << BITS), dim3(256), 0, c->stream, c->hist, nblocks, c->digit_tot);
+static void sort_pass(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, uint32_t nblocks, uint32_t shift,
+                      bool first, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout) {
+    hipLaunchKernelGGL(k_sort_hist<BITS>, dim3(grid), dim3(SORT_THREADS), 0, c->stream, kin, n, n_dev, shift, nblocks,
+                       c->hist);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1 << BITS), dim3(256), 0, c->stream, c->hist, nblocks, n, n_dev, c->digit_tot);
     if (first)
-        hipLaunchKernelGGL((k_sort_scatter<BITS, true>), dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
-                           vout, n, shift, nblocks, c->hist, c->digit_tot);
+        hipLaunchKernelGGL((k_sort_scatter<BITS, true>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
+                           vout, n, n_dev, shift, nblocks, c->hist, c->digit_tot);
     else
-        hipLaunchKernelGGL((k_sort_scatter<BITS, false>), dim3(nblocks), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
-                           vout, n, shift, nblocks, c->hist, c->digit_tot);
+        hipLaunchKernelGGL((k_sort_scatter<BITS, false>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
+                           vout, n, n_dev, shift, nblocks, c->hist, c->digit_tot);
+}
+
+// LSD radix sort of (key, value) pairs over the context's significant key bits.  `first`: the values of
+// the first pass are the element indices (vin unused).  n_dev != null: the count lives on the device
+// (<= n), `grid` blocks walk the tiles.  Returns through kin/vin the buffers that hold the result.
+static void radix_sort_pairs(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, bool first, uint32_t*& kin,
+                             uint32_t*& vin, uint32_t*& kout, uint32_t*& vout) {
+    const uint32_t nblocks = ceil_div(n, SORT_TILE);          // row stride of the histogram
+    // 9-bit digits when they save a pass over 8-bit ones (27 bits: 3 x 9), else 8-bit digits.  Measured
+    // per pass at 16.7 M keys: 124 us (8 bits), 150 us (9 bits), 220 us (10 bits: never worth it).
+    const uint32_t p8 = (c->key_bits + 7) / 8, p9 = (c->key_bits + 8) / 9;
+    const uint32_t bits = p9 < p8 ? 9u : 8u;
+    const uint32_t passes = bits == 9u ? p9 : p8;
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t shift = p * bits;
+        if (bits == 8) sort_pass<8>(c, n, n_dev, grid, nblocks, shift, first && p == 0, kin, vin, kout, vout);
+        else sort_pass<9>(c, n, n_dev, grid, nblocks, shift, first && p == 0, kin, vin, kout, vout);
+        uint32_t* t;
+        t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+}
+
+// ---- the sort as a merge: only the particles whose cell changed are sorted -----------------------------------
+// Between two steps a particle moves a small fraction of a cell, so after the integrate almost every key
+// equals the key its slot was sorted under.  With A = the keys of the current (sorted) order and B = the
+// new keys, the non-movers (A[i] == B[i]) are already in order; the movers are compacted (stable), radix
+// sorted on their own, and both sequences get their merged positions by rank:
+//   non-mover i :  (i - #movers before i) + #movers with (key, slot) < (A[i], i)
+//   mover r     :  r + #non-movers with (key, slot) < (B, slot)
+// The result is the (key, slot) sequence of the full stable sort, element for element, for ANY number of
+// movers; launch_sort only prefers the full sort when the last known mover count makes it cheaper.
+
+__global__ __launch_bounds__(256) void k_mm_mark(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B,
+                                                 uint32_t n, uint64_t* __restrict__ mask,
+                                                 uint32_t* __restrict__ tile_cnt) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool mv = i < n && A[i] != B[i];
+    const uint64_t m = __ballot(mv);
+    if ((threadIdx.x & 63u) == 0 && (i & ~63u) < n) {
+        const uint32_t chunk = i >> 6;
+        mask[chunk] = m;
+        if (m) atomicAdd(&tile_cnt[chunk / MM_TILE_CHUNKS], (uint32_t)__popcll(m));   // sparse
+    }
+}
+
+// one block: exclusive scan of the per-tile mover counts; re-zeroes the counts for the next step
+__global__ __launch_bounds__(1024) void k_mm_tilescan(uint32_t* __restrict__ tile_cnt, uint32_t nt,
+                                                      uint32_t* __restrict__ tile_off, uint32_t* __restrict__ m_dev,
+                                                      volatile uint32_t* __restrict__ m_host) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nt + 1023u) / 1024u;
+    const uint32_t lo = min(threadIdx.x * per, nt), hi = min(lo + per, nt);
+    uint32_t s = 0;
+    for (uint32_t t = lo; t < hi; t++) s += tile_cnt[t];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t t = lo; t < hi; t++) {
+        uint32_t v = tile_cnt[t];
+        tile_off[t] = run;
+        tile_cnt[t] = 0;
+        run += v;
+    }
+    if (threadIdx.x == 1023) { *m_dev = part[1023]; *m_host = part[1023]; }
+}
+
+// thread per chunk: movers before the chunk (M64) and the stable list of movers (new key, slot)
+__global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__ mask, uint32_t nchunks,
+                                                    const uint32_t* __restrict__ tile_off,
+                                                    const uint32_t* __restrict__ B, uint32_t* __restrict__ M64,
+                                                    uint32_t* __restrict__ mk, uint32_t* __restrict__ mi) {
+    __shared__ uint32_t part[256];
+    const uint32_t chunk = blockIdx.x * MM_TILE_CHUNKS + threadIdx.x;
+    uint64_t m = chunk < nchunks ? mask[chunk] : 0ull;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (chunk >= nchunks) return;
+    uint32_t at = tile_off[blockIdx.x] + part[threadIdx.x] - cnt;
+    M64[chunk] = at;
+    while (m) {
+        const uint32_t i = chunk * 64u + (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        mk[at] = B[i];
+        mi[at] = i;
+        at++;
+    }
+}
+
+// first r in [lo, hi) with (mk[r], mi[r]) >= (key, slot)
+__device__ __forceinline__ uint32_t mm_lower_bound(const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
+                                                   uint32_t lo, uint32_t hi, uint32_t key, uint32_t slot) {
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint32_t k = mk[mid];
+        const bool less = k < key || (k == key && mi[mid] < slot);
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// non-movers: one thread per slot.  The bracket [L0, L1] of a whole wave is found with wave-uniform
+// (scalar) searches; it is a single point unless a mover lands inside the wave's key span.
+__global__ __launch_bounds__(256) void k_mm_place(const uint32_t* __restrict__ A, uint32_t n,
+                                                  const uint64_t* __restrict__ mask, const uint32_t* __restrict__ M64,
+                                                  const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
+                                                  const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ ks,
+                                                  uint32_t* __restrict__ vs) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(i);          // slot of lane 0
+    if (first >= n) return;                                            // wave-uniform
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t chunk = first >> 6;
+    const uint32_t m = *m_dev;
+    const uint32_t last = min(first + 63u, n - 1u);
+    const uint32_t L0 = mm_lower_bound(mk, mi, 0u, m, A[first], first);
+    const uint32_t L1 = mm_lower_bound(mk, mi, L0, m, A[last], last);
+    if (i >= n) return;
+    const uint64_t bits = mask[chunk];
+    if ((bits >> lane) & 1ull) return;                                 // a mover: placed by k_mm_place_movers
+    const uint32_t key = A[i];
+    const uint32_t before = M64[chunk] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
+    const uint32_t L = L0 == L1 ? L0 : mm_lower_bound(mk, mi, L0, L1, key, i);
+    const uint32_t dst = i - before + L;
+    ks[dst] = key;
+    vs[dst] = i;
+}
+
+__global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restrict__ A, uint32_t n,
+                                                         const uint64_t* __restrict__ mask,
+                                                         const uint32_t* __restrict__ M64,
+                                                         const uint32_t* __restrict__ mk,
+                                                         const uint32_t* __restrict__ mi,
+                                                         const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ ks,
+                                                         uint32_t* __restrict__ vs) {
+    const uint32_t m = *m_dev;
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < m; r += gridDim.x * 256u) {
+        const uint32_t key = mk[r], slot = mi[r];
+        uint32_t lo = 0, hi = n;                       // s = first slot with A >= key
+        while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (A[mid] < key) lo = mid + 1; else hi = mid; }
+        const uint32_t s = lo;
+        hi = n;                                        // e = first slot with A > key
+        while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (A[mid] <= key) lo = mid + 1; else hi = mid; }
+        const uint32_t e = lo;
+        const uint32_t j = min(max(slot, s), e);       // non-movers of cell `key` below `slot` end here
+        uint32_t before = m;                           // movers among the slots [0, j)
+        if (j < n) before = M64[j >> 6] + (uint32_t)__popcll(mask[j >> 6] & ((1ull << (j & 63u)) - 1ull));
+        const uint32_t dst = r + (j - before);
+        ks[dst] = key;
+        vs[dst] = slot;
+    }
+}
+
+static uint32_t merge_grid_for(uint32_t movers_hint, uint32_t n) {
+    const uint32_t want = ceil_div(2u * movers_hint + 1u, SORT_TILE) + 15u;    // head-room: the hint is stale
+    return min(want, ceil_div(n, SORT_TILE));
+}
+
+static void mm_tilescan(sph_ctx* c, uint32_t n) {
+    const uint32_t nt = ceil_div(ceil_div(n, 64u), MM_TILE_CHUNKS);
+    hipLaunchKernelGGL(k_mm_tilescan, dim3(1), dim3(1024), 0, c->stream, c->mm_tile_cnt, nt, c->mm_tile_off, c->mm_count,
+                       c->mm_count_host_dev);
+}
+
+// forget the marks the integrate epilogue left (the scan re-zeroes the tile counts they added to)
+void mm_drop_marks(sph_ctx* c) {
+    if (!c->mm_marked) return;
+    mm_tilescan(c, c->mm_marked_n);
+    c->mm_marked = false;
+}
+
+// (ks, vs) of the stable sort by B, from the current order (sorted by A); see the block comment above
+static void launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t*& ks, uint32_t*& vs) {
+    const uint32_t* A = c->keyS + c->own_off;
+    const uint32_t* B = c->k0;
+    const uint32_t nchunks = ceil_div(n, 64u), nt = ceil_div(nchunks, MM_TILE_CHUNKS);
+    if (c->mm_marked && !(c->mm_marked_off == c->own_off && c->mm_marked_n == n)) mm_drop_marks(c);   // another range
+    if (!c->mm_marked)                           // else: the fused integrate epilogue compared the keys already
+        hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, A, B, n, c->mm_mask,
+                           c->mm_tile_cnt);
+    c->mm_marked = false;
+    mm_tilescan(c, n);
+    uint32_t* mk = c->mm_k0; uint32_t* mi = c->v0; uint32_t* mk2 = c->mm_k1; uint32_t* mi2 = c->mm_v1;
+    hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, c->mm_tile_off, B, c->mm_M64,
+                       mk, mi);
+    const uint32_t hint = *c->mm_count_host;                 // whatever step last reported: sizes the grid only
+    radix_sort_pairs(c, n, c->mm_count, merge_grid_for(hint, n), false, mk, mi, mk2, mi2);
+    ks = c->k1; vs = c->v1;
+    hipLaunchKernelGGL(k_mm_place, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, A, n, c->mm_mask, c->mm_M64, mk, mi,
+                       c->mm_count, ks, vs);
+    hipLaunchKernelGGL(k_mm_place_movers, dim3(min(ceil_div(2u * hint + 1u, 256u) + 15u, 65535u)), dim3(256), 0, c->stream,
+                       A, n, c->mm_mask, c->mm_M64, mk, mi, c->mm_count, ks, vs);
 }
 
 int launch_sort(sph_ctx* c) {
@@ -278,18 +510,24 @@ int launch_sort(sph_ctx* c) {
                 c->sort_blocks_cap);
     uint32_t* kin = c->k0; uint32_t* vin = c->v0;
     uint32_t* kout = c->k1; uint32_t* vout = c->v1;
-    // 9-bit digits when they save a pass over 8-bit ones (27 bits: 3 x 9), else 8-bit digits.  Measured
-    // per pass at 16.7 M keys: 124 us (8 bits), 150 us (9 bits), 220 us (10 bits: never worth it).
-    const uint32_t p8 = (c->key_bits + 7) / 8, p9 = (c->key_bits + 8) / 9;
-    const uint32_t bits = p9 < p8 ? 9u : 8u;
-    const uint32_t passes = bits == 9u ? p9 : p8;
-    for (uint32_t p = 0; p < passes; p++) {
-        const uint32_t shift = p * bits;
-        if (bits == 8) sort_pass<8>(c, n, nblocks, shift, p == 0, kin, vin, kout, vout);
-        else sort_pass<9>(c, n, nblocks, shift, p == 0, kin, vin, kout, vout);
-        uint32_t* t;
-        t = kin; kin = kout; kout = t;
-        t = vin; vin = vout; vout = t;
+    // The merge needs the order of the last sort to be intact; it is correct for any number of movers but
+    // only cheaper than the full sort while they are few (last known count: a hint, never a condition).
+    c->sort_calls++;
+    const bool can_merge = c->sort_merge && c->order_valid;
+    if (can_merge && *c->mm_count_host <= n / 8u) {
+        launch_sort_merge(c, n, kin, vin);
+        c->sort_merges++;
+    } else {
+        // keep the hint alive, or it would stay high for ever: for free when the integrate epilogue marked
+        // the movers (the scan also re-zeroes the tile counts those marks added to), else every 8th sort
+        if (c->mm_marked) {
+            mm_drop_marks(c);
+        } else if (can_merge && (c->sort_calls & 7u) == 0) {
+            hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, c->keyS + c->own_off, c->k0, n,
+                               c->mm_mask, c->mm_tile_cnt);
+            mm_tilescan(c, n);
+        }
+        radix_sort_pairs(c, n, nullptr, nblocks, true, kin, vin, kout, vout);
     }
     // (kin, vin) now hold the sorted pairs; gather the payload to the canonical offset gcap.  A
     // whole-domain context gets no ghosts later, so its cell table is built in the same pass.
@@ -308,6 +546,7 @@ int launch_sort(sph_ctx* c) {
     t4 = c->velr; c->velr = c->velr2; c->velr2 = t4;
     c->own_off = c->gcap;
     c->last_perm = vin;
+    c->order_valid = true;
     if (cells) { c->cells_lo = c->gcap; c->cells_hi = c->gcap + n; c->cells_valid = true; }
     return SPH_OK;
 }

@@ -177,6 +177,11 @@ int sph_timing_enable(sph_ctx* c, int on);
 /* sums of per-phase device milliseconds since the last reset, and the number of steps */
 int sph_timing_get(sph_ctx* c, float ms[SPH_PH_COUNT], uint32_t* n_steps);
 int sph_timing_reset(sph_ctx* c);
+/* sort statistics: sorts run so far, how many of them took the merge path (only the particles whose
+ * cell changed are sorted; same result as the full sort), and the mover count the device last
+ * reported (synchronises the stream).  SPH_SORT_MERGE=0 in the environment at sph_create time
+ * disables the merge path. */
+int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint32_t* last_movers);
 
 /* ---- z-slab halo / migration (multi-GPU; no counterpart in the reference) ---------------- */
 /* side: 0 = towards lower z (rank-1), 1 = towards higher z (rank+1).

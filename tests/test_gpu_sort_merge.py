@@ -1,0 +1,105 @@
+"""GPU: the sort's merge path (only the particles whose cell changed are sorted, sph_sort.hip:
+launch_sort_merge) must produce the SAME (key, slot) sequence as the full stable radix sort -- element
+for element, for any number of movers -- so every later array is bit-identical too.
+
+Two contexts run the same input, one created with SPH_SORT_MERGE=0 (always the full sort), one with the
+merge path; keys, permutation and state are compared exactly after every step."""
+import os
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  -- before libsph_hip.so is loaded: one HIP runtime per process (capi.load)
+
+from gpufluidsimulator_amd import capi, ic
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(n, box, grid, merge):
+    old = os.environ.get("SPH_SORT_MERGE")
+    os.environ["SPH_SORT_MERGE"] = "1" if merge else "0"        # read once, by sph_create
+    try:
+        return capi.Context(n, box=box, grid=grid)
+    finally:
+        if old is None:
+            del os.environ["SPH_SORT_MERGE"]
+        else:
+            os.environ["SPH_SORT_MERGE"] = old
+
+
+def _lockstep(pos, vel, box, grid, dt, steps, fused):
+    n = pos.shape[0]
+    a, b = _ctx(n, box, grid, False), _ctx(n, box, grid, True)
+    movers = []
+    try:
+        for c in (a, b):
+            c.upload(pos, vel)
+        for s in range(steps):
+            for c in (a, b):
+                if fused:
+                    c.step(dt, 1)
+                else:
+                    c.step_phased(dt, 1)
+            ka, kb = a.keys(), b.keys()
+            assert np.array_equal(ka, kb), f"step {s}: sorted keys differ"
+            assert np.all(np.diff(ka.astype(np.int64)) >= 0)
+            assert np.array_equal(a.order(), b.order()), f"step {s}: permutation differs"
+            movers.append(b.sort_stats()["last_movers"])
+        sa, sb = a.download(), b.download()
+        for k in ("pos", "vel", "density", "pressure"):
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+        st_a, st_b = a.sort_stats(), b.sort_stats()
+        assert st_a["merges"] == 0 and st_a["sorts"] == steps
+        assert st_b["sorts"] == steps
+        return st_b, movers
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_few_movers_dam_break(fused):
+    cfg = ic.CONFIGS["C1"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
+    rng = np.random.default_rng(5)
+    vel = rng.uniform(-60, 60, pos.shape).astype(np.float32)       # a few particles cross a cell face per step
+    st, movers = _lockstep(pos, vel, cfg["box"], cfg["grid"], 4e-5, 16, fused)
+    assert st["merges"] == 15                                       # every sort but the first
+    assert 0 < max(movers) < pos.shape[0] // 8
+
+
+def test_many_movers_and_the_fallback():
+    """Half of the particles change cell every step: the merge is still exact (its grids loop), and once
+    the device has reported the count the full sort takes over (the hint is refreshed every 8th sort)."""
+    box, grid = (2.0, 2.0, 2.0), (32, 32, 32)
+    pos, vel = ic.random_box(20000, box, speed=60.0, fill=0.45)
+    st, movers = _lockstep(pos, vel, box, grid, 5e-4, 20, True)
+    assert max(movers) > pos.shape[0] // 8
+    assert 1 <= st["merges"] < 19
+
+
+def test_clump_and_empty_cells():
+    """Movers into cells that were empty, out of cells that become empty, and a cell holding 150 particles."""
+    box, grid, n = (2.0, 2.0, 2.0), (32, 32, 32), 6000
+    pos, vel = ic.random_box(n, box, speed=40.0, fill=0.45)
+    rng = np.random.default_rng(7)
+    pos[:150] = (np.float32([-0.5, -0.5, -0.5]) + rng.uniform(0.002, 0.060, (150, 3))).astype(np.float32)
+    vel[:150] = rng.uniform(-300, 300, (150, 3)).astype(np.float32)      # the clump bursts
+    st, movers = _lockstep(pos, vel, box, grid, 2e-5, 25, True)
+    assert st["merges"] >= 20 and max(movers) > 0
+
+
+def test_no_movers_at_all():
+    cfg = ic.CONFIGS["C1"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=False)
+    st, movers = _lockstep(pos, vel, cfg["box"], cfg["grid"], 5e-7, 3, True)
+    assert movers == [0, 0, 0] or max(movers) < 8
+    assert st["merges"] == 2
+
+
+def test_c2_size_fused_matches_full_sort():
+    cfg = ic.CONFIGS["C2"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
+    rng = np.random.default_rng(11)
+    vel = rng.uniform(-60, 60, pos.shape).astype(np.float32)
+    st, movers = _lockstep(pos, vel, cfg["box"], cfg["grid"], 4e-5, 10, True)
+    assert st["merges"] == 9 and max(movers) > 100
