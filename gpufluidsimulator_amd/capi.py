@@ -280,6 +280,12 @@ class Context:
         m = min(m, max_cells)
         return k[:m], s[:m], c[:m]
 
+    def cell_range(self, cell):
+        """(start, end) of one cell of the table, relative to the first installed slot; (0, 0) = empty."""
+        a, b = _U32(), _U32()
+        _check(self.L.sph_get_cell_range(self.h, int(cell), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def cell_key(self, x, y, z):
         return int(self.L.sph_cell_key(self.h, int(x), int(y), int(z)))
 

@@ -237,7 +237,12 @@ static void timing_collect(sph_ctx* c) {
 // ---- phase bodies ------------------------------------------------------------------------------------------
 static int do_hash(sph_ctx* c) {
     PhaseTimer t(c, SPH_PH_ZINDEX);
-    int rc = launch_cells_clear(c);      // the table of the previous step dies with its keys
+    // the table of the previous step dies with its keys -- unless the sort is going to merge: then only the
+    // cells the movers leave can become empty, and the sort clears just those (whole-domain contexts, whose
+    // table is rebuilt by the sort's reorder pass over exactly the same slots)
+    c->cells_clear_deferred = !c->slab && c->sort_merge && c->order_valid && c->cells_valid &&
+                              c->cells_lo == c->own_off && c->cells_hi == c->own_off + c->n;
+    int rc = c->cells_clear_deferred ? SPH_OK : launch_cells_clear(c);
     if (rc) return rc;
     rc = launch_hash(c);
     if (rc) return rc;

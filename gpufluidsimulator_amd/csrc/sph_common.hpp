@@ -82,6 +82,7 @@ struct sph_ctx {
     uint2* cells = nullptr;
     uint32_t cells_lo = 0, cells_hi = 0;   // slot range the table was built from
     bool cells_valid = false;
+    bool cells_clear_deferred = false;   // sph_hash left the clearing of the old table to the sort (merge path)
     bool keys_fresh = false;   // k0 already holds the keys of the current positions (written by the integrate epilogue)
 
     // radix sort scratch

@@ -371,8 +371,9 @@ __global__ __launch_bounds__(1024) void k_mm_tilescan(uint32_t* __restrict__ til
 // thread per chunk: movers before the chunk (M64) and the stable list of movers (new key, slot)
 __global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__ mask, uint32_t nchunks,
                                                     const uint32_t* __restrict__ tile_off,
-                                                    const uint32_t* __restrict__ B, uint32_t* __restrict__ M64,
-                                                    uint32_t* __restrict__ mk, uint32_t* __restrict__ mi) {
+                                                    const uint32_t* __restrict__ A, const uint32_t* __restrict__ B,
+                                                    uint32_t* __restrict__ M64, uint32_t* __restrict__ mk,
+                                                    uint32_t* __restrict__ mi, uint2* __restrict__ cells) {
     __shared__ uint32_t part[256];
     const uint32_t chunk = blockIdx.x * MM_TILE_CHUNKS + threadIdx.x;
     uint64_t m = chunk < nchunks ? mask[chunk] : 0ull;
@@ -394,6 +395,9 @@ __global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__
         mk[at] = B[i];
         mi[at] = i;
         at++;
+        // only a cell a mover left can have become empty: clear those, the reorder pass rewrites every
+        // cell that is still occupied (replaces the walk over all old keys, k_cells_clear)
+        if (cells) cells[A[i]] = make_uint2(0u, 0u);
     }
 }
 
@@ -480,7 +484,7 @@ void mm_drop_marks(sph_ctx* c) {
 }
 
 // (ks, vs) of the stable sort by B, from the current order (sorted by A); see the block comment above
-static void launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t*& ks, uint32_t*& vs) {
+static void launch_sort_merge(sph_ctx* c, uint32_t n, bool table_live, uint32_t*& ks, uint32_t*& vs) {
     const uint32_t* A = c->keyS + c->own_off;
     const uint32_t* B = c->k0;
     const uint32_t nchunks = ceil_div(n, 64u), nt = ceil_div(nchunks, MM_TILE_CHUNKS);
@@ -491,8 +495,8 @@ static void launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t*& ks, uint32_t*& 
     c->mm_marked = false;
     mm_tilescan(c, n);
     uint32_t* mk = c->mm_k0; uint32_t* mi = c->v0; uint32_t* mk2 = c->mm_k1; uint32_t* mi2 = c->mm_v1;
-    hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, c->mm_tile_off, B, c->mm_M64,
-                       mk, mi);
+    hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, c->mm_tile_off, A, B,
+                       c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr);
     const uint32_t hint = *c->mm_count_host;                 // whatever step last reported: sizes the grid only
     radix_sort_pairs(c, n, c->mm_count, merge_grid_for(hint, n), false, mk, mi, mk2, mi2);
     ks = c->k1; vs = c->v1;
@@ -514,10 +518,18 @@ int launch_sort(sph_ctx* c) {
     // only cheaper than the full sort while they are few (last known count: a hint, never a condition).
     c->sort_calls++;
     const bool can_merge = c->sort_merge && c->order_valid;
+    // whole-domain contexts: sph_hash left the old cell table in place (cells_clear_deferred) when this
+    // sort could take the merge path, which clears only the cells the movers left
+    const bool table_live = c->cells_clear_deferred && c->cells_valid;
+    c->cells_clear_deferred = false;
     if (can_merge && *c->mm_count_host <= n / 8u) {
-        launch_sort_merge(c, n, kin, vin);
+        launch_sort_merge(c, n, table_live, kin, vin);
         c->sort_merges++;
     } else {
+        if (table_live) {
+            int rc = launch_cells_clear(c);
+            if (rc) return rc;
+        }
         // keep the hint alive, or it would stay high for ever: for free when the integrate epilogue marked
         // the movers (the scan also re-zeroes the tile counts those marks added to), else every 8th sort
         if (c->mm_marked) {

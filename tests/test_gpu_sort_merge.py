@@ -27,7 +27,7 @@ def _ctx(n, box, grid, merge):
             os.environ["SPH_SORT_MERGE"] = old
 
 
-def _lockstep(pos, vel, box, grid, dt, steps, fused):
+def _lockstep(pos, vel, box, grid, dt, steps, fused, full_table=False):
     n = pos.shape[0]
     a, b = _ctx(n, box, grid, False), _ctx(n, box, grid, True)
     movers = []
@@ -45,6 +45,12 @@ def _lockstep(pos, vel, box, grid, dt, steps, fused):
             assert np.all(np.diff(ka.astype(np.int64)) >= 0)
             assert np.array_equal(a.order(), b.order()), f"step {s}: permutation differs"
             movers.append(b.sort_stats()["last_movers"])
+        if full_table:                     # every cell of the table, the empty ones included
+            ncells = int(np.prod(grid))
+            ta = [a.cell_range(k) for k in range(ncells)]
+            assert ta == [b.cell_range(k) for k in range(ncells)]
+            occupied = set(int(k) for k in ka)
+            assert all((r == (0, 0)) == (k not in occupied) for k, r in enumerate(ta))
         sa, sb = a.download(), b.download()
         for k in ("pos", "vel", "density", "pressure"):
             assert np.array_equal(sa[k], sb[k], equal_nan=True), k
@@ -84,7 +90,7 @@ def test_clump_and_empty_cells():
     rng = np.random.default_rng(7)
     pos[:150] = (np.float32([-0.5, -0.5, -0.5]) + rng.uniform(0.002, 0.060, (150, 3))).astype(np.float32)
     vel[:150] = rng.uniform(-300, 300, (150, 3)).astype(np.float32)      # the clump bursts
-    st, movers = _lockstep(pos, vel, box, grid, 2e-5, 25, True)
+    st, movers = _lockstep(pos, vel, box, grid, 2e-5, 25, True, full_table=True)
     assert st["merges"] >= 20 and max(movers) > 0
 
 
