@@ -266,9 +266,7 @@ static int do_cells(sph_ctx* c) {
     PhaseTimer t(c, SPH_PH_BGRID);
     const uint32_t lo = c->own_off - c->n_glo, hi = c->own_off + c->n + c->n_ghi;
     if (!(c->cells_valid && c->cells_lo == lo && c->cells_hi == hi)) {   // whole-domain: built by the sort's reorder pass
-        int rc = launch_cells_clear(c);      // a table over the old ghost set, if any
-        if (rc) return rc;
-        rc = launch_cells_build(c);
+        int rc = launch_cells_build(c);      // slab: adds the ghost cells to the owned ones the sort built
         if (rc) return rc;
     }
     c->stage = sph_ctx::ST_CELLS;

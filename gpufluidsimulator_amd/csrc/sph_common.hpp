@@ -147,6 +147,7 @@ int launch_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, cons
                          uint32_t count);
 int launch_sort(sph_ctx* c);          // radix sort of (k0,v0)[0,n) + reorder into posi2/velr2/keyS
 int launch_cells_clear(sph_ctx* c);
+int launch_cells_clear_range(sph_ctx* c, uint32_t lo, uint32_t hi);
 int launch_cells_build(sph_ctx* c);
 int launch_density(sph_ctx* c);
 int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt);

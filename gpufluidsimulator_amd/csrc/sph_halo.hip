@@ -108,6 +108,15 @@ int sph_migrants_pack(sph_ctx* c, void* buf_dev[2], uint32_t capacity) {
     rc = pack_slice(c, c->own_off, m[0], buf_dev[0], capacity);
     if (!rc) rc = pack_slice(c, c->own_off + c->n - m[1], m[1], buf_dev[1], capacity);
     if (rc) return rc;
+    if (c->cells_valid && c->cells_lo == c->own_off && c->cells_hi == c->own_off + c->n) {
+        // the sort built the table over all owned slots: drop the cells of the particles that leave (they sit in
+        // the two ghost layers, which hold nothing else until the ghosts are installed)
+        rc = launch_cells_clear_range(c, c->own_off, c->own_off + m[0]);
+        if (!rc) rc = launch_cells_clear_range(c, c->own_off + c->n - m[1], c->own_off + c->n);
+        if (rc) return rc;
+        c->cells_lo += m[0];
+        c->cells_hi -= m[1];
+    }
     c->own_off += m[0];
     c->n -= m[0] + m[1];
     return SPH_OK;
@@ -170,8 +179,10 @@ int sph_halo_unpack(sph_ctx* c, const void* lo_dev, uint32_t n_lo, const void* h
     SPH_REQUIRE(n_lo <= c->own_off && c->own_off + c->n + n_hi <= c->tot && n_lo <= c->gcap && n_hi <= c->gcap,
                 SPH_E_CAPACITY, "ghost layers of %u / %u records exceed the ghost capacity %u", n_lo, n_hi, c->gcap);
     SPH_HIP(hipSetDevice(c->device));
-    int rc = launch_cells_clear(c);   // the installed table (if any) refers to the old ghosts
-    if (rc) return rc;
+    if (!(c->cells_valid && c->cells_lo == c->own_off && c->cells_hi == c->own_off + c->n)) {
+        int rc = launch_cells_clear(c);   // a table that includes old ghosts; one over just the owned slots is kept
+        if (rc) return rc;
+    }
     if (n_lo) {
         SPH_REQUIRE(lo_dev, SPH_E_INVALID, "null buffer");
         const uint32_t at = c->own_off - n_lo;

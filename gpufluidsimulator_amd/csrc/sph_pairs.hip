@@ -60,12 +60,35 @@ int launch_cells_clear(sph_ctx* c) {
     return SPH_OK;
 }
 
-int launch_cells_build(sph_ctx* c) {
-    uint32_t lo = c->own_off - c->n_glo, hi = c->own_off + c->n + c->n_ghi;
-    c->cells_lo = lo; c->cells_hi = hi; c->cells_valid = true;
+// clear / build the table entries of the cells that occur in the slot range [lo, hi) (no bookkeeping)
+int launch_cells_clear_range(sph_ctx* c, uint32_t lo, uint32_t hi) {
+    if (hi <= lo) return SPH_OK;
+    hipLaunchKernelGGL(k_cells_clear, dim3(ceil_div(hi - lo, 256)), dim3(256), 0, c->stream, c->keyS, lo, hi, c->cells);
+    SPH_HIP(hipGetLastError());
+    return SPH_OK;
+}
+
+int launch_cells_build_range(sph_ctx* c, uint32_t lo, uint32_t hi) {
     if (hi <= lo) return SPH_OK;
     hipLaunchKernelGGL(k_cells_build, dim3(ceil_div(hi - lo, 256)), dim3(256), 0, c->stream, c->keyS, lo, hi, c->cells);
     SPH_HIP(hipGetLastError());
+    return SPH_OK;
+}
+
+int launch_cells_build(sph_ctx* c) {
+    const uint32_t lo = c->own_off - c->n_glo, hi = c->own_off + c->n + c->n_ghi;
+    int rc;
+    if (c->cells_valid && c->cells_lo == c->own_off && c->cells_hi == c->own_off + c->n) {
+        // the sort's reorder pass built the owned cells; ghost layers hold no owned particle, so their
+        // cells are disjoint from those: add them from the two ghost ranges only
+        rc = launch_cells_build_range(c, lo, c->own_off);
+        if (!rc) rc = launch_cells_build_range(c, c->own_off + c->n, hi);
+    } else {
+        rc = launch_cells_clear(c);      // a table over another slot set, if any
+        if (!rc) rc = launch_cells_build_range(c, lo, hi);
+    }
+    if (rc) return rc;
+    c->cells_lo = lo; c->cells_hi = hi; c->cells_valid = true;
     return SPH_OK;
 }
 

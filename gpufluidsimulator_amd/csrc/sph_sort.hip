@@ -522,9 +522,11 @@ int launch_sort(sph_ctx* c) {
     // sort could take the merge path, which clears only the cells the movers left
     const bool table_live = c->cells_clear_deferred && c->cells_valid;
     c->cells_clear_deferred = false;
+    bool table_kept = false;               // the merge path keeps the live table and clears it sparsely
     if (can_merge && *c->mm_count_host <= n / 8u) {
         launch_sort_merge(c, n, table_live, kin, vin);
         c->sort_merges++;
+        table_kept = table_live;
     } else {
         if (table_live) {
             int rc = launch_cells_clear(c);
@@ -541,17 +543,16 @@ int launch_sort(sph_ctx* c) {
         }
         radix_sort_pairs(c, n, nullptr, nblocks, true, kin, vin, kout, vout);
     }
-    // (kin, vin) now hold the sorted pairs; gather the payload to the canonical offset gcap.  A
-    // whole-domain context gets no ghosts later, so its cell table is built in the same pass.
-    const bool cells = !c->slab;
-    if (cells)
-        hipLaunchKernelGGL(k_reorder<true>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, kin, vin, n,
-                           c->posi + c->own_off, c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap,
-                           c->keyS + c->gcap, c->cells, c->gcap);
-    else
-        hipLaunchKernelGGL(k_reorder<false>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, kin, vin, n,
-                           c->posi + c->own_off, c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap,
-                           c->keyS + c->gcap, c->cells, c->gcap);
+    // (kin, vin) now hold the sorted pairs; gather the payload to the canonical offset gcap and write the cell
+    // table of the owned slots in the same pass.  A slab context adds the cells of its ghost layers later
+    // (launch_cells_build), and drops those of the particles that leave (sph_migrants_pack).
+    if (c->cells_valid && !table_kept) {   // a table nobody cleared (e.g. sph_sort without sph_hash): start clean
+        int rc = launch_cells_clear(c);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_reorder<true>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, kin, vin, n,
+                       c->posi + c->own_off, c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap,
+                       c->keyS + c->gcap, c->cells, c->gcap);
     SPH_HIP(hipGetLastError());
     float4* t4;
     t4 = c->posi; c->posi = c->posi2; c->posi2 = t4;
@@ -559,7 +560,7 @@ int launch_sort(sph_ctx* c) {
     c->own_off = c->gcap;
     c->last_perm = vin;
     c->order_valid = true;
-    if (cells) { c->cells_lo = c->gcap; c->cells_hi = c->gcap + n; c->cells_valid = true; }
+    c->cells_lo = c->gcap; c->cells_hi = c->gcap + n; c->cells_valid = true;
     return SPH_OK;
 }
 
