@@ -238,11 +238,18 @@ static void timing_collect(sph_ctx* c) {
 static int do_hash(sph_ctx* c) {
     PhaseTimer t(c, SPH_PH_ZINDEX);
     // the table of the previous step dies with its keys -- unless the sort is going to merge: then only the
-    // cells the movers leave can become empty, and the sort clears just those (whole-domain contexts, whose
-    // table is rebuilt by the sort's reorder pass over exactly the same slots)
-    c->cells_clear_deferred = !c->slab && c->sort_merge && c->order_valid && c->cells_valid &&
-                              c->cells_lo == c->own_off && c->cells_hi == c->own_off + c->n;
-    int rc = c->cells_clear_deferred ? SPH_OK : launch_cells_clear(c);
+    // cells the movers leave can become empty, and the sort clears just those (the table is rebuilt by the
+    // sort's reorder pass over exactly the same owned slots).  The cells of a slab's old ghosts die here.
+    const uint32_t lo = c->own_off - c->n_glo, hi = c->own_off + c->n + c->n_ghi;
+    c->cells_clear_deferred = c->sort_merge && c->order_valid && c->cells_valid && c->cells_lo == lo && c->cells_hi == hi;
+    int rc;
+    if (c->cells_clear_deferred) {
+        rc = launch_cells_clear_range(c, lo, c->own_off);
+        if (!rc) rc = launch_cells_clear_range(c, c->own_off + c->n, hi);
+        c->cells_lo = c->own_off; c->cells_hi = c->own_off + c->n;
+    } else {
+        rc = launch_cells_clear(c);
+    }
     if (rc) return rc;
     rc = launch_hash(c);
     if (rc) return rc;
