@@ -100,7 +100,7 @@ static int dev_alloc(T** p, size_t count) {
 
 static void free_all(sph_ctx* c) {
     hipFree(c->posi); hipFree(c->velr); hipFree(c->posi2); hipFree(c->velr2); hipFree(c->keyS); hipFree(c->dp);
-    hipFree(c->fpress); hipFree(c->fvisc); hipFree(c->dvel); hipFree(c->pos_out); hipFree(c->cells);
+    hipFree(c->fpress); hipFree(c->fvisc); hipFree(c->dvel); hipFree(c->pos_out); hipFree(c->cells_base);
     hipFree(c->k0); hipFree(c->v0); hipFree(c->k1); hipFree(c->v1); hipFree(c->hist); hipFree(c->digit_tot);
     hipFree(c->d_scratch);
     hipFree(c->mm_mask); hipFree(c->mm_M64); hipFree(c->mm_tile_cnt); hipFree(c->mm_tile_off);
@@ -149,7 +149,9 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (!rc) rc = dev_alloc(&c->fvisc, tot);
     if (!rc) rc = dev_alloc(&c->dvel, tot);
     if (!rc) rc = dev_alloc(&c->pos_out, (size_t)c->pos_out_cap);
-    if (!rc) rc = dev_alloc(&c->cells, (size_t)c->grid.ncells);
+    // one guard entry on either side: the pair kernels read cells[key - 1 .. key + 1] of a row unconditionally
+    if (!rc) rc = dev_alloc(&c->cells_base, (size_t)c->grid.ncells + 2);
+    if (!rc) c->cells = c->cells_base + 1;
     if (!rc) rc = dev_alloc(&c->k0, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->v0, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->k1, (size_t)capacity);
@@ -187,7 +189,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
             }
         }
     }
-    if (!rc && hipMemset(c->cells, 0, (size_t)c->grid.ncells * sizeof(uint2)) != hipSuccess) {
+    if (!rc && hipMemset(c->cells_base, 0, ((size_t)c->grid.ncells + 2) * sizeof(uint2)) != hipSuccess) {
         set_error("hipMemset(cells) failed");
         rc = SPH_E_DEVICE;
     }

@@ -79,7 +79,8 @@ struct sph_ctx {
     uint32_t pos_out_cap = 0;
 
     // cell table: {start, end} per local cell, zero = empty
-    uint2* cells = nullptr;
+    uint2* cells = nullptr;        // = cells_base + 1
+    uint2* cells_base = nullptr;   // the allocation: ncells + one zero guard entry on either side
     uint32_t cells_lo = 0, cells_hi = 0;   // slot range the table was built from
     bool cells_valid = false;
     bool cells_clear_deferred = false;   // sph_hash left the clearing of the old table to the sort (merge path)

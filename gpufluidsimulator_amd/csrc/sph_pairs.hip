@@ -97,21 +97,14 @@ struct Rows {
     uint32_t lo[9], hi[9];
 };
 
-// first non-empty start / last non-empty end of up to three consecutive cells of one row
-__device__ __forceinline__ void row_range(const uint2* __restrict__ cells, uint32_t rowbase, uint32_t cx, uint32_t gx,
-                                          bool rowvalid, uint32_t& lo, uint32_t& hi) {
-    uint2 a = make_uint2(0u, 0u), b = a, d = a;
-    if (rowvalid) {
-        if (cx > 0) a = cells[rowbase + cx - 1];
-        b = cells[rowbase + cx];
-        if (cx + 1 < gx) d = cells[rowbase + cx + 1];
-    }
-    lo = a.y > a.x ? a.x : (b.y > b.x ? b.x : d.x);
-    hi = d.y > d.x ? d.y : (b.y > b.x ? b.y : a.y);
-}
-
 // rows in (dz, dy) order, cells of a row in dx order, particles of a cell in slot order: the
 // candidate order of one particle is fixed, so its fp32 sums are reproducible run to run.
+//
+// Branch-free: all 27 table entries are requested before any is used.  The three cells of a row are
+// cells[k-1], cells[k], cells[k+1] with k = key + (dz*gy + dy)*gx -- one address, three immediate offsets;
+// the table has a zero guard entry on either side, so the reads are in bounds for every key, and whatever
+// lies outside the grid (cx-1 < 0, cx+1 >= gx, a row beyond the y/z faces, an idle lane) is masked after
+// the loads.  A row beyond a face reads the particle's own row instead (any valid address will do).
 __device__ __forceinline__ void lane_rows(const uint2* __restrict__ cells, const GridDesc& g, uint32_t key, bool active,
                                           Rows& R) {
     const uint32_t gx = g.g[0], gy = g.g[1];
@@ -127,17 +120,29 @@ __device__ __forceinline__ void lane_rows(const uint2* __restrict__ cells, const
         cy = t % gy;
         lz = t / gy;
     }
+    const bool has_l = cx > 0u, has_r = cx + 1u < gx;
+    const bool y_ok[3] = {cy > 0u, true, cy + 1u < gy};
+    const bool z_ok[3] = {lz > 0u, true, lz + 1u < g.zl};
+    const int sy_ = (int)gx, sz_ = (int)(gx * gy);       // wave-uniform strides
+    uint2 a[9], b[9], d[9];
+    bool ok[9];
 #pragma unroll
     for (int dz = -1; dz <= 1; dz++) {
 #pragma unroll
         for (int dy = -1; dy <= 1; dy++) {
             const int r = (dz + 1) * 3 + (dy + 1);
-            int ny = (int)cy + dy;
-            int nz = (int)lz + dz;
-            bool ok = active && ny >= 0 && ny < (int)gy && nz >= 0 && nz < (int)g.zl;
-            uint32_t rowbase = ((uint32_t)nz * gy + (uint32_t)ny) * gx;
-            row_range(cells, ok ? rowbase : 0u, cx, gx, ok, R.lo[r], R.hi[r]);
+            ok[r] = active && y_ok[dy + 1] && z_ok[dz + 1];
+            const uint2* p = cells + (ok[r] ? (int)key + dz * sz_ + dy * sy_ : (int)key);
+            a[r] = p[-1]; b[r] = p[0]; d[r] = p[1];
         }
+    }
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const bool na = ok[r] && has_l && a[r].y > a[r].x, nb = ok[r] && b[r].y > b[r].x,
+                   nd = ok[r] && has_r && d[r].y > d[r].x;
+        // first non-empty start / last non-empty end; all empty -> lo = hi = 0
+        R.lo[r] = na ? a[r].x : (nb ? b[r].x : (nd ? d[r].x : 0u));
+        R.hi[r] = nd ? d[r].y : (nb ? b[r].y : (na ? a[r].y : 0u));
     }
 }
 
