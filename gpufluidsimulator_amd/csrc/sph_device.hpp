@@ -33,6 +33,24 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
 
+// min and max of one value over the wave.  The per-lane range lengths these are used on are equal in
+// all 64 lanes more often than not (every cell of a resting lattice holds the same count), and that
+// case costs a readfirstlane, a compare and a scalar test instead of two 7-step DPP reductions.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v);
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v);
+__device__ __forceinline__ void wave_min_max_u32(uint32_t v, uint32_t& vmin, uint32_t& vmax) {
+    const uint32_t v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    if (__ballot(v != v0) == 0ull) { vmin = v0; vmax = v0; return; }     // wave-uniform branch
+    vmin = wave_min_u32(v);
+    vmax = wave_max_u32(v);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32_uniform_first(uint32_t v) {
+    const uint32_t v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    if (__ballot(v != v0) == 0ull) return v0;                             // wave-uniform branch
+    return wave_min_u32(v);
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     v = min(v, dpp_u32<0xB1>(0xFFFFFFFFu, v));        // quad_perm [1,0,3,2]
     v = min(v, dpp_u32<0x4E>(0xFFFFFFFFu, v));        // quad_perm [2,3,0,1]

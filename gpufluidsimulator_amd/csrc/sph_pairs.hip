@@ -263,7 +263,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
             const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
             uint32_t idx = slice + (len ? l0 - a : 0u);
             // every lane has at least tmin candidates: that part of the walk needs no per-lane range test
-            const uint32_t tmin = wave_min_u32(len) & ~(uint32_t)(UNROLL - 1);
+            const uint32_t tmin = wave_min_u32_uniform_first(len) & ~(uint32_t)(UNROLL - 1);
             auto pair = [&](int u, bool valid) {
                 const v2f xy = ((lds_v2f_ptr)s_xy)[idx + u];
                 const float z = ((lds_f32_ptr)s_z)[idx + u];
@@ -404,13 +404,14 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
         [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
             const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
-            const uint32_t T = wave_max_u32(len);      // a known trip count lets hipcc interleave two candidates
+            uint32_t T, tmin_raw;                       // a known trip count lets hipcc interleave two candidates
+            wave_min_max_u32(len, tmin_raw, T);
             uint32_t idx = slice + (len ? l0 - a : 0u);
             // Candidates are walked in chunks of 32.  The pressure/viscosity arithmetic runs for every
             // candidate; the collision test only records "d <= 2R" in a per-lane bit mask (2 VALU per
             // candidate) and the few close pairs (~4 of ~216 per particle) are worked off after the chunk.
             // every lane has at least tmin candidates: that part of the walk needs no per-lane range test
-            const uint32_t tmin = wave_min_u32(len) & ~(uint32_t)(SPH_FORCE_UNROLL - 1);
+            const uint32_t tmin = tmin_raw & ~(uint32_t)(SPH_FORCE_UNROLL - 1);
             uint32_t near = 0u;
             auto pair = [&](int u, bool valid) {
                 const lds_v2f_ptr e = (lds_v2f_ptr)s_e + (idx + u) * 5;
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                             const uint32_t hb = 31u - (uint32_t)__clz((int)near);
                             near &= ~(1u << hb);
                             const uint32_t ci = idx0 + (done - 1u - hb);
-                            const float2* e = &s_e[ci * 5];
+                            const float2* e = &s_e[(ci << 2) + ci];          // ci * 5 without v_mul_lo_u32
                             const float2 qa = e[0], qb = e[1], qc = e[2];
                             const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
                             const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;
