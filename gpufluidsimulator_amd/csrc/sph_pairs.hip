@@ -25,7 +25,7 @@ constexpr int PIECE = 128;          // staged candidates per piece (2 coalesced 
 // The candidate walks read LDS through volatile LDS-address-space pointers: each read then stays ONE
 // ds_read_b64 / ds_read_b32 (2 LDS cycles per wave) with its own immediate offset.  Left alone, hipcc fuses
 // neighbouring reads into ds_read2_b64 / ds_read2_b32, which take 8 / 4 cycles -- half the rate per byte
-// (MI355X_MICROARCH.md, LDS table) -- and that made the LDS pipe, not the VALU, the limit of both pair kernels.
+// (MI355X_MICROARCH.md, LDS table) -- and that kept the LDS pipe 69 % busy (40 % with single reads).
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
 typedef const volatile __attribute__((address_space(3))) float* lds_f32_ptr;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void lane_rows(const uint2* __restrict__ cells, const
 #define SPH_DENS_OCC 6      // waves per SIMD asked of the register allocator (<= 80 VGPRs)
 #endif
 #ifndef SPH_FORCE_OCC
-#define SPH_FORCE_OCC 5     // <= 96 VGPRs: 5 dwords/lane spill outside the candidate loop, still 3-4 % faster than 4 waves
+#define SPH_FORCE_OCC 5     // <= 96 VGPRs (95 used, no spill); 4, 5 and 6 waves time within 2 % of each other
 #endif
 
 __device__ __forceinline__ float inv_sqrt(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
