@@ -106,6 +106,7 @@ static void free_all(sph_ctx* c) {
     hipFree(c->mm_mask); hipFree(c->mm_M64); hipFree(c->mm_tile_cnt); hipFree(c->mm_tile_off);
     hipFree(c->mm_k0); hipFree(c->mm_k1); hipFree(c->mm_v1); hipFree(c->mm_count);
     if (c->mm_count_host) hipHostFree(c->mm_count_host);
+    for (hipEvent_t e : c->mm_done) if (e) hipEventDestroy(e);
     if (c->h_scratch) hipHostFree(c->h_scratch);
 }
 
@@ -180,6 +181,11 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
             set_error("hipHostMalloc(mapped) failed");
             rc = SPH_E_NOMEM;
         }
+        for (int k = 0; k < 4 && !rc; k++)
+            if (hipEventCreateWithFlags(&c->mm_done[k], hipEventDisableTiming) != hipSuccess) {
+                set_error("hipEventCreate failed");
+                rc = SPH_E_DEVICE;
+            }
         if (!rc) {
             *c->mm_count_host = 0;
             if (hipMemset(c->mm_tile_cnt, 0, ntiles * sizeof(uint32_t)) != hipSuccess ||

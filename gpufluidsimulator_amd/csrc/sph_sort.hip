@@ -516,6 +516,11 @@ int launch_sort(sph_ctx* c) {
     uint32_t* kout = c->k1; uint32_t* vout = c->v1;
     // The merge needs the order of the last sort to be intact; it is correct for any number of movers but
     // only cheaper than the full sort while they are few (last known count: a hint, never a condition).
+    // The mover count the host reads below is whatever the device last reported.  A caller that queues many
+    // steps without synchronising would decide all of them on one stale value, so the host never runs more
+    // than four sorts ahead of the device (the queue stays several steps deep: the device never waits).
+    const uint32_t ring = (uint32_t)(c->sort_calls & 3u);
+    if (c->sort_merge && c->sort_calls >= 4) SPH_HIP(hipEventSynchronize(c->mm_done[ring]));
     c->sort_calls++;
     const bool can_merge = c->sort_merge && c->order_valid;
     // whole-domain contexts: sph_hash left the old cell table in place (cells_clear_deferred) when this
@@ -554,6 +559,7 @@ int launch_sort(sph_ctx* c) {
                        c->posi + c->own_off, c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap,
                        c->keyS + c->gcap, c->cells, c->gcap);
     SPH_HIP(hipGetLastError());
+    if (c->sort_merge) SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
     float4* t4;
     t4 = c->posi; c->posi = c->posi2; c->posi2 = t4;
     t4 = c->velr; c->velr = c->velr2; c->velr2 = t4;

@@ -109,3 +109,34 @@ def test_c2_size_fused_matches_full_sort():
     vel = rng.uniform(-60, 60, pos.shape).astype(np.float32)
     st, movers = _lockstep(pos, vel, cfg["box"], cfg["grid"], 4e-5, 10, True)
     assert st["merges"] == 9 and max(movers) > 100
+
+
+def test_mode_transitions_over_a_long_run():
+    """Calm -> violent -> calm: the sort goes merge -> full (hint above N/8) -> merge again (the integrate
+    epilogue keeps reporting the mover count while the full sort runs; steps are queued many at a time, the
+    host stays at most four sorts ahead of the device), and the state stays bit-identical to the always-full-sort run."""
+    cfg = ic.CONFIGS["C2"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
+    rng = np.random.default_rng(23)
+    vel = rng.uniform(-40, 40, pos.shape).astype(np.float32)
+    n = pos.shape[0]
+    a, b = _ctx(n, cfg["box"], cfg["grid"], False), _ctx(n, cfg["box"], cfg["grid"], True)
+    try:
+        for c in (a, b):
+            c.upload(pos, vel)
+        merges = []
+        for dt, steps in ((5e-6, 60), (4e-4, 24), (5e-6, 60), (1e-4, 30), (2e-6, 40)):
+            for c in (a, b):
+                c.step(dt, steps)                      # queued back to back: no sync, no fresh hint in between
+            merges.append(b.sort_stats()["merges"])
+            assert np.array_equal(a.keys(), b.keys())
+            assert np.array_equal(a.order(), b.order())
+        sa, sb = a.download(), b.download()
+        for k in ("pos", "vel", "density", "pressure"):
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+        per_phase = np.diff([0] + merges)
+        assert per_phase[0] >= 58                      # calm: every sort but the first merges
+        assert per_phase[2] >= 50 and per_phase[4] >= 30   # back to merging within a few steps of the calm
+        assert a.sort_stats()["merges"] == 0
+    finally:
+        a.close(); b.close()
