@@ -153,6 +153,16 @@ __device__ __forceinline__ void lane_rows(const uint2* __restrict__ cells, const
 #define SPH_FORCE_OCC 5     // <= 96 VGPRs (95 used, no spill); 4, 5 and 6 waves time within 2 % of each other
 #endif
 
+// A wave-uniform constant lives in an SGPR, and a VALU instruction with an SGPR source issues at ~0.6 of the
+// rate of an all-VGPR one in a back-to-back stream on gfx950 (profiles/valu_rate.hip: 1.75 vs 1.05-1.25 ns per
+// wave-instruction per SIMD; the same for v_cmp + v_addc through an SGPR pair).  Inside the real loops the
+// effect is small (k_force -1 %), but the constants of the candidate loops are parked in VGPRs all the same;
+// the empty asm hides their uniformity from the compiler.
+__device__ __forceinline__ float in_vgpr(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 __device__ __forceinline__ float inv_sqrt(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -246,6 +256,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
     wave_hulls(R, H);
     float4 q0, q1;
     float acc = 0.f;
+    const float h2_v = in_vgpr(ph.h2);
     traverse(
         H,
         [&](uint32_t a) {   // the arrays are padded by 2*PIECE entries: no bounds predicate needed
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
                 const float z = ((lds_f32_ptr)s_z)[idx + u];
                 const float dx = pi.x - xy.x, dy = pi.y - xy.y, dz = pi.z - z;
                 // h^2 - r^2 in three fmas (the subtraction rides along); max(., 0) is the r < h test
-                float d = fmaxf(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, ph.h2))), 0.f);
+                float d = fmaxf(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, h2_v))), 0.f);
                 d = valid ? d : 0.f;
                 acc = fmaf(d * d, d, acc);
             };
@@ -324,15 +335,6 @@ __device__ __forceinline__ void integrate_one(const Phys& ph, float dt, float4& 
     wall(pi.z, vi.z, ph.box_min[2], ph.box_max[2], ph.wall_eps, ph.wall_damping);
 }
 
-// 2*mask + hit in ONE VALU op: add-with-carry, the carry-in being the lane mask of the compare (hipcc turns
-// the C expression into select + shift + or).  The carry-out is never used (32 shifts per 32-bit mask).
-__device__ __forceinline__ uint32_t shift_in(uint32_t mask, uint64_t carry_in) {
-    uint32_t out;
-    uint64_t carry_out;
-    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(out), "=s"(carry_out) : "v"(mask), "s"(carry_in));
-    return out;
-}
-
 // ---- force / collision / integrate in ONE neighbour traversal ------------------------------------------
 // kernelComputeForces (.cu:189-243, pair .cu:39-50):
 //   f_press_i += -r^_ij * m * (p_i + p_j) / (2 rho_j) * SPIKY_GRAD * (h - r)^2,  r < h
@@ -374,6 +376,10 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     float2 e0, e1;
     const float cps = ph.spiky_half_mass / ph.visc_coef;   // pressure coefficient relative to the viscous one
     const float cpi = cps * dpi.y;
+    const float h_v = in_vgpr(ph.h);
+    // d <= 2R  <=>  r2 - next_up(coll_dist2) < 0: the sign bit of one subtraction, shifted into the mask by one
+    // v_alignbit -- two all-VGPR instructions (a compare + add-with-carry goes through an SGPR pair)
+    const float coll_next_v = in_vgpr(__uint_as_float(__float_as_uint(ph.coll_dist2) + 1u));
     float fpx = 0.f, fpy = 0.f, fpz = 0.f, fvx = 0.f, fvy = 0.f, fvz = 0.f;
     float cvx = 0.f, cvy = 0.f, cvz = 0.f;
     uint32_t ccount = 0;
@@ -428,14 +434,18 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                     const float rinv = inv_sqrt(r2);
                     // both kernels vanish continuously at r = h, so "r < h" is max(h - r, 0): one v_max instead
                     // of a compare and two selects
-                    float hr = fmaxf(ph.h - r2 * rinv, 0.f);
+                    float hr = fmaxf(fmaf(-r2, rinv, h_v), 0.f);
                     hr = valid ? hr : 0.f;
                     const float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
                     const float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
                     fpx += s * dx; fpy += s * dy; fpz += s * dz;
                     fvx += w * ux; fvy += w * uy; fvz += w * uz;
                 }
-                if (COLL) near = shift_in(near, __ballot(r2 <= ph.coll_dist2) & __ballot(valid));   // scalar and
+                if (COLL) {
+                    float t = r2 - coll_next_v;                      // negative <=> within collision range
+                    t = valid ? t : 1.0f;
+                    near = __builtin_amdgcn_alignbit(near, __float_as_uint(t), 31);   // (near << 1) | sign(t)
+                }
             };
             for (uint32_t t0 = 0; t0 < T; t0 += 32u) {
                 const uint32_t tend = min(T, t0 + 32u);
