@@ -82,23 +82,37 @@ class TorchDistComm:
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
+        # gloo moves host memory only: device tensors are staged through the host (rehearsals of the
+        # multi-process path on a box with fewer GPUs than ranks; RCCL takes device tensors as they are)
+        self.staged = dist.get_backend() == "gloo" and device.type != "cpu"
+        self.wire = torch.device("cpu") if self.staged else device
 
     def exchange(self, sends, recvs):
         """sends/recvs: lists of (peer, tensor); returns when all of them have completed."""
         dist = self.dist
-        ops = [dist.P2POp(dist.irecv, t, p) for p, t in recvs if t.numel()]
-        ops += [dist.P2POp(dist.isend, t, p) for p, t in sends if t.numel()]
+        recvs = [(p, t) for p, t in recvs if t.numel()]
+        sends = [(p, t) for p, t in sends if t.numel()]
+        if self.staged:
+            landing = [(p, t, self.torch.empty(t.shape, dtype=t.dtype)) for p, t in recvs]
+            ops = [dist.P2POp(dist.irecv, h, p) for p, _, h in landing]
+            ops += [dist.P2POp(dist.isend, t.cpu(), p) for p, t in sends]     # .cpu() orders after the pack kernels
+        else:
+            ops = [dist.P2POp(dist.irecv, t, p) for p, t in recvs]
+            ops += [dist.P2POp(dist.isend, t, p) for p, t in sends]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if self.staged:
+            for _, t, h in landing:
+                t.copy_(h)
 
     def allreduce_sum(self, arr):
-        t = self.torch.as_tensor(np.ascontiguousarray(arr)).to(self.device)
+        t = self.torch.as_tensor(np.ascontiguousarray(arr)).to(self.wire)
         self.dist.all_reduce(t)
         return t.cpu().numpy()
 
     def allreduce_max(self, x):
-        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.wire)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
