@@ -49,6 +49,7 @@ SIGNATURES = {
     "sph_num_particles": (_U32, [_P]),
     "sph_capacity": (_U32, [_P]),
     "sph_upload": (C.c_int, [_P, _U32, _P, _P, _P]),
+    "sph_set_by_index": (C.c_int, [_P, _U32, _U32, C.c_void_p, C.c_void_p]),
     "sph_reset_lattice": (C.c_int, [_P, C.POINTER(_U32), C.c_int, C.POINTER(C.c_float), C.c_uint64, _U32]),
     "sph_download": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
     "sph_download_owned": (C.c_int, [_P, _P, _P, _P]),
@@ -200,6 +201,15 @@ class Context:
         idx = np.ascontiguousarray(index, dtype=np.uint32) if index is not None else None
         _check(self.L.sph_upload(self.h, n, pos.ctypes.data, vel.ctypes.data if vel is not None else None,
                                  idx.ctypes.data if idx is not None else None))
+
+    def set_by_index(self, first_index, pos=None, vel=None):
+        """Overwrite position and/or velocity of the particles with creation indices first_index .. (device side)."""
+        pos = None if pos is None else np.ascontiguousarray(pos, dtype=np.float32)
+        vel = None if vel is None else np.ascontiguousarray(vel, dtype=np.float32)
+        count = (pos if pos is not None else vel).shape[0]
+        assert vel is None or pos is None or vel.shape == pos.shape
+        _check(self.L.sph_set_by_index(self.h, int(first_index), int(count),
+                                       None if pos is None else pos.ctypes.data, None if vel is None else vel.ctypes.data))
 
     def reset_lattice(self, lattice, jitter=True, jitter_dims=None, start=0, count=None):
         """Dam-break lattice generated on the device (bit-identical to ic.dam_break_lattice)."""

@@ -220,29 +220,34 @@ void ParticleSystem::reset(ParticleConfig config) {
 // particleSystem.cpp:923-961.  Overwrites the positions of particles [start, ...) with a jittered
 // sphere lattice; velocities are left alone and `vel` is unused, as upstream.  Unlike upstream the
 // current device state is fetched first (the reference re-uploads a stale host copy in CUDA mode).
+// particleSystem.cpp:928-961.  The reference edits its host copy from `start` on and copies that range to the
+// device -- after update() the host copy is stale there, so the edit rewinds every particle it copies (SURVEY
+// A.2).  Here only the sphere's own particles change, on the device (sph_set_by_index).
 void ParticleSystem::addSphere(int start, float* pos, float* vel, int r, float spacing) {
     (void)vel;
-    downloadAll();
     uint index = (uint)start;
     const float w = m_boxDims.x, h = m_boxDims.y, d = m_boxDims.z;
     const float jitter = m_params.particleRadius * 0.01f;
     uint32_t counter = 0;
+    std::vector<float> xyz;
     for (int z = -r; z <= r; z++)
         for (int y = -r; y <= r; y++)
             for (int x = -r; x <= r; x++) {
                 const float dx = x * spacing, dy = y * spacing, dz = z * spacing;
                 const float l = sqrtf(dx * dx + dy * dy + dz * dz);
                 if ((l <= m_params.particleRadius * 2.0f * r) && (index < m_numParticles)) {
-                    float* p = &m_hPos[(size_t)index * 4];
-                    p[0] = pos[0] + dx + (w * uniform01(counter, 0, kSeed + 1) - w / 2) * jitter;
-                    p[1] = pos[1] + dy + (h * uniform01(counter, 1, kSeed + 1) - h / 2) * jitter;
-                    p[2] = pos[2] + dz + (d * uniform01(counter, 2, kSeed + 1) - d / 2) * jitter;
-                    p[3] = 1.f;
+                    xyz.push_back(pos[0] + dx + (w * uniform01(counter, 0, kSeed + 1) - w / 2) * jitter);
+                    xyz.push_back(pos[1] + dy + (h * uniform01(counter, 1, kSeed + 1) - h / 2) * jitter);
+                    xyz.push_back(pos[2] + dz + (d * uniform01(counter, 2, kSeed + 1) - d / 2) * jitter);
                     index++;
                     counter++;
                 }
             }
-    uploadAll();
+    std::vector<float> xyzw(xyz.size() / 3 * 4);
+    for (size_t k = 0; k < xyz.size() / 3; k++) {
+        xyzw[4 * k] = xyz[3 * k]; xyzw[4 * k + 1] = xyz[3 * k + 1]; xyzw[4 * k + 2] = xyz[3 * k + 2]; xyzw[4 * k + 3] = 1.f;
+    }
+    setArray(POSITION, xyzw.data(), start, (int)(xyz.size() / 3));
 }
 
 void ParticleSystem::dumpParticles(uint start, uint count) {   // particleSystem.cpp:819-827
@@ -259,15 +264,24 @@ float* ParticleSystem::getArray(ParticleArray array) {
 }
 
 void ParticleSystem::setArray(ParticleArray array, const float* data, int start, int count) {
-    m_hostStale = true;
-    downloadAll();
-    std::vector<float>& dst = array == POSITION ? m_hPos : m_hVel;
     if (start < 0 || count < 0 || (size_t)start + (size_t)count > m_numParticles) {
         fprintf(stderr, "ParticleSystem::setArray: range [%d, %d) outside 0..%u\n", start, start + count, m_numParticles);
         exit(EXIT_FAILURE);
     }
-    memcpy(&dst[(size_t)start * 4], data, (size_t)count * 4 * sizeof(float));
-    uploadAll();
+    if (count == 0) return;
+    std::vector<float>& dst = array == POSITION ? m_hPos : m_hVel;
+    if (sph_num_particles(m_ctx) != m_numParticles) {       // nothing on the device yet: edit the host copy, upload it
+        memcpy(&dst[(size_t)start * 4], data, (size_t)count * 4 * sizeof(float));
+        uploadAll();
+        return;
+    }
+    // the particles are on the device: change just these there, by creation index (no round trip of the state)
+    std::vector<float> xyz((size_t)count * 3);
+    for (int i = 0; i < count; i++)
+        for (int a = 0; a < 3; a++) xyz[3 * (size_t)i + a] = data[4 * (size_t)i + a];
+    SPH_CHECK(sph_set_by_index(m_ctx, (uint32_t)start, (uint32_t)count, array == POSITION ? xyz.data() : nullptr,
+                               array == VELOCITY ? xyz.data() : nullptr));
+    if (!m_hostStale) memcpy(&dst[(size_t)start * 4], data, (size_t)count * 4 * sizeof(float));   // a fresh mirror stays fresh
 }
 
 void ParticleSystem::setSimParams(const SimParams& p) {

@@ -300,6 +300,24 @@ static int do_density(sph_ctx* c) {
 
 using namespace sph;
 
+// one thread per owned slot: particles whose creation index falls in the range take their new data
+__global__ __launch_bounds__(256) void k_set_by_index(float4* __restrict__ posi, float4* __restrict__ velr, uint32_t n,
+                                                      uint32_t first, uint32_t count, const float* __restrict__ pos,
+                                                      const float* __restrict__ vel, float4* __restrict__ pos_by_index) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 p = posi[i];
+    const uint32_t k = __float_as_uint(p.w) - first;
+    if (k >= count) return;                               // also rejects indices below `first` (wraps)
+    if (pos) {
+        p.x = pos[3 * k]; p.y = pos[3 * k + 1]; p.z = pos[3 * k + 2];
+        posi[i] = p;
+        if (pos_by_index) pos_by_index[first + k] = make_float4(p.x, p.y, p.z, 1.0f);
+    }
+    if (vel) velr[i] = make_float4(vel[3 * k], vel[3 * k + 1], vel[3 * k + 2], 0.f);
+}
+
+
 extern "C" {
 
 int sph_abi_version(void) { return SPH_ABI_VERSION; }
@@ -433,6 +451,40 @@ int sph_upload(sph_ctx* c, uint32_t n, const float* pos, const float* vel, const
     c->stage = sph_ctx::ST_LOADED;
     c->keys_fresh = false;
     c->order_valid = false;     // the slots no longer follow the last sort
+    c->have_dens = c->have_force = c->have_coll = false;
+    return SPH_OK;
+}
+
+int sph_set_by_index(sph_ctx* c, uint32_t first_index, uint32_t count, const float* pos_xyz, const float* vel_xyz) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(c->slab || (uint64_t)first_index + count <= c->pos_out_cap, SPH_E_INVALID,
+                "creation indices [%u, +%u) exceed the capacity %u", first_index, count, c->pos_out_cap);
+    if (count == 0 || (!pos_xyz && !vel_xyz)) return SPH_OK;
+    SPH_HIP(hipSetDevice(c->device));
+    float* d_pos = nullptr; float* d_vel = nullptr;
+    const size_t bytes = (size_t)count * 3 * sizeof(float);
+    int rc = SPH_OK;
+    if (pos_xyz) rc = dev_alloc(&d_pos, (size_t)count * 3);
+    if (!rc && vel_xyz) rc = dev_alloc(&d_vel, (size_t)count * 3);
+    if (!rc) {
+        hipError_t e = hipSuccess;
+        if (pos_xyz) e = hipMemcpyAsync(d_pos, pos_xyz, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && vel_xyz) e = hipMemcpyAsync(d_vel, vel_xyz, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && c->n) {
+            hipLaunchKernelGGL(k_set_by_index, dim3(ceil_div(c->n, 256)), dim3(256), 0, c->stream, c->posi + c->own_off,
+                               c->velr + c->own_off, c->n, first_index, count, d_pos, d_vel,
+                               c->slab ? nullptr : c->pos_out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);        // the host buffers may go away now
+        if (e != hipSuccess) { set_error("sph_set_by_index: %s", hipGetErrorString(e)); rc = SPH_E_DEVICE; }
+    }
+    hipFree(d_pos); hipFree(d_vel);
+    if (rc) return rc;
+    // positions moved under the keys: hash again; the slots still follow the last sort (order_valid stays)
+    mm_drop_marks(c);
+    c->keys_fresh = false;
+    c->stage = sph_ctx::ST_LOADED;
     c->have_dens = c->have_force = c->have_coll = false;
     return SPH_OK;
 }

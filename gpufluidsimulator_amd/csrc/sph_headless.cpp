@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
     const bool benchmark = flag(argc, argv, "benchmark");
     if (flag(argc, argv, "help")) {
         printf("usage: sph_headless [-benchmark] [-n=<particles>] [-box=<edge>] [-i=<iterations>] [-steps=<per update>] "
-               "[-dump=<count>] [-log=<file>]\n");
+               "[-dump=<count>] [-log=<file>] [-sphere=<update>[,<radius>]] [-out=<file>] [-save=<file>] [-load=<file>]\n");
         return 0;
     }
     int is950 = 0;
@@ -64,7 +64,21 @@ int main(int argc, char** argv) {
     if (!flag(argc, argv, "nowarmup")) psystem->update(timestep, 0);   // warm-up step, not timed
     sph_sync(psystem->context());
     auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < iterations; ++i) psystem->update(timestep, (float)i);
+    // -sphere=<k>[,<r>]: before update k, drop a ball of (2r+1)^3 lattice points (radius r spacings) at the top of
+    // the box the way the GUI's key '4' does (addSphere, particles.cpp:306-318; centred here instead of frand())
+    int sphereAt = -1, ballr = 10;
+    if (const char* v = value(argc, argv, "sphere")) {
+        sphereAt = atoi(v);
+        if (const char* c = strchr(v, ',')) ballr = atoi(c + 1);
+    }
+    for (int i = 0; i < iterations; ++i) {
+        if (i == sphereAt) {
+            const float pr = psystem->getParticleRadius(), tr = pr + (pr * 2.0f) * ballr;
+            float pos[4] = {0.0f, psystem->getBoxMax().y - tr, 0.0f, 0.0f}, vel[4] = {0.f, 0.f, 0.f, 0.f};
+            psystem->addSphere(0, pos, vel, ballr, pr * 2.0f);
+        }
+        psystem->update(timestep, (float)i);
+    }
     sph_sync(psystem->context());
     auto t1 = std::chrono::steady_clock::now();
     const double secs = std::chrono::duration<double>(t1 - t0).count();

@@ -112,6 +112,13 @@ uint32_t sph_capacity(const sph_ctx* c);
  * index (Particle::index), NULL = 0..n-1.  Replaces copyArrayToDevice of the AoS array
  * (particleSystem.cpp:920,960).  Density/pressure/forces are reset to 0. */
 int sph_upload(sph_ctx* c, uint32_t n, const float* pos_xyz, const float* vel_xyz, const uint32_t* index);
+/* Overwrite position and/or velocity (xyz triples, either may be NULL) of the particles whose creation
+ * index lies in [first_index, first_index + count), wherever they sit in the sorted arrays -- no
+ * round trip of the whole state: replaces the host edit + copyArrayToDevice(start, count) of addSphere /
+ * setArray (particleSystem.cpp:928-961).  Densities and forces of the current step become stale: the
+ * next step starts with sph_hash as after sph_upload (the sort still only moves the particles whose
+ * cell changed).  A slab context changes the particles it owns and ignores the others. */
+int sph_set_by_index(sph_ctx* c, uint32_t first_index, uint32_t count, const float* pos_xyz, const float* vel_xyz);
 /* Generate the dam-break lattice ON THE DEVICE (no host arrays, no PCIe): particles with creation index
  * index_start .. index_start+count of an (nx, ny, nz) lattice in the min corner of the box, spacing 2R,
  * zero velocity, counter-based jitter (amplitude from jitter_dims, NULL = the box; jitter = 0 switches it

@@ -153,3 +153,50 @@ def test_user_stream_and_two_contexts():
     # b started from the reversed array: same physics, different summation order inside cells
     assert np.abs(gb["pos"] - want["pos"]).max() <= 1e-6 * 4.0
     assert np.abs(gb["density"] / want["density"] - 1).max() <= 1e-5
+
+
+def test_set_by_index_equals_host_edit_and_reupload():
+    """sph_set_by_index changes some particles in place on the device (by creation index, wherever the sort
+    put them); the result must equal downloading the state, editing it on the host and uploading it again."""
+    box, grid, n = (2.0, 2.0, 2.0), (32, 32, 32), 5000
+    pos, vel = ic.random_box(n, box, speed=8.0, fill=0.4)
+    rng = np.random.default_rng(41)
+    first, count = 700, 900
+    new_pos = rng.uniform(-0.6, 0.6, (count, 3)).astype(np.float32)
+    new_vel = rng.uniform(-5, 5, (count, 3)).astype(np.float32)
+    dt = 1e-6
+    with capi.Context(n, box=box, grid=grid) as a:
+        a.upload(pos, vel)
+        a.step(dt, 3)
+        mid = a.download()
+        a.set_by_index(first, pos=new_pos, vel=new_vel)
+        assert np.array_equal(a.positions4()[first:first + count, :3], new_pos)      # the by-index output follows
+        with pytest.raises(capi.SphError):
+            a.density()                                                                # stale: hash + sort come first
+        a.step(dt, 3)
+        sa = a.download()
+        merges = a.sort_stats()["merges"]
+    assert merges >= 2                                  # (900 of 5000 particles jump: the step after the edit sorts in full)
+    p2, v2 = mid["pos"].copy(), mid["vel"].copy()
+    p2[first:first + count] = new_pos
+    v2[first:first + count] = new_vel
+    with capi.Context(n, box=box, grid=grid) as b:
+        b.upload(p2, v2)
+        b.step(dt, 3)
+        sb = b.download()
+    assert np.abs(sa["pos"] - sb["pos"]).max() <= 1e-6 * max(box)
+    assert np.abs(sa["vel"] - sb["vel"]).max() <= REL * np.abs(sb["vel"]).max()
+    assert np.abs(sa["density"] / sb["density"] - 1).max() <= REL
+    # position only / velocity only, and indices outside the range stay untouched
+    with capi.Context(n, box=box, grid=grid) as c:
+        c.upload(pos, vel)
+        c.step(dt, 1)
+        before = c.download()
+        c.set_by_index(10, vel=new_vel[:5])
+        c.set_by_index(4000, pos=new_pos[:7])
+        c.hash(); c.sort()
+        after = c.download(want=("pos", "vel"))
+    exp_p, exp_v = before["pos"].copy(), before["vel"].copy()
+    exp_v[10:15] = new_vel[:5]
+    exp_p[4000:4007] = new_pos[:7]
+    assert np.array_equal(after["pos"], exp_p) and np.array_equal(after["vel"], exp_v)

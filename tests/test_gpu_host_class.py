@@ -96,3 +96,46 @@ def test_device_lattice_generator_is_bit_identical_to_numpy():
             assert not vel.any()
             c.step(DT, 2)                                   # and the step runs from it
             assert np.isfinite(c.download(count=total, want=("density",))["density"][start:start + cnt]).all()
+
+
+def test_add_sphere_moves_only_its_own_particles():
+    """-sphere=3,4: before update 3 the driver calls ParticleSystem::addSphere (the GUI's key '4',
+    particles.cpp:306-318).  The ball's particles are creation indices 0..k-1; they are rewritten on the device
+    (sph_set_by_index), everybody else carries on -- so the run equals the C ABI path with the same edit."""
+    n, box, r = 4096, 4.0, 4
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "state.bin")
+        _run("-n=4096", "-box=4", "-i=6", "-nowarmup", f"-sphere=3,{r}", f"-out={f}")
+        raw = np.fromfile(f, dtype=np.float32).reshape(2, n, 4)
+    # the same ball, point for point (particleSystem.cpp addSphere: z, y, x loops, l <= 2 R r, jitter stream seed+1)
+    pr = np.float32(1.0 / 64.0)
+    spacing = np.float32(pr * np.float32(2.0))
+    tr = np.float32(pr + spacing * np.float32(r))
+    centre = np.float32([0.0, np.float32(box / 2) - tr, 0.0])
+    pts = []
+    for z in range(-r, r + 1):
+        for y in range(-r, r + 1):
+            for x in range(-r, r + 1):
+                dv = np.float32([x, y, z]) * spacing
+                l = np.sqrt(np.float32(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]), dtype=np.float32)
+                if l <= pr * np.float32(2.0) * np.float32(r):
+                    pts.append(dv)
+    k = len(pts)
+    assert 200 < k < 400
+    cnt = np.arange(k, dtype=np.uint32)
+    jit = np.float32(pr * np.float32(0.01))
+    ball = np.empty((k, 3), np.float32)
+    for a in range(3):
+        u = ic.uniform01(cnt, a, ic.SEED + 1)
+        w = np.float32(box)
+        ball[:, a] = centre[a] + np.float32([p[a] for p in pts]) + (w * u - w / np.float32(2.0)) * jit
+    pos, vel = ic.dam_break_lattice((16, 16, 16), (box,) * 3, jitter=True)
+    with capi.Context(n, box=(box,) * 3, grid=(64,) * 3) as c:
+        c.upload(pos, vel)
+        c.step(DT, 3)
+        c.set_by_index(0, pos=ball)
+        c.step(DT, 3)
+        st = c.download()
+    assert np.array_equal(raw[0, :, :3].view(np.uint32), st["pos"].view(np.uint32))
+    assert np.array_equal(raw[1, :, :3].view(np.uint32), st["vel"].view(np.uint32))
+    assert np.abs(raw[0, :k, :3] - ball).max() < 1e-3 and raw[0, :k, 1].min() > 1.5      # the ball sits at the top
