@@ -108,6 +108,7 @@ def run_single(args):
     phases_ms = {k: v / max(nst, 1) for k, v in ph.items()}
     st = ctx.download(want=("density",))
     ok = bool(np.isfinite(st["density"]).all())
+    phases_ms["_sort_stats"] = ctx.sort_stats()          # how many sorts took the merge path, last mover count
     ctx.close()
     return n, wall, phases_ms, ok, cfg
 
@@ -134,6 +135,7 @@ def main():
         return slab.bench_main(args)
 
     n, wall, phases_ms, ok, cfg = run_single(args)
+    sort_stats = phases_ms.pop("_sort_stats")
     value = n * args.steps / wall
     t_force = phases_ms["force"] * 1e-3
     t_dens = phases_ms["dens"] * 1e-3
@@ -166,7 +168,7 @@ def main():
                      "density_kernel": {"achieved": BYTES_PER_PARTICLE["dens"] * n / t_dens / 1e9, "unit": "GB/s",
                                         "avg_launch_ms": phases_ms["dens"],
                                         "valu_tflops": FLOP_PER_PARTICLE["dens"] * n / t_dens / 1e12}},
-        "phases_ms": phases_ms, "finite": ok,
+        "phases_ms": phases_ms, "sort": sort_stats, "finite": ok,
     }
     if not args.no_cpu:
         cb = cpu_baseline()
