@@ -318,6 +318,12 @@ __global__ __launch_bounds__(256) void k_set_by_index(float4* __restrict__ posi,
 }
 
 
+__global__ __launch_bounds__(256) void k_gather_cells(const uint32_t* __restrict__ keys, uint32_t m,
+                                                      const uint2* __restrict__ cells, uint2* __restrict__ out) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < m) out[k] = cells[keys[k]];
+}
+
 extern "C" {
 
 int sph_abi_version(void) { return SPH_ABI_VERSION; }
@@ -698,17 +704,33 @@ int sph_get_cells(sph_ctx* c, uint32_t max_cells, uint32_t* key, uint32_t* start
     const uint32_t lo = c->cells_lo, hi = c->cells_hi;
     std::vector<uint32_t> ks(hi - lo);
     if (hi > lo) SPH_HIP(hipMemcpy(ks.data(), c->keyS + lo, (hi - lo) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    uint32_t m = 0;
-    for (uint32_t s = 0; s < hi - lo; s++) {
-        if (s && ks[s] == ks[s - 1]) continue;
-        if (m < max_cells) {
-            uint2 v;
-            SPH_HIP(hipMemcpy(&v, c->cells + ks[s], sizeof(v), hipMemcpyDeviceToHost));
-            if (key) key[m] = ks[s];
-            if (start) start[m] = v.x - lo;
-            if (count) count[m] = v.y - v.x;
+    std::vector<uint32_t> uniq;                         // occupied cells, in slot order
+    for (uint32_t s = 0; s < hi - lo; s++)
+        if (s == 0 || ks[s] != ks[s - 1]) uniq.push_back(ks[s]);
+    const uint32_t m = (uint32_t)uniq.size(), take = m < max_cells ? m : max_cells;
+    if (take) {                                         // one gather on the device, one copy back
+        uint32_t* d_keys = nullptr; uint2* d_out = nullptr;
+        int rc = dev_alloc(&d_keys, (size_t)take);
+        if (!rc) rc = dev_alloc(&d_out, (size_t)take);
+        std::vector<uint2> got(take);
+        if (!rc) {
+            hipError_t e = hipMemcpy(d_keys, uniq.data(), take * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_gather_cells, dim3(ceil_div(take, 256)), dim3(256), 0, c->stream, d_keys, take, c->cells,
+                                   d_out);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = hipMemcpy(got.data(), d_out, take * sizeof(uint2), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { set_error("sph_get_cells: %s", hipGetErrorString(e)); rc = SPH_E_DEVICE; }
         }
-        m++;
+        hipFree(d_keys); hipFree(d_out);
+        if (rc) return rc;
+        for (uint32_t k = 0; k < take; k++) {
+            if (key) key[k] = uniq[k];
+            if (start) start[k] = got[k].x - lo;
+            if (count) count[k] = got[k].y - got[k].x;
+        }
     }
     return (int)m;
 }
