@@ -77,7 +77,7 @@ SIGNATURES = {
     "sph_timing_enable": (C.c_int, [_P, C.c_int]),
     "sph_timing_get": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U32)]),
     "sph_timing_reset": (C.c_int, [_P]),
-    "sph_sort_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "sph_sort_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_slab_counts": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_migrants_pack": (C.c_int, [_P, C.POINTER(_P), _U32]),
@@ -316,10 +316,10 @@ class Context:
     def timing_reset(self): _check(self.L.sph_timing_reset(self.h))
 
     def sort_stats(self):
-        """{'sorts', 'merges', 'last_movers'}: how often the sort took the merge path (see sph_hip.h)."""
-        a, b, m = C.c_uint64(), C.c_uint64(), C.c_uint32()
-        _check(self.L.sph_sort_stats(self.h, C.byref(a), C.byref(b), C.byref(m)))
-        return {"sorts": a.value, "merges": b.value, "last_movers": m.value}
+        """{'sorts', 'merges', 'skips', 'last_movers'}: how often the sort took the merge path (see sph_hip.h)."""
+        a, b, k, m = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        _check(self.L.sph_sort_stats(self.h, C.byref(a), C.byref(b), C.byref(k), C.byref(m)))
+        return {"sorts": a.value, "merges": b.value, "skips": k.value, "last_movers": m.value}
 
     def timing_get(self):
         ms = (C.c_float * len(PHASES))()

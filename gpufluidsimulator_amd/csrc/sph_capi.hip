@@ -873,12 +873,13 @@ int sph_timing_reset(sph_ctx* c) {
     return SPH_OK;
 }
 
-int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint32_t* last_movers) {
+int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     SPH_HIP(hipSetDevice(c->device));
     SPH_HIP(hipStreamSynchronize(c->stream));
     if (sorts) *sorts = c->sort_calls;
     if (merges) *merges = c->sort_merges;
+    if (skips) *skips = c->sort_skips;
     if (last_movers) *last_movers = *c->mm_count_host;
     return SPH_OK;
 }

@@ -93,11 +93,11 @@ struct sph_ctx {
     uint32_t* digit_tot = nullptr;  // 256
     uint32_t sort_blocks_cap = 0;
     uint32_t key_bits = 0;
-    const uint32_t* last_perm = nullptr;   // v0 or v1: the permutation of the last sort
+    const uint32_t* last_perm = nullptr;   // v0 or v1: the permutation of the last sort; null = identity
     // the sort as a merge (sph_sort.hip: launch_sort_merge)
     bool sort_merge = true;         // SPH_SORT_MERGE=0 in the environment at create time turns it off
     bool order_valid = false;       // [own_off, own_off+n) is still in the order of the last sort, keyS = its keys
-    uint64_t sort_merges = 0, sort_calls = 0;
+    uint64_t sort_merges = 0, sort_calls = 0, sort_skips = 0;   // skips: merges with no mover at all (nothing done)
     uint64_t* mm_mask = nullptr;    // one bit per slot: key changed since the last sort
     uint32_t* mm_M64 = nullptr;     // movers before each 64-slot chunk
     uint32_t* mm_tile_cnt = nullptr; uint32_t* mm_tile_off = nullptr;

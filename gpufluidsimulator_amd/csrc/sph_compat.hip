@@ -196,10 +196,11 @@ void cudaSortParticles(sph_compat_particle* p, unsigned int n) {
     CK(sph_sort(c.ctx));
     if (n) {   // move the structs like thrust::sort does
         const uint32_t* perm = sph::last_sort_permutation(c.ctx);
+        if (perm)                                   // null: the order did not change
         hipLaunchKernelGGL(k_aos_permute, dim3(ceil_div(n * 22u, 256)), dim3(256), 0, c.ctx->stream, (const uint32_t*)p,
                            (uint32_t*)c.tmp, perm, n);
         CKH(hipGetLastError());
-        CKH(hipMemcpyAsync(p, c.tmp, (size_t)n * sizeof(sph_compat_particle), hipMemcpyDeviceToDevice, c.ctx->stream));
+        if (perm) CKH(hipMemcpyAsync(p, c.tmp, (size_t)n * sizeof(sph_compat_particle), hipMemcpyDeviceToDevice, c.ctx->stream));
     }
     CKH(hipStreamSynchronize(c.ctx->stream));    // thrust::sort blocks the host; keep that
 }

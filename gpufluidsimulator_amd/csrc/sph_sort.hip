@@ -484,16 +484,20 @@ void mm_drop_marks(sph_ctx* c) {
 }
 
 // (ks, vs) of the stable sort by B, from the current order (sorted by A); see the block comment above
+// step 1 of the merge: the movers are marked (by the integrate epilogue, or here) and counted
+static void launch_merge_count(sph_ctx* c, uint32_t n) {
+    if (c->mm_marked && !(c->mm_marked_off == c->own_off && c->mm_marked_n == n)) mm_drop_marks(c);   // another range
+    if (!c->mm_marked)                           // else: the fused integrate epilogue compared the keys already
+        hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, c->keyS + c->own_off, c->k0, n,
+                           c->mm_mask, c->mm_tile_cnt);
+    c->mm_marked = false;
+    mm_tilescan(c, n);
+}
+
 static void launch_sort_merge(sph_ctx* c, uint32_t n, bool table_live, uint32_t*& ks, uint32_t*& vs) {
     const uint32_t* A = c->keyS + c->own_off;
     const uint32_t* B = c->k0;
     const uint32_t nchunks = ceil_div(n, 64u), nt = ceil_div(nchunks, MM_TILE_CHUNKS);
-    if (c->mm_marked && !(c->mm_marked_off == c->own_off && c->mm_marked_n == n)) mm_drop_marks(c);   // another range
-    if (!c->mm_marked)                           // else: the fused integrate epilogue compared the keys already
-        hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, A, B, n, c->mm_mask,
-                           c->mm_tile_cnt);
-    c->mm_marked = false;
-    mm_tilescan(c, n);
     uint32_t* mk = c->mm_k0; uint32_t* mi = c->v0; uint32_t* mk2 = c->mm_k1; uint32_t* mi2 = c->mm_v1;
     hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, c->mm_tile_off, A, B,
                        c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr);
@@ -529,6 +533,23 @@ int launch_sort(sph_ctx* c) {
     c->cells_clear_deferred = false;
     bool table_kept = false;               // the merge path keeps the live table and clears it sparsely
     if (can_merge && *c->mm_count_host <= n / 8u) {
+        const bool was_still = *c->mm_count_host == 0u;
+        launch_merge_count(c, n);
+        if (was_still && table_live && c->own_off == c->gcap) {
+            // Nothing moved last time (a fluid at rest: no particle crosses a cell face for many steps).  If that
+            // is still so, the order, the keys and the cell table are already those of this step and the whole
+            // sort -- 0.3 ms of copying at C3 -- can be left out.  Only the device knows: wait for the count (the
+            // queue is empty at this point, the bubble is a launch latency) and look.
+            SPH_HIP(hipStreamSynchronize(c->stream));
+            if (*c->mm_count_host == 0u) {
+                c->sort_merges++;
+                c->sort_skips++;
+                SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
+                c->last_perm = nullptr;            // identity
+                c->order_valid = true;             // cells_valid / cells_lo / cells_hi: unchanged and still true
+                return SPH_OK;
+            }
+        }
         launch_sort_merge(c, n, table_live, kin, vin);
         c->sort_merges++;
         table_kept = table_live;

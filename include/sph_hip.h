@@ -184,11 +184,13 @@ int sph_timing_enable(sph_ctx* c, int on);
 /* sums of per-phase device milliseconds since the last reset, and the number of steps */
 int sph_timing_get(sph_ctx* c, float ms[SPH_PH_COUNT], uint32_t* n_steps);
 int sph_timing_reset(sph_ctx* c);
-/* sort statistics: sorts run so far, how many of them took the merge path (only the particles whose
- * cell changed are sorted; same result as the full sort), and the mover count the device last
- * reported (synchronises the stream).  SPH_SORT_MERGE=0 in the environment at sph_create time
- * disables the merge path. */
-int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint32_t* last_movers);
+/* sort statistics: sorts run so far; how many of them took the merge path (only the particles whose
+ * cell changed are sorted; same result as the full sort); how many of those found that no particle had
+ * changed cell and did nothing at all (`skips`: the order, the keys and the cell table of the previous
+ * step are still exact -- a fluid at rest; this is the one place where sph_step waits for the device);
+ * and the mover count the device last reported (synchronises the stream).  SPH_SORT_MERGE=0 in the
+ * environment at sph_create time disables the merge path.  Any pointer may be NULL. */
+int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers);
 
 /* ---- z-slab halo / migration (multi-GPU; no counterpart in the reference) ---------------- */
 /* side: 0 = towards lower z (rank-1), 1 = towards higher z (rank+1).

@@ -95,11 +95,41 @@ def test_clump_and_empty_cells():
 
 
 def test_no_movers_at_all():
-    cfg = ic.CONFIGS["C1"]
-    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=False)
-    st, movers = _lockstep(pos, vel, cfg["box"], cfg["grid"], 5e-7, 3, True)
-    assert movers == [0, 0, 0] or max(movers) < 8
-    assert st["merges"] == 2
+    """A lattice at rest: no particle changes cell, so from the third sort on (the first is the full sort, the
+    second reports "0 movers") the merge path finds nothing to do and leaves order, keys and cell table as they
+    are -- and they still equal what the full sort produces every step."""
+    box, grid = (2.0, 2.0, 2.0), (32, 32, 32)
+    pos, vel = ic.dam_break_lattice((8, 8, 8), box, jitter=False)
+    st, movers = _lockstep(pos, vel, box, grid, 5e-7, 8, True, full_table=True)
+    assert movers == [0] * 8
+    assert st["merges"] == 7 and st["skips"] == 7
+
+
+def test_rest_then_motion():
+    """Skipping must stop the moment something moves: at rest for a few steps, then a kick through the API."""
+    box, grid = (2.0, 2.0, 2.0), (32, 32, 32)
+    pos, vel = ic.dam_break_lattice((10, 10, 10), box, jitter=True)
+    n = pos.shape[0]
+    rng = np.random.default_rng(3)
+    kick = rng.uniform(-200, 200, (n, 3)).astype(np.float32)
+    a, b = _ctx(n, box, grid, False), _ctx(n, box, grid, True)
+    try:
+        for c in (a, b):
+            c.upload(pos, vel)
+            c.step(5e-7, 5)
+        assert b.sort_stats()["skips"] >= 3
+        for c in (a, b):
+            c.set_by_index(0, vel=kick)
+            c.step(1e-4, 6)                       # now hundreds of particles change cell per step
+        assert b.sort_stats()["last_movers"] > 0
+        for c in (a, b):
+            c.step(5e-7, 4)
+        assert np.array_equal(a.keys(), b.keys()) and np.array_equal(a.order(), b.order())
+        sa, sb = a.download(), b.download()
+        for k in ("pos", "vel", "density", "pressure"):
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+    finally:
+        a.close(); b.close()
 
 
 def test_c2_size_fused_matches_full_sort():
