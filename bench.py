@@ -110,21 +110,23 @@ def run_single(args):
     ok = bool(np.isfinite(st["density"]).all())
     stats = ctx.sort_stats()                              # sorts, merges, skips (no particle changed cell), movers
     # The dam starts at rest and dt = 5e-7: for the first steps no particle crosses a cell face, and the library
-    # then leaves the (unchanged) order alone.  For the record, the same particles once they DO move: a random
-    # velocity field and 120 steps of run-up, until ~1e5 particles change cell per step (outside the headline number).
-    rng = np.random.default_rng(7)
-    ctx.set_by_index(0, vel=rng.uniform(-20.0, 20.0, (n, 3)).astype(np.float32))
-    ctx.step(1e-5, 120)
-    ctx.sync()
-    t0 = time.perf_counter()
-    ctx.step(1e-5, 10)
-    ctx.sync()
-    moving = {"ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "dt": 1e-5}
-    after = ctx.sort_stats()
-    moving.update(movers_last_step=after["last_movers"], skips=after["skips"] - stats["skips"],
-                  note="same C3 particles after a random +-20 velocity kick and 120 steps: off-lattice, ~1 % of them change "
-                       "cell per step (merge path), more collision partners -- a different, heavier workload")
-    stats["with_movers"] = moving
+    # then leaves the (unchanged) order alone.  --moving adds, for the record, the same particles once they DO move: a
+    # random velocity field and 120 steps of run-up, until ~1e5 particles change cell per step (never the headline number).
+    # (--moving only: the extra launches would otherwise blur the per-kernel averages of a rocprofv3 run of this command)
+    if args.moving:
+        rng = np.random.default_rng(7)
+        ctx.set_by_index(0, vel=rng.uniform(-20.0, 20.0, (n, 3)).astype(np.float32))
+        ctx.step(1e-5, 120)
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.step(1e-5, 10)
+        ctx.sync()
+        moving = {"ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "dt": 1e-5}
+        after = ctx.sort_stats()
+        moving.update(movers_last_step=after["last_movers"], skips=after["skips"] - stats["skips"],
+                      note="same C3 particles after a random +-20 velocity kick and 120 steps: off-lattice, ~1 % of them "
+                           "change cell per step (merge path), more collision partners -- a different, heavier workload")
+        stats["with_movers"] = moving
     phases_ms["_sort_stats"] = stats
     ctx.close()
     return n, wall, phases_ms, ok, cfg
@@ -138,6 +140,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(ic.CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
+    ap.add_argument("--moving", action="store_true",
+                    help="also time the same particles after a velocity kick (particles changing cell every step)")
     args = ap.parse_args()
     rank, world, local = _dist_env()
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
