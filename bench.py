@@ -135,8 +135,8 @@ def run_single(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)       # >= 20 warm-up, >= 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=sorted(ic.CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
