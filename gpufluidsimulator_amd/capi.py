@@ -77,6 +77,7 @@ SIGNATURES = {
     "sph_timing_enable": (C.c_int, [_P, C.c_int]),
     "sph_timing_get": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U32)]),
     "sph_timing_reset": (C.c_int, [_P]),
+    "sph_last_sort_skipped": (C.c_int, [_P]),
     "sph_sort_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_slab_counts": (C.c_int, [_P, C.POINTER(_U32)]),
@@ -314,6 +315,10 @@ class Context:
     # -- timing ---------------------------------------------------------------------------------
     def timing(self, on=True): _check(self.L.sph_timing_enable(self.h, 1 if on else 0))
     def timing_reset(self): _check(self.L.sph_timing_reset(self.h))
+
+    def sort_skipped(self):
+        """True if the last sort found no particle in a new cell and did nothing (no synchronisation)."""
+        return bool(self.L.sph_last_sort_skipped(self.h))
 
     def sort_stats(self):
         """{'sorts', 'merges', 'skips', 'last_movers'}: how often the sort took the merge path (see sph_hip.h)."""

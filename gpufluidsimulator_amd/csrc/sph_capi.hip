@@ -873,6 +873,8 @@ int sph_timing_reset(sph_ctx* c) {
     return SPH_OK;
 }
 
+int sph_last_sort_skipped(const sph_ctx* c) { return c && c->last_sort_skipped ? 1 : 0; }
+
 int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     SPH_HIP(hipSetDevice(c->device));

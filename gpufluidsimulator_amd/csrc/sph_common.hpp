@@ -97,6 +97,7 @@ struct sph_ctx {
     // the sort as a merge (sph_sort.hip: launch_sort_merge)
     bool sort_merge = true;         // SPH_SORT_MERGE=0 in the environment at create time turns it off
     bool order_valid = false;       // [own_off, own_off+n) is still in the order of the last sort, keyS = its keys
+    bool last_sort_skipped = false;
     uint64_t sort_merges = 0, sort_calls = 0, sort_skips = 0;   // skips: merges with no mover at all (nothing done)
     uint64_t* mm_mask = nullptr;    // one bit per slot: key changed since the last sort
     uint32_t* mm_M64 = nullptr;     // movers before each 64-slot chunk

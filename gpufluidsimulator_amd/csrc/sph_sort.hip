@@ -526,6 +526,7 @@ int launch_sort(sph_ctx* c) {
     const uint32_t ring = (uint32_t)(c->sort_calls & 3u);
     if (c->sort_merge && c->sort_calls >= 4) SPH_HIP(hipEventSynchronize(c->mm_done[ring]));
     c->sort_calls++;
+    c->last_sort_skipped = false;
     const bool can_merge = c->sort_merge && c->order_valid;
     // whole-domain contexts: sph_hash left the old cell table in place (cells_clear_deferred) when this
     // sort could take the merge path, which clears only the cells the movers left
@@ -544,6 +545,7 @@ int launch_sort(sph_ctx* c) {
             if (*c->mm_count_host == 0u) {
                 c->sort_merges++;
                 c->sort_skips++;
+                c->last_sort_skipped = true;
                 SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
                 c->last_perm = nullptr;            // identity
                 c->order_valid = true;             // cells_valid / cells_lo / cells_hi: unchanged and still true

@@ -211,6 +211,7 @@ class HipEngine:
     def upload(self, pos, vel, index): self.ctx.upload(pos, vel, index)
     def hash(self): self.ctx.hash()
     def sort(self): self.ctx.sort()
+    def sort_skipped(self): return self.ctx.sort_skipped()
     def build_cells(self): self.ctx.build_cells()
     def density(self): self.ctx.density()
     def slab_counts(self): return self.ctx.slab_counts()
@@ -311,6 +312,7 @@ class SlabSimulation:
         self.lo_peer = self.rank - 1 if self.rank > 0 else None
         self.hi_peer = self.rank + 1 if self.rank + 1 < self.world else None
         self.stats = {"migrants": 0, "resorts": 0, "ghosts": 0}
+        self._counts = None          # slab counts of the previous step, reusable while the sort finds nothing to do
 
     def _alloc_buffers(self):
         e, g = self.engine, self.ghost_capacity
@@ -325,7 +327,10 @@ class SlabSimulation:
         e, c = self.engine, self.comm
         lo, hi = self.lo_peer, self.hi_peer
         e.hash(); e.sort()
-        m_lo, own_lo, own_hi, m_hi = e.slab_counts()
+        if self._counts is not None and e.sort_skipped():
+            m_lo, own_lo, own_hi, m_hi = self._counts        # nobody changed cell: same boundary layers, nobody left
+        else:
+            m_lo, own_lo, own_hi, m_hi = self._counts = e.slab_counts()
         if lo is None: assert m_lo == 0, "particles below the box floor"
         if hi is None: assert m_hi == 0, "particles above the box ceiling"
         # counts: {migrants towards the peer, my boundary-layer particles that stay}
@@ -354,6 +359,7 @@ class SlabSimulation:
                 e.hash(); e.sort()               # newcomers are merged by a second sort (rare, small)
                 self.stats["resorts"] += 1
             self.stats["migrants"] += m_lo + m_hi
+            self._counts = None                  # the owned set changed: count again next step
         # halo A: boundary layers.  What I send = what stayed in my boundary layer + what arrived in it;
         # the peer knows both numbers (it sent me the second one), so no further count message.
         h_lo, h_hi = own_lo + in_lo, own_hi + in_hi
@@ -430,6 +436,7 @@ class SlabSimulation:
         n_own = rec.shape[0]
         self.capacity = max(self.capacity, int(1.5 * n_own) + 4096)
         self.engine = self._factory(self.capacity, self.ghost_capacity, self.params, self.z_lo, self.z_hi)
+        self._counts = None
         self.engine.upload(rec[:, 0:3].copy(), rec[:, 4:7].copy(), np.ascontiguousarray(rec[:, 3]).view(np.uint32).copy())
         self._alloc_buffers()
         self.stats["rebalances"] = self.stats.get("rebalances", 0) + 1

@@ -191,6 +191,10 @@ int sph_timing_reset(sph_ctx* c);
  * and the mover count the device last reported (synchronises the stream).  SPH_SORT_MERGE=0 in the
  * environment at sph_create time disables the merge path.  Any pointer may be NULL. */
 int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers);
+/* 1 if the last sph_sort found that no particle had changed cell and left everything as it was (then
+ * every count derived from the sorted order -- sph_slab_counts, sph_halo_count -- is that of the step
+ * before), else 0.  No synchronisation. */
+int sph_last_sort_skipped(const sph_ctx* c);
 
 /* ---- z-slab halo / migration (multi-GPU; no counterpart in the reference) ---------------- */
 /* side: 0 = towards lower z (rank-1), 1 = towards higher z (rank+1).

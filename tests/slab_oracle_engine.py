@@ -59,6 +59,8 @@ class OracleEngine:
         lz = np.clip(c[2] - self.z_lo + 1, 0, self.zl - 1)
         self.key = (lz * self.grid[1] + c[1]) * self.grid[0] + c[0]
 
+    def sort_skipped(self): return False        # the CPU test engine always sorts
+
     def sort(self):
         o = np.argsort(self.key, kind="stable")
         self.pos, self.vel, self.idx, self.key = self.pos[o], self.vel[o], self.idx[o], self.key[o]
