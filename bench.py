@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- particle-steps/sec of the SPH step on MI355X (see BASELINE.json / DESIGN.md).
+"""bench.py -- particle-steps/sec of the SPH step on MI355X (see BASELINE.json / DESIGN.md section 5).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C1] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--runup R] [--workload C3|C2|C1] [--no-cpu]
 
-N = 1: the whole-domain context runs BASELINE config 3 (dam-break, 16,777,216 particles, 512^3
-grid) with the state resident in HBM; K fused steps are timed between two device syncs.
-N > 1 (launched by torch.distributed.run, one rank per GPU): the domain is cut into N z-slabs of
-16,777,216 particles each (weak scaling), ghost layers and migrants travel over RCCL.
+N = 1: the whole-domain context runs BASELINE config 3 (dam-break, 16,777,216 particles, 512^3 grid, dt 5e-7)
+with the state resident in HBM.  The timed state is a FLOWING dam: the same initial lattice is first stepped R
+times on the device (state preparation, not timed; at dt = 5e-7 nothing crosses a cell face for the first ~1000
+steps), so that in the timed window every phase of the reference's step does work -- cell hash, sort, cell table,
+density, force, collision, integrate (SPH/particleSystem.cpp:773-795).  Then W warm-up steps and K timed steps
+between two device syncs.  `value` is that figure; `value_at_rest` (fresh lattice) and `value_full_sort` (the same
+flowing state with the radix sort forced every step) are reported next to it.
+N > 1 (launched by torch.distributed.run, one rank per GPU): z-slabs, see gpufluidsimulator_amd/slab.py.
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the fused
-force+collision+integrate traversal) by its ALGORITHMIC bytes over its mean
-device time measured with HIP events on the library's stream; `cpu_baseline` times the
-reference's own OpenMP code (oracle/_ref, kind "reference") or the C restatement (kind "port") on
-the host cores, on a bounded sample (a 64^3-particle dam break).
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the fused force+collision+integrate
+traversal) by its ALGORITHMIC bytes over its mean device time measured with HIP events on the library's stream
+during the flowing steps; `cpu_baseline` times the reference's own OpenMP code (oracle/_ref, kind "reference") and
+the C restatement (kind "port") on the host cores, on a bounded sample (a 64^3-particle dam break).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -37,9 +41,12 @@ BYTES_PER_PARTICLE = {
     "dens": 20,                 # R pos 12 ; W rho 4 + p 4
     # R pos 12 + vel 12 + rho 4 + p 4 + index 4 = 36 ; W pos 12 + vel 12 + index 4 + gl_pos float4 16 + next key 4 = 48
     "force_fused": 36 + 48,
+    # merge path of the sort: R old key 4 + mover mask ; gather R (key,slot) 8 + pos/vel 32, W pos/vel 32 + key 4
+    "sort_merge": 80,
 }
 # useful flops: candidates x per-pair arithmetic of the reference formulas
 FLOP_PER_PARTICLE = {"dens": 216 * 11, "force_fused": 216 * 34}
+DEFAULT_RUNUP = {"C3": 6000, "C2": 6000, "C1": 4000}
 
 
 def _dist_env():
@@ -49,87 +56,154 @@ def _dist_env():
     return rank, world, local
 
 
-def cpu_baseline(budget_s=20.0):
-    """Reference CPU path on a bounded sample of the same workload: a 64^3-particle dam break
-    (BASELINE config 2 geometry), as many steps as fit the budget (>= 3)."""
-    sys.path.insert(0, ROOT)
-    from oracle import refio
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: same step, host cores of this box, bounded sample
+# ---------------------------------------------------------------------------------------------------------------
+def _median_rate(run, reps=3):
+    rates = [run() for _ in range(reps)]
+    return statistics.median(rates), rates
+
+
+def cpu_baseline(budget_s=24.0):
+    """The reference's own OpenMP path (kind "reference", oracle/_ref/sph_ref: SPH/particleSystem.cpp compiled in
+    the build container) and the C restatement (kind "port", oracle/sph_oracle.c compiled here with -O3
+    -march=native) on a 64^3-particle dam break (BASELINE config 2 geometry): all host threads and one thread,
+    median of 3 runs each.  The headline `value` is the reference's figure when its binary is present."""
+    from oracle import oracle, refio
     cfg = ic.CONFIGS["C2"]
     pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = pos.shape[0]
+    model, cores = oracle.cpu_info()
+    dt = float(ic.DEFAULT_DT)
+    share = budget_s / 4.0                # four legs: {reference, port} x {all threads, one thread}
+    out = {"unit": "particle-steps/s", "cpu_model": model, "host_threads": cores,
+           "sample": "dam-break 64^3 = 262144 particles, 128^3 grid, dt 5e-7, jittered lattice; median of 3 runs"}
+    legs = {}
+
+    # -- port: oracle/sph_oracle.c, -O3 -march=native -fopenmp, built on this machine
+    o = oracle.Oracle(pos, vel, cfg["box"], cfg["grid"], oracle.CELL_MORTON, fast="native")
+
+    def port_run(threads, steps):
+        def run():
+            o.L.orc_set_num_threads(threads)
+            t0 = time.perf_counter()
+            o.step(dt, steps)
+            return n * steps / (time.perf_counter() - t0)
+        return run
+    o.L.orc_set_num_threads(cores)
+    t0 = time.perf_counter(); o.step(dt, 1); per = time.perf_counter() - t0
+    steps_all = int(max(1, min(50, share / 3.0 / max(per, 1e-3))))
+    rate, rates = _median_rate(port_run(cores, steps_all))
+    legs["port"] = {"value": rate, "cores": cores, "steps_per_run": steps_all, "runs": rates,
+                    "build": "oracle/sph_oracle.c, gcc -O3 -march=native -fopenmp (compiled on this host)"}
+    rate1, rates1 = _median_rate(port_run(1, 1))
+    legs["port"]["one_thread"] = {"value": rate1, "runs": rates1, "steps_per_run": 1}
+    o.close()
+
+    # -- reference: the reference's z* methods, g++ -O2 -fopenmp (prebuilt where /root/reference exists)
     if refio.available():
-        # the reference parallelises with `omp parallel for schedule(static, 4)` over ALL grid cells; on a
-        # many-core host more threads is not faster, so probe a few team sizes and keep the best
-        best_t, best_rate = 0, 0.0
+        # its `omp parallel for schedule(static, 4)` over ALL grid cells gets slower beyond a few dozen threads:
+        # probe a few team sizes (one step each) and keep the best
+        best_t, best_rate = 1, 0.0
         for t in sorted({8, 16, 32, 64, cores}):
             if t > cores:
                 continue
-            _, probe = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, 2, threads=t)
+            _, probe = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], dt, 1, threads=t)
             if probe["particle_steps_per_s"] > best_rate:
                 best_t, best_rate = t, probe["particle_steps_per_s"]
-        per_step = pos.shape[0] / best_rate
-        steps = int(max(3, min(200, budget_s / max(per_step, 1e-3))))
-        _, st = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], ic.DEFAULT_DT, steps, threads=best_t)
-        return {"value": st["particle_steps_per_s"], "unit": "particle-steps/s", "cores": int(st["threads"]),
-                "kind": "reference",
-                "sample": f"dam-break 64^3 = 262144 particles, 128^3 grid, {steps} steps, the reference's OpenMP "
-                          f"path (SPH/particleSystem.cpp z* methods, g++ -O2 -fopenmp), {st['threads']} threads "
-                          f"(best of a probe over team sizes on {cores} available cores)",
-                "phase_s": st["phase_s"]}
-    from oracle import oracle
-    o = oracle.Oracle(pos, vel, cfg["box"], cfg["grid"], oracle.CELL_MORTON, fast=True)
-    t0 = time.time(); o.step(float(ic.DEFAULT_DT), 2); per_step = (time.time() - t0) / 2
-    steps = int(max(3, min(200, budget_s / max(per_step, 1e-3))))
-    t0 = time.time(); o.step(float(ic.DEFAULT_DT), steps); dt = time.time() - t0
-    return {"value": pos.shape[0] * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": f"dam-break 64^3 = 262144 particles, 128^3 grid, {steps} steps, oracle/sph_oracle.c "
-                      f"(gcc -O3 -march=native -fopenmp), {cores} threads"}
+        steps_all = int(max(1, min(50, share / 3.0 * best_rate / n)))
+
+        def ref_run(threads, steps):
+            def run():
+                _, st = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], dt, steps, threads=threads)
+                return st["particle_steps_per_s"]
+            return run
+        rate, rates = _median_rate(ref_run(best_t, steps_all))
+        legs["reference"] = {"value": rate, "cores": best_t, "steps_per_run": steps_all, "runs": rates,
+                             "build": "SPH/particleSystem.cpp z* methods (OpenMP mode), g++ -O2 -fopenmp; team size = "
+                                      f"best of a probe over {{8,16,32,64,{cores}}} threads"}
+        rate1, rates1 = _median_rate(ref_run(1, 1))
+        legs["reference"]["one_thread"] = {"value": rate1, "runs": rates1, "steps_per_run": 1}
+    kind = "reference" if "reference" in legs else "port"
+    out.update(value=legs[kind]["value"], cores=legs[kind]["cores"], kind=kind,
+               one_thread=legs[kind]["one_thread"]["value"])
+    out.update(legs)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# single GPU
+# ---------------------------------------------------------------------------------------------------------------
+def _timed(ctx, dt, steps):
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.step(dt, steps)
+    ctx.sync()
+    return time.perf_counter() - t0
+
+
+def _phases(ctx, dt, steps):
+    ctx.timing(True); ctx.timing_reset()
+    ctx.step(dt, steps)
+    ctx.sync()
+    ph, nst = ctx.timing_get()
+    ctx.timing(False)
+    return {k: v / max(nst, 1) for k, v in ph.items()}
 
 
 def run_single(args):
     cfg = ic.CONFIGS[args.workload]
     n = cfg["lattice"][0] * cfg["lattice"][1] * cfg["lattice"][2]
-    ctx = capi.Context(n, box=cfg["box"], grid=cfg["grid"], device=0)
-    ctx.reset_lattice(cfg["lattice"], jitter=True)        # synthetic data generated in HBM (== ic.dam_break_lattice)
     dt = float(ic.DEFAULT_DT)
-    ctx.step(dt, args.warmup)
-    ctx.sync()
-    # timed region: K steps, state resident in HBM, one sync on either side
+    ctx = capi.Context(n, box=cfg["box"], grid=cfg["grid"], device=0)
+    res = {"n": n, "cfg": cfg}
+
+    # ---- state preparation: the dam after R steps (on the device, not timed) -----------------------------------
+    ctx.reset_lattice(cfg["lattice"], jitter=True)        # synthetic data generated in HBM (== ic.dam_break_lattice)
     t0 = time.perf_counter()
-    ctx.step(dt, args.steps)
-    ctx.sync()
-    wall = time.perf_counter() - t0
-    # per-phase device times (HIP events on the library's stream) from a second, instrumented run
-    ctx.timing(True); ctx.timing_reset()
-    ctx.step(dt, args.steps)
-    ctx.sync()
-    ph, nst = ctx.timing_get()
-    ctx.timing(False)
-    phases_ms = {k: v / max(nst, 1) for k, v in ph.items()}
-    st = ctx.download(want=("density",))
-    ok = bool(np.isfinite(st["density"]).all())
-    stats = ctx.sort_stats()                              # sorts, merges, skips (no particle changed cell), movers
-    # The dam starts at rest and dt = 5e-7: for the first steps no particle crosses a cell face, and the library
-    # then leaves the (unchanged) order alone.  --moving adds, for the record, the same particles once they DO move: a
-    # random velocity field and 120 steps of run-up, until ~1e5 particles change cell per step (never the headline number).
-    # (--moving only: the extra launches would otherwise blur the per-kernel averages of a rocprofv3 run of this command)
-    if args.moving:
-        rng = np.random.default_rng(7)
-        ctx.set_by_index(0, vel=rng.uniform(-20.0, 20.0, (n, 3)).astype(np.float32))
-        ctx.step(1e-5, 120)
-        ctx.sync()
-        t0 = time.perf_counter()
-        ctx.step(1e-5, 10)
-        ctx.sync()
-        moving = {"ms_per_step": (time.perf_counter() - t0) / 10 * 1e3, "dt": 1e-5}
-        after = ctx.sort_stats()
-        moving.update(movers_last_step=after["last_movers"], skips=after["skips"] - stats["skips"],
-                      note="same C3 particles after a random +-20 velocity kick and 120 steps: off-lattice, ~1 % of them "
-                           "change cell per step (merge path), more collision partners -- a different, heavier workload")
-        stats["with_movers"] = moving
-    phases_ms["_sort_stats"] = stats
+    left = args.runup
+    while left > 0:                                       # in pieces: a progress line per piece on stderr
+        k = min(left, 2000)
+        ctx.step(dt, k); ctx.sync()
+        left -= k
+        print(f"[bench] run-up {args.runup - left}/{args.runup} steps, {time.perf_counter() - t0:.1f} s", file=sys.stderr,
+              flush=True)
+    res["runup_s"] = time.perf_counter() - t0
+
+    # ---- the headline: W warm-up + K timed steps of the flowing dam ------------------------------------------------
+    ctx.step(dt, args.warmup)
+    s0 = ctx.sort_stats()
+    res["wall"] = _timed(ctx, dt, args.steps)
+    s1 = ctx.sort_stats()
+    res["sort"] = {"sorts": s1["sorts"] - s0["sorts"], "merges": s1["merges"] - s0["merges"],
+                   "skips": s1["skips"] - s0["skips"],
+                   "movers_per_step": (s1["movers_total"] - s0["movers_total"]) / max(args.steps, 1),
+                   "last_movers": s1["last_movers"]}
+    # per-phase device times (HIP events on the library's stream) from a second, instrumented pass over the same regime
+    res["phases_ms"] = _phases(ctx, dt, args.steps)
+    st = ctx.download(want=("density", "vel"))
+    res["finite"] = bool(np.isfinite(st["density"]).all() and np.isfinite(st["vel"]).all())
+    res["vmax"] = float(np.abs(st["vel"]).max())
+    del st
+
+    # ---- the same flowing state with the full radix sort every step --------------------------------------------------
+    ctx.set_sort_mode(merge=False)
+    ctx.step(dt, min(args.warmup, 3))
+    res["wall_full_sort"] = _timed(ctx, dt, args.steps)
+    res["phases_ms_full_sort"] = _phases(ctx, dt, min(args.steps, 20))
+    ctx.set_sort_mode(merge=True)
+
+    # ---- the dam at rest (first steps after the reset: nothing changes cell) ----------------------------------------------
+    ctx.reset_lattice(cfg["lattice"], jitter=True)
+    ctx.step(dt, args.warmup)
+    r0 = ctx.sort_stats()
+    res["wall_rest"] = _timed(ctx, dt, args.steps)
+    r1 = ctx.sort_stats()
+    res["sort_rest"] = {"sorts": r1["sorts"] - r0["sorts"], "skips": r1["skips"] - r0["skips"],
+                        "movers_per_step": (r1["movers_total"] - r0["movers_total"]) / max(args.steps, 1)}
+    res["phases_ms_rest"] = _phases(ctx, dt, min(args.steps, 20))
     ctx.close()
-    return n, wall, phases_ms, ok, cfg
+    return res
 
 
 def main():
@@ -137,11 +211,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)       # >= 20 warm-up, >= 100 timed steps
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="C3", choices=sorted(ic.CONFIGS))
+    ap.add_argument("--runup", type=int, default=None,
+                    help="steps of state preparation before the warm-up (default: 6000 for C3 -- a flowing dam)")
+    ap.add_argument("--workload", default="C3", choices=sorted(ic.CONFIGS) + ["C4"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="--gpus N > 1: weak = 16.7 M particles per GPU; strong = BASELINE config 4 (67,108,864 in total)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
-    ap.add_argument("--moving", action="store_true",
-                    help="also time the same particles after a velocity kick (particles changing cell every step)")
     args = ap.parse_args()
     rank, world, local = _dist_env()
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
@@ -154,30 +230,35 @@ def main():
     if args.gpus > 1 or world > 1 or args.force_slab:
         from gpufluidsimulator_amd import slab
         return slab.bench_main(args)
+    if args.workload == "C4":
+        sys.exit("--workload C4 is the multi-GPU configuration: use --gpus N --scaling strong")
+    if args.runup is None:
+        args.runup = DEFAULT_RUNUP[args.workload]
 
-    n, wall, phases_ms, ok, cfg = run_single(args)
-    sort_stats = phases_ms.pop("_sort_stats")
-    value = n * args.steps / wall
-    t_force = phases_ms["force"] * 1e-3
-    t_dens = phases_ms["dens"] * 1e-3
-    fbytes = BYTES_PER_PARTICLE["force_fused"] * n
-    achieved = fbytes / t_force / 1e9
+    r = run_single(args)
+    n, cfg, phases_ms = r["n"], r["cfg"], r["phases_ms"]
+    value = n * args.steps / r["wall"]
+    t_force, t_dens, t_sort = phases_ms["force"] * 1e-3, phases_ms["dens"] * 1e-3, phases_ms["sort"] * 1e-3
+    achieved = BYTES_PER_PARTICLE["force_fused"] * n / t_force / 1e9
     traffic = None
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
             pj = json.load(open(prof))
-            if pj.get("workload") == args.workload:
+            if pj.get("workload") == args.workload and pj.get("state") == "flow":
                 traffic = pj.get("force_fused_hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    flow_ok = r["sort"]["skips"] == 0 and r["sort"]["movers_per_step"] >= 1e-4 * n
     out = {
         "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["wall"] / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"dam-break {args.workload}: {cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} "
-                               f"= {n} particles, grid {cfg['grid'][0]}^3, box {cfg['box'][0]}, dt 5e-7, jittered lattice",
-                   "particles": n, "grid": list(cfg["grid"]), "parallelism": "1 GPU, whole domain"},
+                               f"= {n} particles, grid {cfg['grid'][0]}^3, box {cfg['box'][0]}, dt 5e-7, jittered lattice, "
+                               f"FLOWING: timed after {args.runup} run-up steps on the device (+{args.warmup} warm-up)",
+                   "particles": n, "grid": list(cfg["grid"]), "parallelism": "1 GPU, whole domain",
+                   "state": "flow", "runup_steps": args.runup, "runup_seconds": r["runup_s"]},
         "roofline": {"bound": "hbm", "kernel": "k_force<force+collision+integrate>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_particle": BYTES_PER_PARTICLE["force_fused"],
@@ -187,15 +268,25 @@ def main():
                               "peak_tflops": VALU_PEAK_TFLOPS,
                               "frac": FLOP_PER_PARTICLE["force_fused"] * n / t_force / 1e12 / VALU_PEAK_TFLOPS},
                      "density_kernel": {"achieved": BYTES_PER_PARTICLE["dens"] * n / t_dens / 1e9, "unit": "GB/s",
+                                        "frac": BYTES_PER_PARTICLE["dens"] * n / t_dens / 1e9 / HBM_PEAK_GBS,
                                         "avg_launch_ms": phases_ms["dens"],
-                                        "valu_tflops": FLOP_PER_PARTICLE["dens"] * n / t_dens / 1e12}},
-        "phases_ms": phases_ms, "sort": sort_stats, "finite": ok,
+                                        "valu_tflops": FLOP_PER_PARTICLE["dens"] * n / t_dens / 1e12},
+                     "sort_phase": {"achieved": BYTES_PER_PARTICLE["sort_merge"] * n / max(t_sort, 1e-9) / 1e9,
+                                    "unit": "GB/s", "avg_ms": phases_ms["sort"],
+                                    "frac": BYTES_PER_PARTICLE["sort_merge"] * n / max(t_sort, 1e-9) / 1e9 / HBM_PEAK_GBS}},
+        "phases_ms": phases_ms, "sort": r["sort"], "flowing": flow_ok, "finite": r["finite"], "vmax": r["vmax"],
+        "value_full_sort": n * args.steps / r["wall_full_sort"],
+        "ms_per_step_full_sort": r["wall_full_sort"] / args.steps * 1e3, "phases_ms_full_sort": r["phases_ms_full_sort"],
+        "value_at_rest": n * args.steps / r["wall_rest"], "ms_per_step_at_rest": r["wall_rest"] / args.steps * 1e3,
+        "phases_ms_at_rest": r["phases_ms_rest"], "sort_at_rest": r["sort_rest"],
     }
     if not args.no_cpu:
         cb = cpu_baseline()
         out["cpu_baseline"] = cb
         out["gpu_over_cpu"] = value / cb["value"]
     print(json.dumps(out), flush=True)
+    if not flow_ok:
+        sys.exit("bench: the timed window was not a flowing state (sort skipped or too few particles changed cell)")
 
 
 if __name__ == "__main__":

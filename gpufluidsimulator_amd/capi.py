@@ -37,6 +37,8 @@ SIGNATURES = {
     "sph_abi_version": (C.c_int, []),
     "sph_last_error": (C.c_char_p, []),
     "sph_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sph_select_device": (C.c_int, [C.c_int]),
+    "sph_selected_device": (C.c_int, []),
     "sph_default_params": (None, [C.POINTER(Params), C.POINTER(C.c_float), C.POINTER(_U32)]),
     "sph_grid_dim_for_edge": (_U32, [C.c_float, C.c_float]),
     "sph_create": (C.c_int, [C.POINTER(_P), C.c_int, _U32, C.POINTER(Params)]),
@@ -51,9 +53,9 @@ SIGNATURES = {
     "sph_upload": (C.c_int, [_P, _U32, _P, _P, _P]),
     "sph_set_by_index": (C.c_int, [_P, _U32, _U32, C.c_void_p, C.c_void_p]),
     "sph_reset_lattice": (C.c_int, [_P, C.POINTER(_U32), C.c_int, C.POINTER(C.c_float), C.c_uint64, _U32]),
-    "sph_download": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
+    "sph_download": (C.c_int, [_P, _U32, _U32, _P, _P, _P, _P]),
     "sph_download_owned": (C.c_int, [_P, _P, _P, _P]),
-    "sph_download_forces": (C.c_int, [_P, _U32, _P, _P, _P, _P]),
+    "sph_download_forces": (C.c_int, [_P, _U32, _U32, _P, _P, _P, _P]),
     "sph_snapshot_save": (C.c_int, [_P, C.c_char_p]),
     "sph_snapshot_load": (C.c_int, [_P, C.c_char_p]),
     "sph_snapshot_info": (C.c_int, [C.c_char_p, C.POINTER(_U32), C.POINTER(Params)]),
@@ -78,7 +80,9 @@ SIGNATURES = {
     "sph_timing_get": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(_U32)]),
     "sph_timing_reset": (C.c_int, [_P]),
     "sph_last_sort_skipped": (C.c_int, [_P]),
-    "sph_sort_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "sph_sort_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                 C.POINTER(C.c_uint64)]),
+    "sph_set_sort_mode": (C.c_int, [_P, C.c_int]),
     "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_slab_counts": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_migrants_pack": (C.c_int, [_P, C.POINTER(_P), _U32]),
@@ -118,7 +122,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.sph_abi_version() != 1:
+        if lib.sph_abi_version() != 2:
             raise SphError("libsph_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -227,7 +231,8 @@ class Context:
         for k in want:
             out[k] = np.full((count, 3) if k in ("pos", "vel") else (count,), np.nan, dtype=np.float32)
         ptr = lambda k: out[k].ctypes.data if k in out else None
-        _check(self.L.sph_download(self.h, int(index_base), ptr("pos"), ptr("vel"), ptr("density"), ptr("pressure")))
+        _check(self.L.sph_download(self.h, int(index_base), int(count), ptr("pos"), ptr("vel"), ptr("density"),
+                                   ptr("pressure")))
         return out
 
     def download_owned(self):
@@ -247,7 +252,8 @@ class Context:
             out["dv"] = np.full((count, 3), np.nan, dtype=np.float32)
             out["count"] = np.full((count,), -1, dtype=np.int32)
         ptr = lambda k: out[k].ctypes.data if k in out else None
-        _check(self.L.sph_download_forces(self.h, int(index_base), ptr("fpress"), ptr("fvisc"), ptr("dv"), ptr("count")))
+        _check(self.L.sph_download_forces(self.h, int(index_base), int(count), ptr("fpress"), ptr("fvisc"), ptr("dv"),
+                                          ptr("count")))
         return out
 
     def save(self, path):
@@ -321,10 +327,15 @@ class Context:
         return bool(self.L.sph_last_sort_skipped(self.h))
 
     def sort_stats(self):
-        """{'sorts', 'merges', 'skips', 'last_movers'}: how often the sort took the merge path (see sph_hip.h)."""
-        a, b, k, m = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
-        _check(self.L.sph_sort_stats(self.h, C.byref(a), C.byref(b), C.byref(k), C.byref(m)))
-        return {"sorts": a.value, "merges": b.value, "skips": k.value, "last_movers": m.value}
+        """{'sorts', 'merges', 'skips', 'last_movers', 'movers_total'}: how often the sort took the merge path and
+        how many particles changed cell (see sph_hip.h)."""
+        a, b, k, m, t = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()
+        _check(self.L.sph_sort_stats(self.h, C.byref(a), C.byref(b), C.byref(k), C.byref(m), C.byref(t)))
+        return {"sorts": a.value, "merges": b.value, "skips": k.value, "last_movers": m.value, "movers_total": t.value}
+
+    def set_sort_mode(self, merge=True):
+        """merge=False: full radix sort every step (the SPH_SORT_MERGE=0 behaviour)."""
+        _check(self.L.sph_set_sort_mode(self.h, 1 if merge else 0))
 
     def timing_get(self):
         ms = (C.c_float * len(PHASES))()

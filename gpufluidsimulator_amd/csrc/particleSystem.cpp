@@ -85,6 +85,9 @@ extern "C" void sph_ic_random_box(uint64_t n, const float box[3], float speed, u
 
 // ---- lifetime (particleSystem.cpp:38-71, 108-190) ----------------------------------------------------
 ParticleSystem::ParticleSystem(uint numParticles, float3 boxDims, ParticleComputeMode mode)
+    : ParticleSystem(numParticles, boxDims, mode, uint3{0u, 0u, 0u}) {}
+
+ParticleSystem::ParticleSystem(uint numParticles, float3 boxDims, ParticleComputeMode mode, uint3 gridDims)
     : m_bInitialized(false), m_numParticles(numParticles), m_boxDims(boxDims), m_solverIterations(1),
       m_compute_mode(mode), m_ctx(nullptr), m_hostStale(false), m_log(nullptr), m_logLastMs(0), m_logGlobalMs(0), m_logFreqMs(2000.0) {
     if (mode != CUDA_PARALLEL) {
@@ -92,9 +95,9 @@ ParticleSystem::ParticleSystem(uint numParticles, float3 boxDims, ParticleComput
                         "(SEQUENTIAL / OMP_PARALLEL are the reference's CPU paths; there is no CPU fallback)\n");
         exit(EXIT_FAILURE);
     }
-    m_grid.x = next_pow2((uint)(boxDims.x / (0.66666f * kH)));   // particleSystem.cpp:46, per axis
-    m_grid.y = next_pow2((uint)(boxDims.y / (0.66666f * kH)));
-    m_grid.z = next_pow2((uint)(boxDims.z / (0.66666f * kH)));
+    m_grid.x = gridDims.x ? gridDims.x : next_pow2((uint)(boxDims.x / (0.66666f * kH)));   // particleSystem.cpp:46, per axis
+    m_grid.y = gridDims.y ? gridDims.y : next_pow2((uint)(boxDims.y / (0.66666f * kH)));
+    m_grid.z = gridDims.z ? gridDims.z : next_pow2((uint)(boxDims.z / (0.66666f * kH)));
     m_params.particleRadius = kRadius;                            // particleSystem.cpp:51-62
     m_params.colliderPos = make_float3(-1.2f, -0.8f, 0.8f);
     m_params.gravity = make_float3(0.f, 0.f, 0.f);
@@ -119,7 +122,7 @@ void ParticleSystem::_initialize(int numParticles) {
     const float box[3] = {m_boxDims.x, m_boxDims.y, m_boxDims.z};
     const uint32_t grid[3] = {m_grid.x, m_grid.y, m_grid.z};
     sph_default_params(&p, box, grid);
-    SPH_CHECK(sph_create(&m_ctx, 0, m_numParticles ? m_numParticles : 1, &p));
+    SPH_CHECK(sph_create(&m_ctx, -1, m_numParticles ? m_numParticles : 1, &p));   // -1: sph_select_device's choice
     m_bInitialized = true;
 }
 
@@ -145,7 +148,7 @@ void ParticleSystem::downloadAll() {
     if (!m_hostStale) return;
     const size_t n = m_numParticles;
     m_xyz.resize(n * 3); m_vxyz.resize(n * 3); m_hDens.resize(n);
-    SPH_CHECK(sph_download(m_ctx, 0, m_xyz.data(), m_vxyz.data(), m_hDens.data(), nullptr));
+    SPH_CHECK(sph_download(m_ctx, 0, (uint32_t)n, m_xyz.data(), m_vxyz.data(), m_hDens.data(), nullptr));
     for (size_t i = 0; i < n; i++) {
         for (int a = 0; a < 3; a++) { m_hPos[4 * i + a] = m_xyz[3 * i + a]; m_hVel[4 * i + a] = m_vxyz[3 * i + a]; }
         m_hPos[4 * i + 3] = 1.0f;

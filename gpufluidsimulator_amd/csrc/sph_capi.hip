@@ -12,6 +12,7 @@
 namespace sph {
 
 static thread_local std::string g_err;
+static int g_device = 0;        // sph_select_device: what `device < 0` means in sph_create
 
 void set_error(const char* fmt, ...) {
     char buf[512];
@@ -104,7 +105,8 @@ static void free_all(sph_ctx* c) {
     hipFree(c->k0); hipFree(c->v0); hipFree(c->k1); hipFree(c->v1); hipFree(c->hist); hipFree(c->digit_tot);
     hipFree(c->d_scratch);
     hipFree(c->mm_mask); hipFree(c->mm_M64); hipFree(c->mm_tile_cnt); hipFree(c->mm_tile_off);
-    hipFree(c->mm_k0); hipFree(c->mm_k1); hipFree(c->mm_v1); hipFree(c->mm_count);
+    hipFree(c->mm_k0); hipFree(c->mm_k1); hipFree(c->mm_v1); hipFree(c->mm_count); hipFree(c->mm_total);
+    if (c->mm_counted) hipEventDestroy(c->mm_counted);
     if (c->mm_count_host) hipHostFree(c->mm_count_host);
     for (hipEvent_t e : c->mm_done) if (e) hipEventDestroy(e);
     if (c->h_scratch) hipHostFree(c->h_scratch);
@@ -121,7 +123,8 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
         set_error("no HIP device available (%s): libsph_hip has no CPU fallback", hipGetErrorString(e));
         return SPH_E_DEVICE;
     }
-    SPH_REQUIRE(device >= 0 && device < ndev, SPH_E_DEVICE, "device %d out of range (%d devices)", device, ndev);
+    if (device < 0) device = g_device;       // the device chosen with sph_select_device (default 0)
+    SPH_REQUIRE(device < ndev, SPH_E_DEVICE, "device %d out of range (%d devices)", device, ndev);
     SPH_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     SPH_HIP(hipGetDeviceProperties(&prop, device));
@@ -176,6 +179,11 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
         if (!rc) rc = dev_alloc(&c->mm_k1, (size_t)capacity);
         if (!rc) rc = dev_alloc(&c->mm_v1, (size_t)capacity);
         if (!rc) rc = dev_alloc(&c->mm_count, (size_t)1);
+        if (!rc) rc = dev_alloc(&c->mm_total, (size_t)1);
+        if (!rc && hipEventCreateWithFlags(&c->mm_counted, hipEventDisableTiming) != hipSuccess) {
+            set_error("hipEventCreate failed");
+            rc = SPH_E_DEVICE;
+        }
         if (!rc && (hipHostMalloc((void**)&c->mm_count_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
                     hipHostGetDevicePointer((void**)&c->mm_count_host_dev, c->mm_count_host, 0) != hipSuccess)) {
             set_error("hipHostMalloc(mapped) failed");
@@ -189,7 +197,8 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
         if (!rc) {
             *c->mm_count_host = 0;
             if (hipMemset(c->mm_tile_cnt, 0, ntiles * sizeof(uint32_t)) != hipSuccess ||
-                hipMemset(c->mm_count, 0, sizeof(uint32_t)) != hipSuccess) {
+                hipMemset(c->mm_count, 0, sizeof(uint32_t)) != hipSuccess ||
+                hipMemset(c->mm_total, 0, sizeof(unsigned long long)) != hipSuccess) {
                 set_error("hipMemset failed");
                 rc = SPH_E_DEVICE;
             }
@@ -341,6 +350,25 @@ int sph_device_count(int* is_gfx950) {
     }
     return n;
 }
+
+int sph_select_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s): libsph_hip has no CPU fallback", hipGetErrorString(e));
+        return SPH_E_DEVICE;
+    }
+    SPH_REQUIRE(device >= 0 && device < n, SPH_E_DEVICE, "device %d out of range (%d devices)", device, n);
+    hipDeviceProp_t prop;
+    SPH_HIP(hipGetDeviceProperties(&prop, device));
+    SPH_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, SPH_E_DEVICE,
+                "device %d is %s; libsph_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    SPH_HIP(hipSetDevice(device));
+    g_device = device;
+    return SPH_OK;
+}
+
+int sph_selected_device(void) { return g_device; }
 
 void sph_default_params(sph_params* p, const float box_dims[3], const uint32_t grid[3]) {
     memset(p, 0, sizeof(*p));
@@ -532,14 +560,19 @@ static int fetch_sorted(sph_ctx* c, std::vector<float4>* hp, std::vector<float4>
 
 static inline uint32_t idx_of(const float4& p) { uint32_t u; memcpy(&u, &p.w, 4); return u; }
 
-int sph_download(sph_ctx* c, uint32_t base, float* pos, float* vel, float* density, float* pressure) {
+// Particles whose creation index lies outside [base, base + count) are not written: the caller's arrays hold
+// `count` entries and nothing beyond them is touched (an index below `base` wraps to a huge offset and fails
+// the same test).
+int sph_download(sph_ctx* c, uint32_t base, uint32_t count, float* pos, float* vel, float* density, float* pressure) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     std::vector<float4> hp, hv;
     std::vector<float2> hd;
     int rc = fetch_sorted(c, &hp, vel ? &hv : nullptr, (density || pressure) ? &hd : nullptr);
     if (rc) return rc;
     for (uint32_t s = 0; s < c->n; s++) {
-        size_t i = (size_t)(idx_of(hp[s]) - base);
+        const uint32_t rel = idx_of(hp[s]) - base;
+        if (rel >= count) continue;
+        const size_t i = rel;
         if (pos) { pos[3 * i] = hp[s].x; pos[3 * i + 1] = hp[s].y; pos[3 * i + 2] = hp[s].z; }
         if (vel) { vel[3 * i] = hv[s].x; vel[3 * i + 1] = hv[s].y; vel[3 * i + 2] = hv[s].z; }
         if (density) density[i] = hd[s].x;
@@ -561,7 +594,7 @@ int sph_download_owned(sph_ctx* c, float* pos, float* vel, uint32_t* index) {
     return SPH_OK;
 }
 
-int sph_download_forces(sph_ctx* c, uint32_t base, float* fp, float* fv, float* dv, int32_t* count) {
+int sph_download_forces(sph_ctx* c, uint32_t base, uint32_t n_out, float* fp, float* fv, float* dv, int32_t* count) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     SPH_REQUIRE((!fp && !fv) || c->have_force, SPH_E_STATE, "sph_force has not run for this particle order");
     SPH_REQUIRE((!dv && !count) || c->have_coll, SPH_E_STATE, "sph_collide has not run for this particle order");
@@ -576,7 +609,9 @@ int sph_download_forces(sph_ctx* c, uint32_t base, float* fp, float* fv, float* 
     }
     if (n && (dv || count)) SPH_HIP(hipMemcpy(d.data(), c->dvel + c->own_off, n * sizeof(float4), hipMemcpyDeviceToHost));
     for (uint32_t s = 0; s < n; s++) {
-        size_t i = (size_t)(idx_of(hp[s]) - base);
+        const uint32_t rel = idx_of(hp[s]) - base;
+        if (rel >= n_out) continue;
+        const size_t i = rel;
         if (fp) { fp[3 * i] = a[s].x; fp[3 * i + 1] = a[s].y; fp[3 * i + 2] = a[s].z; }
         if (fv) { fv[3 * i] = b[s].x; fv[3 * i + 1] = b[s].y; fv[3 * i + 2] = b[s].z; }
         if (dv) { dv[3 * i] = d[s].x; dv[3 * i + 1] = d[s].y; dv[3 * i + 2] = d[s].z; }
@@ -640,6 +675,16 @@ int sph_snapshot_load(sph_ctx* c, const char* path) {
     if (rc) return rc;
     std::vector<float> pos((size_t)n * 3), vel((size_t)n * 3);
     std::vector<uint32_t> idx(n);
+    if (!c->slab) {
+        // a whole-domain snapshot numbers its particles 0..n-1, each once: a file that says otherwise is
+        // corrupt (external input -- every by-index buffer of the host class is sized from n)
+        std::vector<bool> seen(n, false);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t k = idx_of(hp[i]);
+            SPH_REQUIRE(k < n && !seen[k], SPH_E_INVALID, "%s: creation index %u of record %u is out of range or repeated", path, k, i);
+            seen[k] = true;
+        }
+    }
     for (uint32_t i = 0; i < n; i++) {
         pos[3 * i] = hp[i].x; pos[3 * i + 1] = hp[i].y; pos[3 * i + 2] = hp[i].z;
         vel[3 * i] = hv[i].x; vel[3 * i + 1] = hv[i].y; vel[3 * i + 2] = hv[i].z;
@@ -875,10 +920,22 @@ int sph_timing_reset(sph_ctx* c) {
 
 int sph_last_sort_skipped(const sph_ctx* c) { return c && c->last_sort_skipped ? 1 : 0; }
 
-int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers) {
+int sph_set_sort_mode(sph_ctx* c, int merge) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    c->sort_merge = merge != 0;
+    return SPH_OK;
+}
+
+int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers,
+                   uint64_t* movers_total) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     SPH_HIP(hipSetDevice(c->device));
     SPH_HIP(hipStreamSynchronize(c->stream));
+    if (movers_total) {
+        unsigned long long t = 0;
+        SPH_HIP(hipMemcpy(&t, c->mm_total, sizeof(t), hipMemcpyDeviceToHost));
+        *movers_total = t;
+    }
     if (sorts) *sorts = c->sort_calls;
     if (merges) *merges = c->sort_merges;
     if (skips) *skips = c->sort_skips;

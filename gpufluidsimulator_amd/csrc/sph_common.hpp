@@ -106,7 +106,9 @@ struct sph_ctx {
     uint32_t* mm_count = nullptr;           // movers of the current sort (device)
     uint32_t* mm_count_host = nullptr;      // pinned, written by the device: last known count (a hint)
     uint32_t* mm_count_host_dev = nullptr;  // device view of the same word
+    unsigned long long* mm_total = nullptr; // movers of all sorts so far (device; sph_sort_stats)
     hipEvent_t mm_done[4] = {nullptr, nullptr, nullptr, nullptr};   // end of the last four sorts: bounds the host's run-ahead
+    hipEvent_t mm_counted = nullptr;        // after the mover count of the current sort (queried, never waited for)
     // the fused integrate epilogue already wrote mm_mask / mm_tile_cnt for the range it was launched on
     bool mm_marked = false;
     uint32_t mm_marked_off = 0, mm_marked_n = 0;

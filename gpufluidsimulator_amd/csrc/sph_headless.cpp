@@ -1,7 +1,10 @@
 // sph_headless.cpp -- headless driver with the reference's command line
 // (SPH/particles.cpp:676-706: -n= -box= -i= -benchmark -device=) and its runBenchmark()
 // output line (:176-192), on top of include/particleSystem.h.  No GLUT / OpenGL.
-//   sph_headless -benchmark -n=262144 -box=8 -i=100 [-steps=1] [-dump=8] [-log=benchmark.txt]
+//   sph_headless -benchmark -n=262144 -box=8 -i=100 [-device=0] [-grid=128] [-ic=grid|random] [-steps=1] [-dump=8]
+//                [-log=benchmark.txt]
+// Several GPUs: one process per GPU (z-slabs, RCCL) -- `python bench.py --gpus N`; this driver is the
+// reference's single-device program.
 #include "../../include/particleSystem.h"
 
 #include <chrono>
@@ -40,9 +43,23 @@ int main(int argc, char** argv) {
     if (const char* v = value(argc, argv, "i")) iterations = atoi(v);
     if (const char* v = value(argc, argv, "steps")) substeps = atoi(v);
     if (const char* v = value(argc, argv, "dump")) dump = atoi(v);
+    int device = 0;                        // findCudaDevice: -device=N, else the first device (helper_cuda.h:845)
+    if (const char* v = value(argc, argv, "device")) device = atoi(v);
+    uint gridDim = 0;                      // 0: the reference's formula nextPow2(box / (0.66666 h))
+    if (const char* v = value(argc, argv, "grid")) gridDim = (uint)strtoul(v, nullptr, 10);
+    ParticleSystem::ParticleConfig ic = ParticleSystem::CONFIG_GRID;   // initParticleSystem resets to CONFIG_GRID
+    if (const char* v = value(argc, argv, "ic")) {
+        if (!strcmp(v, "random")) ic = ParticleSystem::CONFIG_RANDOM;
+        else if (strcmp(v, "grid")) { fprintf(stderr, "-ic=%s: expected grid or random\n", v); return EXIT_FAILURE; }
+    }
+    if (value(argc, argv, "gpus") && atoi(value(argc, argv, "gpus")) > 1) {
+        fprintf(stderr, "-gpus=N>1: one process per GPU -- launch `python bench.py --gpus N` (z-slabs over RCCL)\n");
+        return EXIT_FAILURE;
+    }
     const bool benchmark = flag(argc, argv, "benchmark");
     if (flag(argc, argv, "help")) {
-        printf("usage: sph_headless [-benchmark] [-n=<particles>] [-box=<edge>] [-i=<iterations>] [-steps=<per update>] "
+        printf("usage: sph_headless [-benchmark] [-n=<particles>] [-box=<edge>] [-i=<iterations>] [-device=<id>] [-grid=<cells per axis>] "
+               "[-ic=grid|random] [-steps=<per update>] "
                "[-dump=<count>] [-log=<file>] [-sphere=<update>[,<radius>]] [-out=<file>] [-save=<file>] [-load=<file>]\n");
         return 0;
     }
@@ -51,9 +68,17 @@ int main(int argc, char** argv) {
         fprintf(stderr, "No gfx950 (MI355X) device found, exiting\n");   // cudaInit, particleSystem.cu:432-435
         return EXIT_FAILURE;
     }
-    ParticleSystem* psystem = new ParticleSystem(numParticles, make_float3(box, box, box), ParticleSystem::HIP_PARALLEL);
-    psystem->reset(ParticleSystem::CONFIG_GRID);          // initParticleSystem, particles.cpp:119-132
-    if (const char* v = value(argc, argv, "load")) psystem->loadState(v);
+    if (sph_select_device(device) < 0) {                  // cudaInit -> findCudaDevice -> cudaSetDevice
+        fprintf(stderr, "-device=%d: %s\n", device, sph_last_error());
+        return EXIT_FAILURE;
+    }
+    ParticleSystem* psystem = new ParticleSystem(numParticles, make_float3(box, box, box), ParticleSystem::HIP_PARALLEL,
+                                                 uint3{gridDim, gridDim, gridDim});
+    psystem->reset(ic);                                   // initParticleSystem, particles.cpp:119-132
+    if (const char* v = value(argc, argv, "load")) {
+        psystem->loadState(v);
+        numParticles = (uint)psystem->getNumParticles();  // the snapshot decides how many particles there are
+    }
     psystem->setIterations(substeps);
     if (const char* v = value(argc, argv, "log")) {
         const char* fq = value(argc, argv, "logfreq");

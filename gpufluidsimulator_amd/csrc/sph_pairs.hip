@@ -182,6 +182,11 @@ constexpr int UNROLL = 4;        // density: candidates per unrolled group
 #ifndef SPH_FORCE_UNROLL
 #define SPH_FORCE_UNROLL 2
 #endif
+// 1: the collision impulse uses sqrtf and a true division like the reference (dot / (dij * dij)); 0: one v_rcp_f32
+// of r2 (1 ulp).  The PREDICATES are exact either way; this only moves the last bit of the impulse (A/B in DESIGN 4).
+#ifndef SPH_COLL_EXACT_DIV
+#define SPH_COLL_EXACT_DIV 0
+#endif
 
 // Per-row hulls of the wave's candidate ranges (wave-uniform).
 struct Hulls {
@@ -377,9 +382,13 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     const float cps = ph.spiky_half_mass / ph.visc_coef;   // pressure coefficient relative to the viscous one
     const float cpi = cps * dpi.y;
     const float h_v = in_vgpr(ph.h);
-    // d <= 2R  <=>  r2 - next_up(coll_dist2) < 0: the sign bit of one subtraction, shifted into the mask by one
-    // v_alignbit -- two all-VGPR instructions (a compare + add-with-carry goes through an SGPR pair)
-    const float coll_next_v = in_vgpr(__uint_as_float(__float_as_uint(ph.coll_dist2) + 1u));
+    // Collision range, two stages.  The candidate loop only needs a cheap SUPERSET: its r2 comes out of three
+    // fused multiply-adds and differs from the reference's x*x + (y*y + z*z) by a few ulps, so the mask bit is
+    // the sign of r2 - (coll_dist2 + 8 ulps), shifted in by one v_alignbit (two all-VGPR instructions; a compare
+    // + add-with-carry goes through an SGPR pair).  The EXACT predicate of computeCollision -- the reference's r2
+    // in the reference's operation order, unfused, against the exact threshold coll_dist2 (see derive()) -- is
+    // applied to the few masked candidates in the drain loop below.
+    const float coll_next_v = in_vgpr(__uint_as_float(__float_as_uint(ph.coll_dist2) + 8u));
     float fpx = 0.f, fpy = 0.f, fpz = 0.f, fvx = 0.f, fvy = 0.f, fvz = 0.f;
     float cvx = 0.f, cvy = 0.f, cvz = 0.f;
     uint32_t ccount = 0;
@@ -478,12 +487,26 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                             const float2 qa = e[0], qb = e[1], qc = e[2];
                             const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
                             const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;
-                            const float r2c = dx * dx + dy * dy + dz * dz;
-                            const float dot = -(dx * ux + dy * uy + dz * uz);           // r_ij . (v_i - v_j)
+                            // computeCollision (particleSystem.cu:52-65) decides on dij = sqrtf(rij.squaredNorm()) <= 2R
+                            // and rij.dot(vij) < 0, Eigen reducing a 3-vector as a0 + (a1 + a2) with one rounding per
+                            // operation.  Both predicates are evaluated exactly that way (no contraction), so that on
+                            // identical inputs the same pairs collide as in the reference: sqrtf is monotone, hence
+                            // dij <= 2R  <=>  r2 <= coll_dist2 (the largest float whose root is <= 2R, derive()).
                             // j == i needs no test: r_ij = 0 gives r.v = -0, which is not < 0 (the reference skips
-                            // the pair by index, particleSystem.cu:54; a coincident pair fails r.v < 0 there too)
-                            const bool hit = dot < 0.f;
+                            // the pair by index, :54; a coincident pair fails r.v < 0 there too).
+                            float r2c, dot;
+                            {
+#pragma clang fp contract(off)
+                                r2c = dx * dx + (dy * dy + dz * dz);
+                                dot = -(dx * ux + (dy * uy + dz * uz));                 // r_ij . (v_i - v_j)
+                            }
+                            const bool hit = r2c <= ph.coll_dist2 && dot < 0.f;
+#if SPH_COLL_EXACT_DIV
+                            float cfac = 0.f;
+                            if (hit) { const float dij = sqrtf(r2c); cfac = ph.coll_mass * (dot / (dij * dij)); }
+#else
                             const float cfac = hit ? ph.coll_mass * dot * __builtin_amdgcn_rcpf(r2c) : 0.f;
+#endif
                             cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
                             ccount += hit ? 1u : 0u;
                         }

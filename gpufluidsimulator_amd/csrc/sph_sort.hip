@@ -344,7 +344,8 @@ __global__ __launch_bounds__(256) void k_mm_mark(const uint32_t* __restrict__ A,
 // one block: exclusive scan of the per-tile mover counts; re-zeroes the counts for the next step
 __global__ __launch_bounds__(1024) void k_mm_tilescan(uint32_t* __restrict__ tile_cnt, uint32_t nt,
                                                       uint32_t* __restrict__ tile_off, uint32_t* __restrict__ m_dev,
-                                                      volatile uint32_t* __restrict__ m_host) {
+                                                      volatile uint32_t* __restrict__ m_host,
+                                                      unsigned long long* __restrict__ m_total) {
     __shared__ uint32_t part[1024];
     const uint32_t per = (nt + 1023u) / 1024u;
     const uint32_t lo = min(threadIdx.x * per, nt), hi = min(lo + per, nt);
@@ -365,7 +366,10 @@ __global__ __launch_bounds__(1024) void k_mm_tilescan(uint32_t* __restrict__ til
         tile_cnt[t] = 0;
         run += v;
     }
-    if (threadIdx.x == 1023) { *m_dev = part[1023]; *m_host = part[1023]; }
+    if (threadIdx.x == 1023) {
+        *m_dev = part[1023]; *m_host = part[1023];
+        if (m_total) *m_total += part[1023];          // one block: no atomic needed (sph_sort_stats: movers_total)
+    }
 }
 
 // thread per chunk: movers before the chunk (M64) and the stable list of movers (new key, slot)
@@ -470,16 +474,17 @@ static uint32_t merge_grid_for(uint32_t movers_hint, uint32_t n) {
     return min(want, ceil_div(n, SORT_TILE));
 }
 
-static void mm_tilescan(sph_ctx* c, uint32_t n) {
+// `counted`: the movers belong to a sort (they add to the running total), not to marks being dropped
+static void mm_tilescan(sph_ctx* c, uint32_t n, bool counted) {
     const uint32_t nt = ceil_div(ceil_div(n, 64u), MM_TILE_CHUNKS);
     hipLaunchKernelGGL(k_mm_tilescan, dim3(1), dim3(1024), 0, c->stream, c->mm_tile_cnt, nt, c->mm_tile_off, c->mm_count,
-                       c->mm_count_host_dev);
+                       c->mm_count_host_dev, counted ? c->mm_total : (unsigned long long*)nullptr);
 }
 
 // forget the marks the integrate epilogue left (the scan re-zeroes the tile counts they added to)
 void mm_drop_marks(sph_ctx* c) {
     if (!c->mm_marked) return;
-    mm_tilescan(c, c->mm_marked_n);
+    mm_tilescan(c, c->mm_marked_n, false);
     c->mm_marked = false;
 }
 
@@ -491,7 +496,7 @@ static void launch_merge_count(sph_ctx* c, uint32_t n) {
         hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, c->keyS + c->own_off, c->k0, n,
                            c->mm_mask, c->mm_tile_cnt);
     c->mm_marked = false;
-    mm_tilescan(c, n);
+    mm_tilescan(c, n, true);
 }
 
 static void launch_sort_merge(sph_ctx* c, uint32_t n, bool table_live, uint32_t*& ks, uint32_t*& vs) {
@@ -539,10 +544,12 @@ int launch_sort(sph_ctx* c) {
         if (was_still && table_live && c->own_off == c->gcap) {
             // Nothing moved last time (a fluid at rest: no particle crosses a cell face for many steps).  If that
             // is still so, the order, the keys and the cell table are already those of this step and the whole
-            // sort -- 0.3 ms of copying at C3 -- can be left out.  Only the device knows: wait for the count (the
-            // queue is empty at this point, the bubble is a launch latency) and look.
-            SPH_HIP(hipStreamSynchronize(c->stream));
-            if (*c->mm_count_host == 0u) {
+            // sort -- 0.3 ms of copying at C3 -- can be left out.  Only the device knows, and the host does not
+            // wait for it: the count is looked at only if the device has ALREADY produced it (a caller in
+            // lockstep with the device, e.g. one update() per frame); a host that runs ahead of the device
+            // queues the merge, which does the same job for 0 movers.  sph_step stays asynchronous.
+            SPH_HIP(hipEventRecord(c->mm_counted, c->stream));
+            if (hipEventQuery(c->mm_counted) == hipSuccess && *c->mm_count_host == 0u) {
                 c->sort_merges++;
                 c->sort_skips++;
                 c->last_sort_skipped = true;
@@ -563,11 +570,12 @@ int launch_sort(sph_ctx* c) {
         // keep the hint alive, or it would stay high for ever: for free when the integrate epilogue marked
         // the movers (the scan also re-zeroes the tile counts those marks added to), else every 8th sort
         if (c->mm_marked) {
-            mm_drop_marks(c);
+            mm_tilescan(c, c->mm_marked_n, true);
+            c->mm_marked = false;
         } else if (can_merge && (c->sort_calls & 7u) == 0) {
             hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, c->keyS + c->own_off, c->k0, n,
                                c->mm_mask, c->mm_tile_cnt);
-            mm_tilescan(c, n);
+            mm_tilescan(c, n, true);
         }
         radix_sort_pairs(c, n, nullptr, nblocks, true, kin, vin, kout, vout);
     }

@@ -49,12 +49,20 @@ def cell_layer_of(z, box_z, gz):
     return np.clip(np.floor(q).astype(np.int64), 0, int(gz) - 1)
 
 
+MIN_SLAB_LAYERS = 2
+
+
 def choose_cuts(hist, world):
-    """Count-balanced slab boundaries: cuts[r] .. cuts[r+1] are rank r's cell layers."""
+    """Count-balanced slab boundaries: cuts[r] .. cuts[r+1] are rank r's cell layers.
+
+    Every slab keeps at least MIN_SLAB_LAYERS = 2 layers: the halo protocol treats a slab's lowest and highest
+    layer as two different boundary layers (what arrives from below lands in the first, what arrives from above in
+    the second); with a one-layer slab they would be the same layer and a neighbour would be sent too few ghosts."""
     hist = np.asarray(hist, dtype=np.int64)
     gz, total = hist.shape[0], int(hist.sum())
-    if world > gz:
-        raise ValueError(f"{world} ranks but only {gz} cell layers")
+    m = MIN_SLAB_LAYERS if world > 1 else 1
+    if world * m > gz:
+        raise ValueError(f"{world} ranks need {m} cell layers each but the grid has only {gz}")
     prefix = np.concatenate([[0], np.cumsum(hist)])
     cuts = [0]
     for r in range(1, world):
@@ -63,10 +71,11 @@ def choose_cuts(hist, world):
         # the boundary that splits the counts best: z or z-1
         if z > 0 and abs(prefix[z - 1] - target) <= abs(prefix[min(z, gz)] - target):
             z -= 1
-        z = max(z, cuts[-1] + 1)              # every slab keeps at least one layer
-        z = min(z, gz - (world - r))
+        z = max(z, cuts[-1] + m)              # every slab keeps at least m layers ...
+        z = min(z, gz - m * (world - r))      # ... and leaves as many to each rank above
         cuts.append(z)
     cuts.append(gz)
+    assert all(b - a >= m for a, b in zip(cuts, cuts[1:])), cuts
     return [int(c) for c in cuts]
 
 

@@ -56,7 +56,11 @@ public:
         HIP_PARALLEL = CUDA_PARALLEL   // what actually runs here
     };
 
+    // Runs on the HIP device chosen with sph_select_device() (default 0), as the reference runs on
+    // the device findCudaDevice() made current (`-device=N`).
     ParticleSystem(uint numParticles, float3 boxDims, ParticleComputeMode mode);
+    // additive: an explicit grid instead of nextPow2(box / (0.66666 h)) per axis (a 0 keeps the formula)
+    ParticleSystem(uint numParticles, float3 boxDims, ParticleComputeMode mode, uint3 gridDims);
     ~ParticleSystem();
 
     enum ParticleConfig { CONFIG_RANDOM, CONFIG_GRID, _NUM_CONFIGS };

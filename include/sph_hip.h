@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 1
+#define SPH_ABI_VERSION 2
 
 enum {
     SPH_OK = 0,
@@ -85,6 +85,12 @@ const char* sph_last_error(void);
  * device 0 is a gfx950.  Replaces cudaInit/findCudaDevice (particleSystem.cu:427-436). */
 int sph_device_count(int* is_gfx950);
 
+/* Choose the HIP device that contexts created with device = -1 use (default 0): the cudaSetDevice of
+ * findCudaDevice behind the reference's `-device=N` flag (common/inc/helper_cuda.h:845,
+ * particleSystem.cu:427-436, particles.cpp:676-706).  Fails if the device is not a gfx950. */
+int sph_select_device(int device);
+int sph_selected_device(void);
+
 /* Fill *p with the reference's constants for a box of dimensions box_dims centred on the
  * origin (particleSystem.cpp:50-62) and the given grid. */
 void sph_default_params(sph_params* p, const float box_dims[3], const uint32_t grid[3]);
@@ -92,7 +98,8 @@ void sph_default_params(sph_params* p, const float box_dims[3], const uint32_t g
 uint32_t sph_grid_dim_for_edge(float edge, float h);
 
 /* ---- context ------------------------------------------------------------------------- */
-/* Whole-domain context for up to `capacity` particles on HIP device `device`.
+/* Whole-domain context for up to `capacity` particles on HIP device `device` (-1: the device chosen
+ * with sph_select_device).
  * Replaces the allocateArray calls of _initialize (particleSystem.cpp:121-124). */
 int sph_create(sph_ctx** out, int device, uint32_t capacity, const sph_params* p);
 /* z-slab context (multi-GPU): owns the cell layers [z_lo, z_hi) of the global grid and keeps
@@ -126,15 +133,18 @@ int sph_set_by_index(sph_ctx* c, uint32_t first_index, uint32_t count, const flo
  * initGrid + the AoS upload of reset(CONFIG_GRID) (SPH/particleSystem.cpp:839-874, 909-920). */
 int sph_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, const float jitter_dims[3],
                       uint64_t index_start, uint32_t count);
-/* Gather the state BY CREATION INDEX relative to index_base: out[(index-index_base)*3+k].
+/* Gather the state BY CREATION INDEX relative to index_base: out[(index-index_base)*3+k].  The output
+ * arrays hold index_count entries (x3 for the vectors); particles whose creation index lies outside
+ * [index_base, index_base + index_count) are skipped, nothing beyond the arrays is written.
  * Any pointer may be NULL.  (The reference never copies particles back in CUDA mode; this is
  * the additive getArray of the north star.) */
-int sph_download(sph_ctx* c, uint32_t index_base, float* pos_xyz, float* vel_xyz, float* density, float* pressure);
+int sph_download(sph_ctx* c, uint32_t index_base, uint32_t index_count, float* pos_xyz, float* vel_xyz, float* density,
+                 float* pressure);
 /* The owned particles compactly, in slot order: n x xyz, n x xyz, n creation indices (any may be NULL).
  * What a slab driver needs to move whole particles between ranks (re-balancing). */
 int sph_download_owned(sph_ctx* c, float* pos_xyz, float* vel_xyz, uint32_t* index);
-int sph_download_forces(sph_ctx* c, uint32_t index_base, float* fpress_xyz, float* fvisc_xyz, float* dv_xyz,
-                        int32_t* collision_count);
+int sph_download_forces(sph_ctx* c, uint32_t index_base, uint32_t index_count, float* fpress_xyz, float* fvisc_xyz,
+                        float* dv_xyz, int32_t* collision_count);
 /* The `gl_pos` analogue of cudaIntegrate (particleSystem.cu:416-419): float4 (x,y,z,1) per
  * creation index, written by sph_integrate / sph_step.  Device pointer, n*16 bytes. */
 int sph_positions_dev(sph_ctx* c, void** out_dev);
@@ -187,10 +197,15 @@ int sph_timing_reset(sph_ctx* c);
 /* sort statistics: sorts run so far; how many of them took the merge path (only the particles whose
  * cell changed are sorted; same result as the full sort); how many of those found that no particle had
  * changed cell and did nothing at all (`skips`: the order, the keys and the cell table of the previous
- * step are still exact -- a fluid at rest; this is the one place where sph_step waits for the device);
- * and the mover count the device last reported (synchronises the stream).  SPH_SORT_MERGE=0 in the
- * environment at sph_create time disables the merge path.  Any pointer may be NULL. */
-int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers);
+ * step are still exact -- a fluid at rest; taken only when the device has already reported the count, the
+ * host never waits for it); the mover count the device last reported; and the sum of the mover counts of
+ * all sorts so far (movers_total: particles that changed cell, summed over steps).  Synchronises the stream.
+ * Any pointer may be NULL. */
+int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers,
+                   uint64_t* movers_total);
+/* merge != 0 (default): the sort may take the merge path; 0: the full radix sort every step (what
+ * SPH_SORT_MERGE=0 in the environment selects at sph_create time).  Takes effect at the next sort. */
+int sph_set_sort_mode(sph_ctx* c, int merge);
 /* 1 if the last sph_sort found that no particle had changed cell and left everything as it was (then
  * every count derived from the sorted order -- sph_slab_counts, sph_halo_count -- is that of the step
  * before), else 0.  No synchronisation. */

@@ -106,7 +106,47 @@ def gen_morton():
     _save("morton_c1", pos=pos, zindex=recs[("zindex", 1)], box=np.float32(cfg["box"]), grid=np.uint32(cfg["grid"]))
 
 
-GENS = {"c1": gen_c1, "random": gen_random, "c2": gen_c2, "morton": gen_morton}
+def _gen_flow(tag, lattice, box, grid, runup, lock_steps, phase_steps):
+    """Developed flow.  The reference runs the dam break `runup` steps (at dt 5e-7 the first particles change
+    cell after ~1000 steps; by 3000-4000 there are wall hits, collisions and a steady stream of cell changes);
+    that state -- positions and velocities by creation index -- is stored as the fixture's INPUT.  The reference
+    is then restarted from exactly these arrays (so the fixture is self-contained) and stepped `lock_steps` times:
+    the state after every step is stored for lockstep tests (upload state k, step once, compare with state k+1:
+    chaos has no room to accumulate), per-phase records for the first `phase_steps` steps."""
+    pos, vel = ic.dam_break_lattice(lattice, box, jitter=True)
+    recs, stats = refio.run_ref(pos, vel, box, grid, ic.DEFAULT_DT, runup, dump_steps=(runup,))
+    print(f"{tag}: reference run-up of {runup} steps: {stats['seconds']:.1f} s")
+    st = recs[("state", runup)]
+    pos0, vel0 = np.ascontiguousarray(st[:, 0:3]), np.ascontiguousarray(st[:, 3:6])
+    recs, _ = refio.run_ref(pos0, vel0, box, grid, ic.DEFAULT_DT, phase_steps, phases=True)
+    arrs = _phase_arrays(recs, tuple(range(1, phase_steps + 1)))
+    recs, _ = refio.run_ref(pos0, vel0, box, grid, ic.DEFAULT_DT, lock_steps, dump_steps=tuple(range(1, lock_steps + 1)))
+    for s in range(1, lock_steps + 1):
+        arrs[f"state_{s}"] = recs[("state", s)]
+    cells = lambda p: np.floor((p + np.float32(box[0] / 2)) / np.float32(box[0]) * np.float32(grid)).astype(np.int64)
+    moved = int((cells(recs[("state", lock_steps)][:, 0:3]) != cells(pos0)).any(axis=1).sum())
+    print(f"{tag}: {moved} of {pos0.shape[0]} particles change cell within the {lock_steps} stored steps; "
+          f"|v|max {np.abs(vel0).max():.1f}, collisions at step 1: {int((recs_coll(arrs) > 0).sum())}")
+    _save(tag, pos=pos0, vel=vel0, box=np.float32(box), grid=np.uint32((grid,) * 3), dt=np.float32(ic.DEFAULT_DT),
+          runup=np.uint32(runup), lock_steps=np.uint32(lock_steps), phase_steps=np.uint32(phase_steps), **arrs)
+
+
+def recs_coll(arrs):
+    return arrs["s1_coll"][:, 3]
+
+
+def gen_c1_flow():
+    """BASELINE config 1 (16^3 particles, box 4, grid 64^3) after 4000 reference steps."""
+    cfg = ic.CONFIGS["C1"]
+    _gen_flow("c1_flow", cfg["lattice"], cfg["box"], cfg["grid"][0], 4000, 10, 2)
+
+
+def gen_d24_flow():
+    """A bigger block with an interior (24^3 = 13824 particles, box 4, grid 64^3) after 4000 reference steps."""
+    _gen_flow("d24_flow", (24, 24, 24), (4.0, 4.0, 4.0), 64, 4000, 3, 1)
+
+
+GENS = {"c1_flow": gen_c1_flow, "d24_flow": gen_d24_flow, "c1": gen_c1, "random": gen_random, "c2": gen_c2, "morton": gen_morton}
 
 if __name__ == "__main__":
     if not refio.available():

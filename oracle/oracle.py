@@ -42,12 +42,53 @@ def build(fast: bool = False) -> str:
     return so
 
 
+def cpu_info():
+    """(model name, logical cpus available to this process) from /proc/cpuinfo and the affinity mask."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, cores
+
+
+def build_native() -> str:
+    """The speed build (-O3 -march=native) compiled ON THE MACHINE THAT RUNS IT, one file per CPU model
+    under oracle/_native/: a -march=native object built in the build container must not be run on the
+    GPU box's (different) host CPU.  bench.py's cpu_baseline "port" leg uses this."""
+    import hashlib
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = line
+                    break
+    except OSError:
+        pass
+    tag = hashlib.sha1((cpu_info()[0] + flags).encode()).hexdigest()[:10]
+    out_dir = os.path.join(HERE, "_native")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, f"liboracle_fast_{tag}.so")
+    src = [os.path.join(HERE, f) for f in ("sph_oracle.c", "sph_oracle.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c99", "-shared", "-o", so,
+                               src[0], "-lm"])
+    return so
+
+
 _libs = {}
 
 
-def lib(fast: bool = False):
+def lib(fast=False):
+    """fast: False = the bit-exact build, True = liboracle_fast.so, "native" = build_native()."""
     if fast not in _libs:
-        L = C.CDLL(build(fast))
+        L = C.CDLL(build_native() if fast == "native" else build(fast))
         L.orc_create.restype = C.POINTER(_Sys)
         L.orc_create.argtypes = [C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32]
         for fn in ("orc_destroy", "orc_map_zindex", "orc_sort", "orc_construct_bgrid", "orc_construct_grid_array",

@@ -183,12 +183,25 @@ public:
         copyArrayToDevice((void*)m_d_particles, m_particles.data(), m_numParticles * sizeof(Particle));   // :920
         m_bInitialized = true;           // update() asserts it; the destructor never runs (_Exit)
     }
-    void dropin_step(float dt, uint32_t stepno, bool state) {
+    void dropin_step(float dt, uint32_t stepno, bool state, bool phases) {
         update(dt, 0.f);                 // the reference's code, CUDA branch
-        if (state) {
+        if (state || phases) {
             threadSync();
             copyArrayFromDevice(m_particles.data(), m_d_particles, m_numParticles * sizeof(Particle));
             rec_particles(TAG_STATE, stepno);
+        }
+        if (phases) {
+            // what the seam left in the caller's B / B' arrays and in Particle::zindex (particleSystem.cu:503-528):
+            // read back through the seam's own copy call into the members rec_cells / rec_bprime print
+            rec_by_slot_u32(TAG_ORDER, stepno, 1);
+            rec_by_slot_u32(TAG_SORTED_Z, stepno, 0);
+            copyArrayFromDevice(m_h_B, m_d_B, m_h_B_size * sizeof(Grid_item));
+            rec_cells(stepno);
+            m_h_B_prime = new Grid_item[m_h_B_prime_size ? m_h_B_prime_size : 1];
+            copyArrayFromDevice(m_h_B_prime, m_d_B_prime, m_h_B_prime_size * sizeof(Grid_item));
+            rec_bprime(stepno);
+            delete[] m_h_B_prime;
+            m_h_B_prime = nullptr;
         }
     }
 #endif
@@ -265,7 +278,7 @@ int main(int argc, char** argv) {
     double t0 = omp_get_wtime();
     for (uint32_t s = 1; s <= steps; s++) {
 #ifdef REF_DROPIN
-        h->dropin_step(dt, s, dump_steps.count(s) != 0 || s == steps);
+        h->dropin_step(dt, s, dump_steps.count(s) != 0 || s == steps, (flags & 1) != 0);
 #else
         h->step(dt, s, (flags & 1) != 0, dump_steps.count(s) != 0 || s == steps, phase_s);
 #endif

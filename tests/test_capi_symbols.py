@@ -25,7 +25,7 @@ def test_library_builds_and_exports_the_header():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sph_hip.h but not exported"
         assert n in capi.SIGNATURES, f"{n} has no ctypes signature in capi.py"
-    assert lib.sph_abi_version() == 1
+    assert lib.sph_abi_version() == 2
 
 
 def test_reference_seam_symbols_are_exported():

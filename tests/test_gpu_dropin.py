@@ -37,3 +37,50 @@ def test_reference_update_random_clump():
         assert np.abs(st[:, 6] / ref[:, 6] - 1).max() <= 1e-5
         bad = np.abs(st[:, 3:6] - ref[:, 3:6]).max(axis=1) > 4e-5 * np.abs(ref[:, 3:6]).max()
         assert bad.mean() <= 2e-3
+
+
+def _morton_decode(z):
+    """zIndex2coord of the reference (particleSystem.cu:105-124): every third bit."""
+    z = np.asarray(z, dtype=np.uint64)
+    out = []
+    for a in range(3):
+        v = np.zeros_like(z)
+        for b in range(10):
+            v |= ((z >> np.uint64(3 * b + a)) & np.uint64(1)) << np.uint64(b)
+        out.append(v.astype(np.int64))
+    return out
+
+
+@pytest.mark.parametrize("name", ["c1_jitter", "random_clump"])
+def test_seam_fills_B_and_Bprime_like_the_reference(name):
+    """cudaConstructBGrid / cudaConstructGridArray leave {nParticles, start} per occupied cell in the caller's B and
+    one {nParticles <= 32, start} entry per 32-particle chunk in B', with the size handed back to the host
+    (particleSystem.cu:503-528).  Cells carry this library's row-major number (as does Particle::zindex), so B is
+    compared cell by cell through the cell coordinates; B' must chunk the sorted array exactly like the
+    reference's (same number of entries, same chunk sizes per cell)."""
+    g = load_golden(name)
+    grid = int(g["grid"][0])
+    recs, _ = refio.run_ref(g["pos"], g["vel"], g["box"], grid, float(g["dt"]), 1, phases=True, binary=refio.DROPIN_BIN)
+    cells, bprime = recs[("bcells", 1)], recs[("bprime", 1)]
+    sorted_z, order = recs[("sorted_z", 1)], recs[("order", 1)]
+    ref_cells, ref_bprime = g["s1_bcells"], g["s1_bprime"]
+    n = order.shape[0]
+    # the particle array is sorted by the key it carries, and B describes exactly its runs
+    assert np.all(np.diff(sorted_z.astype(np.int64)) >= 0)
+    key, cnt, start = cells[:, 0].astype(np.int64), cells[:, 1].astype(np.int64), cells[:, 2].astype(np.int64)
+    assert cnt.sum() == n
+    for k, c, s in zip(key[:2000], cnt[:2000], start[:2000]):
+        assert np.all(sorted_z[s:s + c] == k) and (s == 0 or sorted_z[s - 1] != k) and (s + c == n or sorted_z[s + c] != k)
+    # same occupied cells with the same counts as the reference's B (Morton-numbered there)
+    x, y, z = key % grid, (key // grid) % grid, key // (grid * grid)
+    rx, ry, rz = _morton_decode(ref_cells[:, 0])
+    mine = dict(zip(zip(x.tolist(), y.tolist(), z.tolist()), cnt.tolist()))
+    theirs = dict(zip(zip(rx.tolist(), ry.tolist(), rz.tolist()), ref_cells[:, 1].astype(np.int64).tolist()))
+    assert mine == theirs
+    # B': one entry per chunk of <= 32, tiling the sorted array in order; same multiset of chunk sizes per cell
+    assert bprime.shape[0] == ref_bprime.shape[0]
+    bs, bn = bprime[:, 0].astype(np.int64), bprime[:, 1].astype(np.int64)
+    assert bs[0] == 0 and np.all(bs[1:] == bs[:-1] + bn[:-1]) and bs[-1] + bn[-1] == n and bn.max() <= 32 and bn.min() >= 1
+    assert sorted(bn.tolist()) == sorted(ref_bprime[:, 1].astype(np.int64).tolist())
+    for s, c in zip(bs[:2000], bn[:2000]):
+        assert np.all(sorted_z[s:s + c] == sorted_z[s])

@@ -44,10 +44,14 @@ def test_choose_cuts_balances_counts():
     assert max(counts) == min(counts) == 2000
     with pytest.raises(ValueError):
         slab.choose_cuts(np.ones(3), 4)
-    # degenerate: everything in one layer -> slabs still get >= 1 layer each
+    # degenerate: everything in one layer -> every slab still gets >= 2 layers (the halo protocol needs its two
+    # boundary layers to be different layers)
     h = np.zeros(8, dtype=np.int64); h[5] = 10
     cuts = slab.choose_cuts(h, 3)
-    assert all(b > a for a, b in zip(cuts, cuts[1:])) and cuts[-1] == 8
+    assert all(b - a >= 2 for a, b in zip(cuts, cuts[1:])) and cuts[-1] == 8
+    with pytest.raises(ValueError):
+        slab.choose_cuts(np.ones(7), 4)     # 4 slabs x 2 layers do not fit 7 layers
+    assert slab.choose_cuts(np.ones(8), 4) == [0, 2, 4, 6, 8]
 
 
 def test_cell_layer_matches_the_oracle_hash():
