@@ -83,6 +83,8 @@ SIGNATURES = {
     "sph_sort_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                  C.POINTER(C.c_uint64)]),
     "sph_set_sort_mode": (C.c_int, [_P, C.c_int]),
+    "sph_set_precision": (C.c_int, [_P, C.c_int]),
+    "sph_get_precision": (C.c_int, [_P]),
     "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_slab_counts": (C.c_int, [_P, C.POINTER(_U32)]),
     "sph_migrants_pack": (C.c_int, [_P, C.POINTER(_P), _U32]),
@@ -333,9 +335,15 @@ class Context:
         _check(self.L.sph_sort_stats(self.h, C.byref(a), C.byref(b), C.byref(k), C.byref(m), C.byref(t)))
         return {"sorts": a.value, "merges": b.value, "skips": k.value, "last_movers": m.value, "movers_total": t.value}
 
+    def set_precision(self, mixed_f16=False):
+        """False: fp32 (the reference's precision); True: BASELINE config 5 -- fp32 state, packed-fp16 pair arithmetic
+        and per-row accumulators in the density / force traversals."""
+        _check(self.L.sph_set_precision(self.h, 1 if mixed_f16 else 0))
+
     def set_sort_mode(self, merge=True):
-        """merge=False: full radix sort every step (the SPH_SORT_MERGE=0 behaviour)."""
-        _check(self.L.sph_set_sort_mode(self.h, 1 if merge else 0))
+        """merge=False/0: full radix sort every step (the SPH_SORT_MERGE=0 behaviour); True/1: merge while few
+        particles change cell; 2: merge whatever the count (tests)."""
+        _check(self.L.sph_set_sort_mode(self.h, int(merge)))
 
     def timing_get(self):
         ms = (C.c_float * len(PHASES))()

@@ -102,7 +102,8 @@ static int dev_alloc(T** p, size_t count) {
 static void free_all(sph_ctx* c) {
     hipFree(c->posi); hipFree(c->velr); hipFree(c->posi2); hipFree(c->velr2); hipFree(c->keyS); hipFree(c->dp);
     hipFree(c->fpress); hipFree(c->fvisc); hipFree(c->dvel); hipFree(c->pos_out); hipFree(c->cells_base);
-    hipFree(c->k0); hipFree(c->v0); hipFree(c->k1); hipFree(c->v1); hipFree(c->hist); hipFree(c->digit_tot);
+    hipFree(c->k0); hipFree(c->v0); hipFree(c->k1); hipFree(c->v1); hipFree(c->os_hist); hipFree(c->os_base); hipFree(c->os_tickets); hipFree(c->os_tot); hipFree(c->os_status); hipFree(c->os_status32); hipFree(c->keyS2); hipFree(c->mm_tileL);
+    if (c->os_err_host) hipHostFree(c->os_err_host);
     hipFree(c->d_scratch);
     hipFree(c->mm_mask); hipFree(c->mm_M64); hipFree(c->mm_tile_cnt); hipFree(c->mm_tile_off);
     hipFree(c->mm_k0); hipFree(c->mm_k1); hipFree(c->mm_v1); hipFree(c->mm_count); hipFree(c->mm_total);
@@ -139,7 +140,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (rc) { delete c; return rc; }
     c->cap = capacity; c->gcap = gcap; c->tot = capacity + 2 * gcap; c->slab = slab;
     c->own_off = gcap;
-    c->sort_blocks_cap = ceil_div(capacity, 4096) + 1;
+    c->sort_blocks_cap = ceil_div(capacity, SORT_TILE_KEYS) + 1;
     c->pos_out_cap = slab ? 0 : capacity;
     // + 2*PIECE entries: the pair kernels stage whole 128-entry pieces without bounds predicates
     const size_t tot = (size_t)c->tot + 256;
@@ -148,6 +149,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (!rc) rc = dev_alloc(&c->posi2, tot);
     if (!rc) rc = dev_alloc(&c->velr2, tot);
     if (!rc) rc = dev_alloc(&c->keyS, tot);
+    if (!rc) rc = dev_alloc(&c->keyS2, tot);
     if (!rc) rc = dev_alloc(&c->dp, tot);
     if (!rc) rc = dev_alloc(&c->fpress, tot);
     if (!rc) rc = dev_alloc(&c->fvisc, tot);
@@ -160,8 +162,32 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (!rc) rc = dev_alloc(&c->v0, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->k1, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->v1, (size_t)capacity);
-    if (!rc) rc = dev_alloc(&c->hist, (size_t)512 * c->sort_blocks_cap);
-    if (!rc) rc = dev_alloc(&c->digit_tot, (size_t)512);
+    const size_t os_groups = (size_t)c->sort_blocks_cap / 4 + 3;   // enough for groups of >= 4 tiles
+    c->os_groups_cap = (uint32_t)os_groups;
+    if (!rc) rc = dev_alloc(&c->os_hist, os_groups * 4 * 512);
+    if (!rc) rc = dev_alloc(&c->os_base, os_groups * 4 * 512);
+    if (!rc) rc = dev_alloc(&c->os_tickets, (size_t)4 * os_groups);
+    if (!rc) rc = dev_alloc(&c->os_tot, (size_t)4 * 512);
+    if (!rc) rc = dev_alloc(&c->os_status, (size_t)512 * c->sort_blocks_cap);
+    if (!rc) rc = dev_alloc(&c->os_status32, (size_t)512 * c->sort_blocks_cap);
+    if (!rc) rc = dev_alloc(&c->mm_tileL, (size_t)c->sort_blocks_cap + 2);
+    if (!rc && (hipHostMalloc((void**)&c->os_err_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&c->os_err_dev, c->os_err_host, 0) != hipSuccess)) {
+        set_error("hipHostMalloc(mapped) failed");
+        rc = SPH_E_NOMEM;
+    }
+    if (!rc) {
+        *c->os_err_host = 0;
+        if (hipMemset(c->os_status, 0, (size_t)512 * c->sort_blocks_cap * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(c->os_status32, 0, (size_t)512 * c->sort_blocks_cap * sizeof(uint32_t)) != hipSuccess ||
+            hipMemset(c->os_tickets, 0, 4 * os_groups * sizeof(uint32_t)) != hipSuccess ||
+            hipMemset(c->os_hist, 0, os_groups * 4 * 512 * sizeof(uint32_t)) != hipSuccess ||
+            hipMemset(c->keyS, 0, tot * sizeof(uint32_t)) != hipSuccess ||
+            hipMemset(c->keyS2, 0, tot * sizeof(uint32_t)) != hipSuccess) {
+            set_error("hipMemset failed");
+            rc = SPH_E_DEVICE;
+        }
+    }
     if (!rc) rc = dev_alloc(&c->d_scratch, (size_t)64);
     if (!rc && hipHostMalloc((void**)&c->h_scratch, 64 * sizeof(uint32_t)) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -441,6 +467,8 @@ int sph_get_params(const sph_ctx* c, sph_params* p) {
 int sph_sync(sph_ctx* c) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     SPH_HIP(hipStreamSynchronize(c->stream));
+    SPH_REQUIRE(*c->os_err_host == 0u, SPH_E_DEVICE,
+                "radix sort: a look-back on another tile's digit counts timed out (results of the last sort are invalid)");
     return SPH_OK;
 }
 
@@ -920,9 +948,20 @@ int sph_timing_reset(sph_ctx* c) {
 
 int sph_last_sort_skipped(const sph_ctx* c) { return c && c->last_sort_skipped ? 1 : 0; }
 
+int sph_set_precision(sph_ctx* c, int precision) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(precision == SPH_PRECISION_F32 || precision == SPH_PRECISION_MIXED_F16, SPH_E_INVALID,
+                "unknown precision %d", precision);
+    c->precision = precision;
+    return SPH_OK;
+}
+
+int sph_get_precision(const sph_ctx* c) { return c ? c->precision : SPH_PRECISION_F32; }
+
 int sph_set_sort_mode(sph_ctx* c, int merge) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     c->sort_merge = merge != 0;
+    c->sort_merge_always = merge == 2;
     return SPH_OK;
 }
 

@@ -14,6 +14,10 @@
 namespace sph {
 
 constexpr int WAVE = 64;
+#ifndef SPH_SORT_KPT
+#define SPH_SORT_KPT 16
+#endif
+constexpr uint32_t SORT_TILE_KEYS = 256 * SPH_SORT_KPT;   // keys per radix-sort tile (sph_sort.hip)
 constexpr uint32_t MM_TILE_CHUNKS = 256;   // merge sort: 64-slot chunks per scan tile (sph_sort.hip)
 
 // Grid description passed by value to kernels (replaces the device-resident SimParams*
@@ -49,6 +53,7 @@ struct sph_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     sph_params params{};
+    int precision = SPH_PRECISION_F32;   // sph_set_precision
     sph::GridDesc grid{};
     sph::Phys phys{};
 
@@ -71,6 +76,7 @@ struct sph_ctx {
     float4* posi2 = nullptr;  // ping-pong targets of reorder / integrate
     float4* velr2 = nullptr;
     uint32_t* keyS = nullptr; // cell key per slot (same indexing as posi)
+    uint32_t* keyS2 = nullptr;// ping-pong target of the sort
     float2* dp = nullptr;     // density, pressure
     float4* fpress = nullptr; // phase API outputs
     float4* fvisc = nullptr;
@@ -89,13 +95,23 @@ struct sph_ctx {
     // radix sort scratch
     uint32_t* k0 = nullptr; uint32_t* v0 = nullptr;
     uint32_t* k1 = nullptr; uint32_t* v1 = nullptr;
-    uint32_t* hist = nullptr;       // 256 * nblocks
-    uint32_t* digit_tot = nullptr;  // 256
+    uint32_t* os_hist = nullptr;    // [group][4 passes][512 digits]: digit counts per group of 16 tiles
+    uint32_t* os_base = nullptr;    // same shape: first output position of a (group, digit)
+    uint32_t* os_tickets = nullptr; // one per pass (re-armed by k_os_scan)
+    uint32_t* os_tot = nullptr;     // [4 passes][512 digits]: keys per digit
+    uint32_t os_groups_cap = 0;
+    unsigned long long* os_status = nullptr;   // (tile, digit) look-back words {epoch << 1 | is_prefix, count} (one-group sorts)
+    uint32_t* os_status32 = nullptr;           // (tile, digit) words {epoch:19, count:13} (grouped sorts)
+    uint32_t os_epoch = 0;          // changes with every pass of every sort: the status table is never cleared
+    uint32_t* os_err_host = nullptr;           // pinned, mapped: set by a look-back that timed out
+    uint32_t* os_err_dev = nullptr;
     uint32_t sort_blocks_cap = 0;
     uint32_t key_bits = 0;
-    const uint32_t* last_perm = nullptr;   // v0 or v1: the permutation of the last sort; null = identity
+    const uint32_t* last_perm = nullptr;   // v0 or v1: the permutation of the last sort; null = identity / not kept
+    bool keep_perm = false;         // the merge path also writes the permutation (only the compat seam needs it)
     // the sort as a merge (sph_sort.hip: launch_sort_merge)
     bool sort_merge = true;         // SPH_SORT_MERGE=0 in the environment at create time turns it off
+    bool sort_merge_always = false; // sph_set_sort_mode(c, 2): merge whatever the mover count (tests)
     bool order_valid = false;       // [own_off, own_off+n) is still in the order of the last sort, keyS = its keys
     bool last_sort_skipped = false;
     uint64_t sort_merges = 0, sort_calls = 0, sort_skips = 0;   // skips: merges with no mover at all (nothing done)
@@ -111,6 +127,8 @@ struct sph_ctx {
     hipEvent_t mm_counted = nullptr;        // after the mover count of the current sort (queried, never waited for)
     // the fused integrate epilogue already wrote mm_mask / mm_tile_cnt for the range it was launched on
     bool mm_marked = false;
+    bool mm_scanned = false;        // ... and the scan that counts them is already queued (mm_scan_marks)
+    uint32_t* mm_tileL = nullptr;   // coarse mover ranks per 4096 slots (k_mm_tile_rank)
     uint32_t mm_marked_off = 0, mm_marked_n = 0;
     uint32_t* d_scratch = nullptr;  // small device scratch (counts)
     uint32_t* h_scratch = nullptr;  // pinned host mirror
@@ -130,6 +148,7 @@ namespace sph {
 
 void set_error(const char* fmt, ...);
 void mm_drop_marks(sph_ctx* c);     // sph_sort.hip
+void mm_scan_marks(sph_ctx* c);     // sph_sort.hip
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define SPH_HIP(call)                                                        \
@@ -153,6 +172,7 @@ int launch_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, cons
 int launch_sort(sph_ctx* c);          // radix sort of (k0,v0)[0,n) + reorder into posi2/velr2/keyS
 int launch_cells_clear(sph_ctx* c);
 int launch_cells_clear_range(sph_ctx* c, uint32_t lo, uint32_t hi);
+int launch_cells_build_range(sph_ctx* c, uint32_t lo, uint32_t hi);
 int launch_cells_build(sph_ctx* c);
 int launch_density(sph_ctx* c);
 int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt);

@@ -177,6 +177,7 @@ void configure(Compat& c, unsigned int n, const sph_compat_simparams* params_dev
         if (c.bp_cnt) { hipFree(c.bp_cnt); c.bp_cnt = nullptr; }
         if (c.bp_off) { hipFree(c.bp_off); c.bp_off = nullptr; }
         CK(sph_create(&c.ctx, -1, n ? n : 1, &q));      // -1: the device cudaInit / sph_select_device chose
+        c.ctx->keep_perm = true;                        // cudaSortParticles moves the caller's structs by it
         CKH(hipMalloc((void**)&c.tmp, (size_t)(n ? n : 1) * sizeof(sph_compat_particle)));
         const size_t nt = (size_t)ceil_div(n ? n : 1, 256u);
         CKH(hipMalloc((void**)&c.bp_cnt, nt * sizeof(uint32_t)));

@@ -308,11 +308,144 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
     }
 }
 
+// ---- mixed precision (BASELINE config 5): fp32 positions, fp16 neighbour accumulators -----------------------
+// Same traversal, same candidates, same order; what changes is the arithmetic of a PAIR.  Candidates are staged
+// in LDS as fp16 coordinates relative to a wave-uniform reference point and in units of h (so |x'| <~ 4 and
+// r'^2 = r^2 / h^2 comes out of the packed arithmetic directly), two neighbouring candidates per 32-bit word:
+// every v_pk_* instruction works on TWO candidates of the lane's range and every LDS read fetches two.  The sum of
+// the NORMALISED kernel W' = (1 - r'^2)^3 in [0, 1] is accumulated in packed fp16 over one row (<= ~30 terms of at
+// most 1: the raw densities, ~2e6, would overflow fp16) and added to an fp32 total after every
+// row; the physical scale m * POLY6 * h^6 is applied once, in fp32.  Tolerance: DESIGN.md section 4 (mixed).
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) h2* lds_h2_ptr;
+
+__device__ __forceinline__ h2 h2_splat(float x) { const _Float16 v = (_Float16)x; return h2{v, v}; }
+// 1.0 in the halves that are valid, 0.0 in the others
+__device__ __forceinline__ h2 h2_mask(bool lo, bool hi) {
+    const uint32_t bits = (lo ? 0x3C00u : 0u) | (hi ? 0x3C000000u : 0u);
+    return __builtin_bit_cast(h2, bits);
+}
+
+constexpr int HPAIRS = PIECE / 2;                       // packed candidate pairs per staged piece
+constexpr int LDS_PAIRS = (PAIR_WAVES + 1) * HPAIRS + 8;
+constexpr int HUNROLL = 4;                              // pairs per unrolled group (8 candidates)
+
+// A lane's range [l0, l1) may start at an odd candidate.  So that its pairs are whole all the same, every piece is
+// staged TWICE: pairs (2p, 2p+1) in the lower half of the LDS arrays and pairs (2p+1, 2p+2) in the upper half; a
+// lane reads the copy that matches the parity of its l0.  Only the LAST pair of a range can then be half outside it
+// (odd length) -- one masked iteration per row instead of a mask on every pair.
+struct PairWalk {
+    uint32_t idx;        // LDS pair index of the first pair
+    uint32_t whole;      // pairs entirely inside the range
+    bool odd;            // one more candidate in the low half of pair `whole`
+    uint32_t kmin, T;    // wave-uniform: pairs every lane has / pairs of the longest lane
+};
+
+__device__ __forceinline__ PairWalk pair_walk(uint32_t slice_pairs, uint32_t l0, uint32_t l1) {
+    PairWalk w;
+    const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
+    w.idx = (len && (l0 & 1u) ? (uint32_t)LDS_PAIRS : 0u) + slice_pairs + (len ? l0 >> 1 : 0u);
+    w.whole = len >> 1;
+    w.odd = (len & 1u) != 0u;
+    uint32_t tmin;
+    wave_min_max_u32(w.whole + (w.odd ? 1u : 0u), tmin, w.T);
+    w.kmin = wave_min_u32_uniform_first(w.whole) & ~(uint32_t)(HUNROLL - 1);
+    return w;
+}
+
+__global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const float4* __restrict__ posi,
+                                                                          const uint32_t* __restrict__ keyS,
+                                                                          const uint2* __restrict__ cells,
+                                                                          float2* __restrict__ dp, uint32_t tgt_lo,
+                                                                          uint32_t tgt_hi, GridDesc g, Phys ph) {
+    struct XY { h2 x, y; };                                   // 8 bytes: one ds_read_b64 per pair
+    __shared__ XY s_xy[2 * LDS_PAIRS];
+    __shared__ h2 s_z[2 * LDS_PAIRS];
+    const h2 zero = h2{(_Float16)0, (_Float16)0}, one = h2{(_Float16)1, (_Float16)1};
+    for (uint32_t k = threadIdx.x; k < 2 * LDS_PAIRS; k += PAIR_THREADS) {      // over-reads stay finite
+        s_xy[k].x = zero; s_xy[k].y = zero; s_z[k] = zero;
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slice = wave * HPAIRS;
+    const uint32_t i = tgt_lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE + lane;
+    const bool active = i < tgt_hi;
+    const uint32_t ii = active ? i : tgt_hi - 1;
+    const float4 pi = posi[ii];
+    Rows R;
+    lane_rows(cells, g, keyS[ii], active, R);
+    Hulls H;
+    wave_hulls(R, H);
+    // reference point: the wave's first particle (wave-uniform; every candidate of the wave lies within a few cells)
+    const float rx = __builtin_amdgcn_readfirstlane(pi.x), ry = __builtin_amdgcn_readfirstlane(pi.y),
+                rz = __builtin_amdgcn_readfirstlane(pi.z);
+    const float inv_h = 1.0f / ph.h;
+    const h2 tx = h2_splat((pi.x - rx) * inv_h), ty = h2_splat((pi.y - ry) * inv_h), tz = h2_splat((pi.z - rz) * inv_h);
+    float4 q0, q1, q2;
+    float acc = 0.f;
+    traverse(
+        H,
+        [&](uint32_t a) {   // lane L stages candidates 2L, 2L+1 and 2L+2; the arrays are padded by 2*PIECE
+            q0 = posi[a + 2u * lane];
+            q1 = posi[a + 2u * lane + 1u];
+            q2 = posi[a + 2u * lane + 2u];
+        },
+        [&]() {
+            const _Float16 x0 = (_Float16)((q0.x - rx) * inv_h), x1 = (_Float16)((q1.x - rx) * inv_h),
+                           x2 = (_Float16)((q2.x - rx) * inv_h);
+            const _Float16 y0 = (_Float16)((q0.y - ry) * inv_h), y1 = (_Float16)((q1.y - ry) * inv_h),
+                           y2 = (_Float16)((q2.y - ry) * inv_h);
+            const _Float16 z0 = (_Float16)((q0.z - rz) * inv_h), z1 = (_Float16)((q1.z - rz) * inv_h),
+                           z2 = (_Float16)((q2.z - rz) * inv_h);
+            s_xy[slice + lane].x = h2{x0, x1}; s_xy[slice + lane].y = h2{y0, y1}; s_z[slice + lane] = h2{z0, z1};
+            s_xy[LDS_PAIRS + slice + lane].x = h2{x1, x2}; s_xy[LDS_PAIRS + slice + lane].y = h2{y1, y2};
+            s_z[LDS_PAIRS + slice + lane] = h2{z1, z2};
+        },
+        [&](int r, uint32_t a, uint32_t b) {
+            const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
+            const PairWalk w = pair_walk(slice, l1 > l0 ? l0 - a : 0u, l1 > l0 ? l1 - a : 0u);
+            uint32_t idx = w.idx;
+            h2 row = zero;                                             // this row's sum of W', both halves
+            auto pair = [&](int u, h2 m, bool masked) {
+                const h2 x = ((lds_h2_ptr)&s_xy[idx + u].x)[0], y = ((lds_h2_ptr)&s_xy[idx + u].x)[1];
+                const h2 z = ((lds_h2_ptr)s_z)[idx + u];
+                const h2 dx = tx - x, dy = ty - y, dz = tz - z;
+                h2 t = one - dx * dx;                                  // 1 - r'^2: three v_pk_fma_f16
+                t = t - dy * dy;
+                t = t - dz * dz;
+                t = __builtin_elementwise_max(t, zero);                // r' < 1  <=>  r < h
+                if (masked) t = t * m;
+                row = row + (t * t) * t;
+            };
+            uint32_t k = 0;
+            for (; k < w.kmin; k += HUNROLL) {
+#pragma unroll
+                for (int u = 0; u < HUNROLL; u++) pair(u, one, false);
+                idx += HUNROLL;
+            }
+            for (; k < w.T; k++) {                                     // until every lane is through its range
+                pair(0, h2_mask(k < w.whole + (w.odd ? 1u : 0u), k < w.whole), true);
+                idx++;
+            }
+            acc += (float)row.x + (float)row.y;
+        });
+    if (active) {
+        const float h2f = ph.h2;
+        float rho = acc * (ph.poly6_mass * (h2f * h2f * h2f));          // m POLY6 h^6 sum (1 - r'^2)^3
+        float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
+        dp[i] = make_float2(rho, p);
+    }
+}
+
 int launch_density(sph_ctx* c) {
     if (c->n == 0) return SPH_OK;
     uint32_t lo = c->own_off, hi = c->own_off + c->n;
-    hipLaunchKernelGGL(k_density, dim3(ceil_div(c->n, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
-                       c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
+    if (c->precision == SPH_PRECISION_MIXED_F16)
+        hipLaunchKernelGGL(k_density_h, dim3(ceil_div(c->n, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
+                           c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
+    else
+        hipLaunchKernelGGL(k_density, dim3(ceil_div(c->n, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
+                           c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
 }
@@ -575,7 +708,10 @@ int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt)
         t = c->posi; c->posi = c->posi2; c->posi2 = t;
         t = c->velr; c->velr = c->velr2; c->velr2 = t;
         c->keys_fresh = true;
-        if (mark) { c->mm_marked = true; c->mm_marked_off = lo; c->mm_marked_n = c->n; }
+        if (mark) {
+            c->mm_marked = true; c->mm_scanned = false; c->mm_marked_off = lo; c->mm_marked_n = c->n;
+            mm_scan_marks(c);          // count them now: the next sort finds the number ready
+        }
     }
     return SPH_OK;
 }

@@ -10,7 +10,16 @@
 namespace sph {
 
 constexpr int SORT_THREADS = 256;            // 4 waves
-constexpr int SORT_KPT = 16;                 // keys per thread
+#ifndef SPH_SORT_KPT
+#define SPH_SORT_KPT 16
+#endif
+// 1: the ranked pairs of a tile are parked in LDS in digit order and written out with neighbouring threads on
+// neighbouring addresses; 0: every lane stores its pair straight from registers (uncoalesced, but 8 KB of LDS
+// per block instead of 40: three times the waves per CU)
+#ifndef SPH_SORT_STAGE
+#define SPH_SORT_STAGE 1
+#endif
+constexpr int SORT_KPT = SPH_SORT_KPT;       // keys per thread
 constexpr int SORT_WAVE_TILE = WAVE * SORT_KPT;          // 1024 consecutive keys per wave
 constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;       // 4096 keys per block
 
@@ -23,193 +32,414 @@ __global__ __launch_bounds__(256) void k_hash(const float4* __restrict__ posi, u
     keys[i] = cell_key(g, p.x, p.y, p.z);
 }
 
-// ---- pass 1 of 3: per-block digit histogram ----------------------------------------------------
-// BITS = 8 or 9 bits per pass: 27 significant key bits (512^3 cells) sort in 3 passes of 9.
-// All three kernels walk "virtual blocks" (tiles of SORT_TILE keys) grid-stride, and take the element
-// count either by value or from device memory (n_dev, clamped to n): the main sort launches one block
-// per tile; the sort of the movers (see launch_sort_merge) is sized from a stale estimate and is
-// correct for any count.
+// ---- onesweep LSD radix sort of (key, value) pairs ----------------------------------------------------
+// A histogram kernel counts the digits per GROUP of tiles, a small kernel turns the counts into the first output
+// position of every (group, digit); then ONE kernel per pass:
+// a block takes a tile of 4096 consecutive keys (by ticket, so that tiles are started in order), counts its
+// digits, publishes the counts, obtains the number of equal digits in the EARLIER tiles OF ITS GROUP by decoupled
+// look-back over the predecessors' published words, ranks its keys (stable: waves, rows and lanes in key order), parks the
+// pairs in LDS in digit order and writes them out -- neighbouring threads store neighbouring addresses of one
+// digit's run.  Per pass 16 B per key of HBM traffic (the three-kernel hist / scan / scatter it replaces: 20 B and
+// an uncoalesced scatter) and P + 1 launches per sort instead of 3 P.
+//
+// Inter-block words (MI355X: 8 XCDs, private L2s, no coherent L1): one 8-byte word per (tile, digit),
+// {epoch << 1 | is_prefix, count}, stored and polled with relaxed agent-scope atomics (sc1: write-through /
+// L1-bypassing) -- the value IS the flag, so no fence is needed (cdna_hip_programming.md, Guideline 16, R2).  The
+// epoch changes with every pass of every sort, so the table is never cleared.  A block only ever waits for blocks
+// with a smaller ticket, and a ticket is taken by a block that is already running: the wait always ends; it is
+// bounded all the same (sph_sync reports a timeout).
+//
+// All kernels take the element count by value or from device memory (n_dev, clamped to n): the movers' sort of
+// the merge path is sized from a stale estimate and is correct for any count.
+constexpr int OS_TILE = SORT_TILE;                       // 4096 keys per tile
+// Tiles per look-back group.  One chain over all 4096 tiles of C3 made a pass take 240 us (~58 ns per tile), so a
+// big sort uses groups of 16 tiles whose chains run in parallel -- at the price of one histogram kernel PER PASS (the
+// digit counts of a group are those of the keys as that pass finds them).  Up to OS_ONE_GROUP_TILES tiles (the movers'
+// sort of the merge path) there is ONE group: its counts do not depend on the order of the keys, so a single
+// histogram kernel up front serves every pass (P + 2 launches per sort).
+#ifndef SPH_OS_GROUP
+#define SPH_OS_GROUP 16
+#endif
+constexpr uint32_t OS_GROUP = SPH_OS_GROUP;
+constexpr uint32_t OS_ONE_GROUP_TILES = 64;
+constexpr uint32_t OS_ALL_TILES = 0xFFFFFFFFu;           // group_tiles value for "one group"
+constexpr uint32_t OS_SPIN_LIMIT = 1u << 22;
+
 __device__ __forceinline__ uint32_t sort_count(uint32_t n, const uint32_t* __restrict__ n_dev) {
     return n_dev ? min(*n_dev, n) : n;
 }
 
+// exclusive scan of one value per thread over a 256-thread block (wave shuffles + 4 wave totals in LDS)
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_wtot /*[4]*/, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= (uint32_t)off) inc += t;
+    }
+    if (lane == 63u) s_wtot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) { const uint32_t t = s_wtot[w]; if (w < wave) base += t; tot += t; }
+    if (total) *total = tot;
+    __syncthreads();                                     // s_wtot may be reused by the caller
+    return base + inc - v;
+}
+
+// count[d] += 1 for every valid lane.  Keys arrive nearly sorted (particle order of the previous step, or lattice
+// order), so the high digits are the same in all 64 lanes more often than not: then one lane adds the popcount
+// instead of 64 lanes queueing up on one LDS word.
+__device__ __forceinline__ void wave_count_digit(uint32_t* counts, uint32_t d, bool valid) {
+    const uint64_t act = __ballot(valid);
+    if (act == 0ull) return;                                              // wave-uniform
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, __builtin_ctzll(act));
+    if (__ballot(valid && d != d0) == 0ull) {                             // wave-uniform
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(act)) atomicAdd(&counts[d0], (uint32_t)__popcll(act));
+    } else if (valid) {
+        atomicAdd(&counts[d], 1u);
+    }
+}
+
+// digit counts of the passes pass0 .. pass0+passes-1 per group of tiles: hist[(group * 4 + pass) * 512 + digit],
+// ACCUMULATED (k_os_scan zeroes what it has read).  A block counts OS_HIST_TILES consecutive tiles (all of one
+// group) in LDS and adds what it found; 16-byte loads.
+constexpr uint32_t OS_HIST_TILES = 4;
 template <int BITS>
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t* __restrict__ keys, uint32_t n_arg,
-                                                            const uint32_t* __restrict__ n_dev, uint32_t shift,
-                                                            uint32_t nblocks, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint32_t* __restrict__ keys, uint32_t n_arg,
+                                                          const uint32_t* __restrict__ n_dev, uint32_t pass0,
+                                                          uint32_t passes, uint32_t group_tiles,
+                                                          uint32_t* __restrict__ hist) {
     constexpr int RADIX = 1 << BITS;
-    __shared__ uint32_t h[RADIX];
+    __shared__ uint32_t h[4 * RADIX];
     const uint32_t n = sort_count(n_arg, n_dev);
-    const uint32_t nvb = (n + SORT_TILE - 1) / SORT_TILE;
-    for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) h[d] = 0;
+    const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    const uint32_t nchunks = (ntiles + OS_HIST_TILES - 1) / OS_HIST_TILES;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        for (uint32_t d = threadIdx.x; d < passes * RADIX; d += SORT_THREADS) h[d] = 0;
         __syncthreads();
-        uint32_t base = vb * SORT_TILE;
+        const uint32_t t0 = chunk * OS_HIST_TILES, t1 = min(t0 + OS_HIST_TILES, ntiles);
+        for (uint32_t tile = t0; tile < t1; tile++) {
 #pragma unroll
-        for (int t = 0; t < SORT_KPT; t++) {
-            uint32_t i = base + t * SORT_THREADS + threadIdx.x;
-            if (i < n) atomicAdd(&h[(keys[i] >> shift) & (RADIX - 1)], 1u);
-        }
-        __syncthreads();
-        for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) hist[(size_t)d * nblocks + vb] = h[d];   // digit-major
-        __syncthreads();
-    }
-}
-
-// ---- pass 2 of 3: one block per digit scans its row of per-block counts --------------------------
-__global__ __launch_bounds__(256) void k_sort_scan(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t n_arg,
-                                                   const uint32_t* __restrict__ n_dev,
-                                                   uint32_t* __restrict__ digit_tot) {
-    __shared__ uint32_t part[256];
-    const uint32_t n = sort_count(n_arg, n_dev);
-    const uint32_t nvb = (n + SORT_TILE - 1) / SORT_TILE;      // entries of the row in use (<= nblocks, the stride)
-    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
-    uint32_t per = (nvb + 255u) / 256u;
-    uint32_t lo = min(threadIdx.x * per, nvb);
-    uint32_t hi = min(lo + per, nvb);
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += row[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 256 partial sums
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - s;   // exclusive
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t v = row[i];
-        row[i] = run;
-        run += v;
-    }
-    if (threadIdx.x == 255) digit_tot[blockIdx.x] = part[255];
-}
-
-// ---- pass 3 of 3: stable scatter -------------------------------------------------------------------
-// Each wave owns 1024 consecutive keys of the block's tile and walks them 64 at a time in order.
-// Rank of a key among equal digits inside one 64-key row: ballot-based match-any + popcount of the
-// lower lanes; running per-wave, per-digit counters live in LDS.
-template <int BITS, bool FIRST>
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t* __restrict__ kin,
-                                                               const uint32_t* __restrict__ vin,
-                                                               uint32_t* __restrict__ kout,
-                                                               uint32_t* __restrict__ vout, uint32_t n_arg,
-                                                               const uint32_t* __restrict__ n_dev,
-                                                               uint32_t shift, uint32_t nblocks,
-                                                               const uint32_t* __restrict__ hist,
-                                                               const uint32_t* __restrict__ digit_tot) {
-    constexpr int RADIX = 1 << BITS;
-    constexpr int DPT = RADIX / SORT_THREADS;       // digits per thread: 1 or 2 (consecutive digits)
-    __shared__ uint32_t wh[4][RADIX];     // per-wave digit counters -> running offsets
-    __shared__ uint32_t part[SORT_THREADS];
-    const uint32_t n = sort_count(n_arg, n_dev);
-    const uint32_t nvb = (n + SORT_TILE - 1) / SORT_TILE;
-    if (blockIdx.x >= nvb) return;                  // block-uniform
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // exclusive scan of the digit totals (global base of every digit): thread t owns digits t*DPT ..
-    uint32_t tot[DPT], sum = 0;
+            for (int q = 0; q < SORT_KPT / 4; q++) {
+                const uint32_t i = tile * OS_TILE + (q * SORT_THREADS + threadIdx.x) * 4u;
+                uint4 k4 = make_uint4(0u, 0u, 0u, 0u);
+                if (i + 3u < n) k4 = *reinterpret_cast<const uint4*>(keys + i);
+                else {
+                    if (i < n) k4.x = keys[i];
+                    if (i + 1u < n) k4.y = keys[i + 1u];
+                    if (i + 2u < n) k4.z = keys[i + 2u];
+                }
+                const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
-    for (int k = 0; k < DPT; k++) { tot[k] = digit_tot[threadIdx.x * DPT + k]; sum += tot[k]; }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < SORT_THREADS; off <<= 1) {
-        uint32_t v = threadIdx.x >= (uint32_t)off ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    const uint32_t digit_base = part[threadIdx.x] - sum;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-
-    for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-        for (int w = 0; w < 4; w++)
-            for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) wh[w][d] = 0;
-        uint32_t my_base[DPT];
-        {
-            uint32_t run = digit_base;
-#pragma unroll
-            for (int k = 0; k < DPT; k++) {
-                my_base[k] = run + hist[(size_t)(threadIdx.x * DPT + k) * nblocks + vb];
-                run += tot[k];
+                for (int e = 0; e < 4; e++)
+                    for (uint32_t p = 0; p < passes; p++)
+                        wave_count_digit(h + p * RADIX, (kk[e] >> ((pass0 + p) * BITS)) & (RADIX - 1), i + e < n);
             }
         }
         __syncthreads();
+        const uint32_t grp = group_tiles == OS_ALL_TILES ? 0u : t0 / group_tiles;
+        for (uint32_t d = threadIdx.x; d < passes * RADIX; d += SORT_THREADS)
+            if (h[d]) atomicAdd(&hist[(grp * 4u + pass0 + d / RADIX) * 512u + (d % RADIX)], h[d]);
+        __syncthreads();
+    }
+}
 
-        // load this wave's keys (registers) and count digits per wave
-        const uint32_t wbase = vb * SORT_TILE + wave * SORT_WAVE_TILE;
-        uint32_t key[SORT_KPT];
+// One wave per digit (blockIdx.y = pass - pass0): base[(group * 4 + pass) * 512 + digit] = keys with this digit in
+// EARLIER groups, tot[pass * 512 + digit] = keys with this digit; the counts are zeroed for the next sort and the
+// pass's ticket is re-armed.
+template <int BITS>
+__global__ __launch_bounds__(256) void k_os_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ base,
+                                                 uint32_t* __restrict__ tot, uint32_t n_arg,
+                                                 const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ tickets,
+                                                 uint32_t tickets_stride, uint32_t pass0, uint32_t group_tiles) {
+    constexpr uint32_t RADIX = 1u << BITS;
+    const uint32_t n = sort_count(n_arg, n_dev);
+    const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    const uint32_t ngroups = group_tiles == OS_ALL_TILES ? 1u : (ntiles + group_tiles - 1) / group_tiles;
+    const uint32_t p = pass0 + blockIdx.y;
+    const uint32_t d = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (d >= RADIX) return;                                  // wave-uniform
+    if (d == 0 && lane == 0) tickets[(size_t)p * tickets_stride] = 0u;      // one-group form: one ticket per pass
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += 64u) {
+        const uint32_t g = g0 + lane;
+        const uint32_t idx = (g * 4u + p) * 512u + d;
+        uint32_t v = 0;
+        if (g < ngroups) { v = hist[idx]; hist[idx] = 0u; }
+        if (d == 0 && g < ngroups) tickets[(size_t)p * tickets_stride + g] = 0u;   // grouped form: one ticket per group
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= (uint32_t)off) inc += t;
+        }
+        if (g < ngroups) base[idx] = carry + inc - v;
+        carry += (uint32_t)__shfl((int)inc, 63);
+    }
+    if (lane == 0) tot[p * 512u + d] = carry;
+}
+
+typedef unsigned long long os_word;
+__device__ __forceinline__ void os_publish(os_word* w, uint32_t epoch, bool prefix, uint32_t value) {
+    __hip_atomic_store(w, ((os_word)((epoch << 1) | (prefix ? 1u : 0u)) << 32) | value, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// GROUPED (big sorts, groups of OS_GROUP tiles): a tile publishes ONE word per digit, {epoch:19, count:13} (two digits
+// per 8-byte store), and sums the counts of the <= 15 earlier tiles of its group -- independent loads, all in flight
+// at once, no chain at all; tickets are per group (no hot word).  !GROUPED (one group, the movers' sort: few tiles,
+// but correct for any number): the classic {count} / {inclusive prefix} words with a chained look-back.
+constexpr uint32_t OS_CNT_BITS = 13;                     // a tile holds at most 4096 = 2^12 keys of one digit
+__device__ __forceinline__ uint32_t os_pack32(uint32_t epoch, uint32_t count) { return (epoch << OS_CNT_BITS) | count; }
+
+template <int BITS, bool FIRST, bool GROUPED>
+__global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                          uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                          uint32_t n_arg, const uint32_t* __restrict__ n_dev,
+                                                          uint32_t shift, const uint32_t* __restrict__ group_base,
+                                                          const uint32_t* __restrict__ digit_tot,
+                                                          uint32_t group_tiles, os_word* __restrict__ status,
+                                                          uint32_t* __restrict__ status32,
+                                                          uint32_t* __restrict__ ticket, uint32_t epoch,
+                                                          uint32_t* __restrict__ err) {
+    constexpr int RADIX = 1 << BITS;
+    constexpr int DPT = RADIX / SORT_THREADS;       // digits per thread: 1 or 2 (consecutive digits)
+    __shared__ uint32_t wh[4][RADIX];               // per-wave digit counts -> running positions inside the tile
+    __shared__ uint32_t s_delta[RADIX];             // global position minus LDS position of a digit's keys of this tile
+#if SPH_SORT_STAGE
+    __shared__ uint32_t s_key[OS_TILE], s_val[OS_TILE];
+#endif
+    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_round;
+    if (threadIdx.x == 0) s_round = 0;
+    const uint32_t n = sort_count(n_arg, n_dev);
+    const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // first output position of every digit: exclusive scan of the pass's totals (thread t owns digits t*DPT ..)
+    uint32_t dbase[DPT];
+    {
+        uint32_t tot[DPT], sum = 0;
+#pragma unroll
+        for (int k = 0; k < DPT; k++) { tot[k] = digit_tot[threadIdx.x * DPT + k]; sum += tot[k]; }
+        uint32_t run = block_excl_scan_256(sum, s_wtot, nullptr);
+#pragma unroll
+        for (int k = 0; k < DPT; k++) { dbase[k] = run; run += tot[k]; }
+    }
+    for (;;) {
+        if (threadIdx.x == 0) {
+            if (GROUPED) {
+                // block b of round r belongs to group (b + r * grid) / OS_GROUP and takes the next tile of THAT group:
+                // a tile only ever waits for tiles whose ticket was drawn before its own, i.e. by running blocks
+                const uint32_t vb = blockIdx.x + s_round * gridDim.x;
+                s_round++;
+                const uint32_t g = vb / OS_GROUP;
+                s_tile = g * OS_GROUP + (g * OS_GROUP < ntiles ? atomicAdd(ticket + g, 1u) : 0u);
+                if (g * OS_GROUP >= ntiles) s_tile = 0xFFFFFFFFu;
+            } else {
+                s_tile = atomicAdd(ticket, 1u);
+            }
+        }
+        for (int w = 0; w < 4; w++)
+            for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) wh[w][d] = 0;
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= ntiles) return;                 // block-uniform
+
+        // this wave's 1024 consecutive keys (registers), counted per wave
+        const uint32_t wbase = tile * OS_TILE + wave * SORT_WAVE_TILE;
+        uint32_t key[SORT_KPT], val[SORT_KPT];
 #pragma unroll
         for (int t = 0; t < SORT_KPT; t++) {
-            uint32_t i = wbase + t * WAVE + lane;
+            const uint32_t i = wbase + t * WAVE + lane;
             key[t] = i < n ? kin[i] : 0xFFFFFFFFu;
-            if (i < n) atomicAdd(&wh[wave][(key[t] >> shift) & (RADIX - 1)], 1u);
+            val[t] = FIRST ? i : (i < n ? vin[i] : 0u);
+            wave_count_digit(wh[wave], (key[t] >> shift) & (RADIX - 1), i < n);
         }
         __syncthreads();
-        // per digit: exclusive scan over the 4 waves, plus the global base
+
+        // per digit: count of the tile and exclusive offsets of the four waves; publish the count at once
+        const uint32_t grp = group_tiles == OS_ALL_TILES ? 0u : tile / group_tiles;
+        const uint32_t gstart = group_tiles == OS_ALL_TILES ? 0u : grp * group_tiles;
+        uint32_t cnt[DPT], tstart[DPT];
 #pragma unroll
         for (int k = 0; k < DPT; k++) {
             const uint32_t d = threadIdx.x * DPT + k;
-            uint32_t o = my_base[k];
+            uint32_t o = 0;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                uint32_t cnt = wh[w][d];
-                wh[w][d] = o;
-                o += cnt;
+            for (int w = 0; w < 4; w++) { const uint32_t c = wh[w][d]; wh[w][d] = o; o += c; }
+            cnt[k] = o;
+            if (!GROUPED) os_publish(status + (size_t)tile * RADIX + d, epoch, tile == gstart, o);
+        }
+        if (GROUPED) {
+            uint32_t* st32 = status32 + (size_t)tile * RADIX + threadIdx.x * DPT;
+            if (DPT == 2)
+                __hip_atomic_store(reinterpret_cast<os_word*>(st32),
+                                   ((os_word)os_pack32(epoch, cnt[DPT - 1]) << 32) | os_pack32(epoch, cnt[0]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                __hip_atomic_store(st32, os_pack32(epoch, cnt[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // positions inside the tile: digits in ascending order
+        {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < DPT; k++) sum += cnt[k];
+            uint32_t run = block_excl_scan_256(sum, s_wtot, nullptr);
+#pragma unroll
+            for (int k = 0; k < DPT; k++) {
+                const uint32_t d = threadIdx.x * DPT + k;
+                tstart[k] = run;
+#pragma unroll
+                for (int w = 0; w < 4; w++) wh[w][d] += run;      // wave-exclusive offset + start of the digit
+                run += cnt[k];
             }
         }
         __syncthreads();
 
-        volatile uint32_t* cnt = wh[wave];
+        // rank: rows of 64 keys in order; equal digits of a row by ballot match-any + popcount of the lower lanes
+        volatile uint32_t* pos = wh[wave];
+#if !SPH_SORT_STAGE
+        uint32_t lpos[SORT_KPT];                            // position of the key inside the tile (digit order)
+#endif
 #pragma unroll
         for (int t = 0; t < SORT_KPT; t++) {
-            uint32_t i = wbase + t * WAVE + lane;
-            bool valid = i < n;
-            uint32_t d = (key[t] >> shift) & (RADIX - 1);
+            const uint32_t i = wbase + t * WAVE + lane;
+            const bool valid = i < n;
+            const uint32_t d = (key[t] >> shift) & (RADIX - 1);
             uint64_t peers = __ballot(valid);
 #pragma unroll
             for (int b = 0; b < BITS; b++) {
-                bool bit = (d >> b) & 1u;
-                uint64_t m = __ballot(bit);
+                const bool bit = (d >> b) & 1u;
+                const uint64_t m = __ballot(bit);
                 peers &= bit ? m : ~m;
             }
-            uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
             uint32_t base = 0;
-            if (valid) base = cnt[d];                       // every peer reads the same word
+            if (valid) base = pos[d];                       // every peer reads the same word
             __builtin_amdgcn_wave_barrier();
-            if (valid && rank == 0) cnt[d] = base + (uint32_t)__popcll(peers);   // LDS is in order per wave
+            if (valid && rank == 0) pos[d] = base + (uint32_t)__popcll(peers);   // LDS is in order per wave
             __builtin_amdgcn_wave_barrier();
-            if (valid) {
-                uint32_t dst = base + rank;
-                kout[dst] = key[t];
-                vout[dst] = FIRST ? i : vin[i];
+#if SPH_SORT_STAGE
+            if (valid) { s_key[base + rank] = key[t]; s_val[base + rank] = val[t]; }
+#else
+            lpos[t] = base + rank;
+#endif
+        }
+
+        // keys with the same digit in the EARLIER tiles of the group: decoupled look-back, AFTER the ranking -- by
+        // now the predecessors have long published, so the walk rarely meets an unfinished tile
+        {
+            uint32_t excl[DPT];
+#pragma unroll
+            for (int k = 0; k < DPT; k++) excl[k] = 0;
+            if (GROUPED) {
+                // the counts of the earlier tiles of the group: every load is issued before the first is looked at
+                const uint32_t npred = tile - gstart;
+                const uint32_t* st32 = status32 + (size_t)gstart * RADIX + threadIdx.x * DPT;
+                os_word w[OS_GROUP - 1];
+#pragma unroll
+                for (uint32_t q = 0; q < OS_GROUP - 1; q++)
+                    if (q < npred) {
+                        if (DPT == 2) w[q] = __hip_atomic_load(reinterpret_cast<const os_word*>(st32 + (size_t)q * RADIX),
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else w[q] = __hip_atomic_load(st32 + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                uint32_t spins = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < OS_GROUP - 1; q++)
+                    if (q < npred) {
+                        for (;;) {
+                            const bool ok = (uint32_t)w[q] >> OS_CNT_BITS == epoch &&
+                                            (DPT == 1 || (uint32_t)(w[q] >> 32) >> OS_CNT_BITS == epoch);
+                            if (ok) break;
+                            if (++spins > OS_SPIN_LIMIT) { *err = 1u; w[q] = 0; break; }      // give up: counts of 0
+                            __builtin_amdgcn_s_sleep(1);
+                            if (DPT == 2) w[q] = __hip_atomic_load(reinterpret_cast<const os_word*>(st32 + (size_t)q * RADIX),
+                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else w[q] = __hip_atomic_load(st32 + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        excl[0] += (uint32_t)w[q] & ((1u << OS_CNT_BITS) - 1u);
+                        if (DPT == 2) excl[DPT - 1] += (uint32_t)(w[q] >> 32) & ((1u << OS_CNT_BITS) - 1u);
+                    }
+            } else if (tile != gstart) {
+                bool open[DPT];
+#pragma unroll
+                for (int k = 0; k < DPT; k++) open[k] = true;
+                uint32_t spins = 0;
+                for (uint32_t j = tile; j-- > gstart;) {           // the digits of a thread walk back together
+                    bool any_open = false;
+#pragma unroll
+                    for (int k = 0; k < DPT; k++) {
+                        if (!open[k]) continue;
+                        const os_word* src = status + (size_t)j * RADIX + threadIdx.x * DPT + k;
+                        os_word w;
+                        for (;;) {
+                            w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((uint32_t)(w >> 33) == epoch) break;
+                            if (++spins > OS_SPIN_LIMIT) { *err = 1u; w = (os_word)1 << 32; break; }   // give up: prefix 0
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        excl[k] += (uint32_t)w;
+                        if ((w >> 32) & 1ull) open[k] = false; else any_open = true;
+                    }
+                    if (!any_open) break;
+                }
+#pragma unroll
+                for (int k = 0; k < DPT; k++)
+                    os_publish(status + (size_t)tile * RADIX + threadIdx.x * DPT + k, epoch, true, excl[k] + cnt[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < DPT; k++) {
+                const uint32_t d = threadIdx.x * DPT + k;
+                s_delta[d] = dbase[k] + group_base[(grp * 4u) * 512u + d] + excl[k] - tstart[k];
             }
         }
-        __syncthreads();                                    // wh is re-zeroed by the next tile
+        __syncthreads();
+
+#if SPH_SORT_STAGE
+        // write out in LDS (= digit) order: a digit's keys go to consecutive addresses
+        const uint32_t tile_n = min((uint32_t)OS_TILE, n - tile * OS_TILE);
+#pragma unroll 4
+        for (int t = 0; t < SORT_KPT; t++) {
+            const uint32_t q = t * SORT_THREADS + threadIdx.x;
+            if (q < tile_n) {
+                const uint32_t k = s_key[q];
+                const uint32_t d = (k >> shift) & (RADIX - 1);
+                const uint32_t dst = s_delta[d] + q;
+                kout[dst] = k;
+                vout[dst] = s_val[q];
+            }
+        }
+#else
+#pragma unroll
+        for (int t = 0; t < SORT_KPT; t++) {
+            const uint32_t i = wbase + t * WAVE + lane;
+            if (i < n) {
+                const uint32_t dst = s_delta[(key[t] >> shift) & (RADIX - 1)] + lpos[t];
+                kout[dst] = key[t];
+                vout[dst] = val[t];
+            }
+        }
+#endif
+        __syncthreads();                                    // LDS is re-used by the next tile
     }
 }
 
-// ---- reorder: gather the SoA payload into sorted order; optionally build the cell table ------------
-// CELLS: the {start, end} entries of kernelConstructBGrid (.cu:311-329) fall out of the same pass
-// (boundary flags on the sorted keys, no atomics) when no ghost layers will be added afterwards.
-template <bool CELLS>
+// ---- reorder: gather the SoA payload into sorted order (full-sort path) -----------------------------
 __global__ __launch_bounds__(256) void k_reorder(const uint32_t* __restrict__ ks, const uint32_t* __restrict__ vs,
                                                  uint32_t n, const float4* __restrict__ posi,
                                                  const float4* __restrict__ velr, float4* __restrict__ posi_out,
-                                                 float4* __restrict__ velr_out, uint32_t* __restrict__ key_out,
-                                                 uint2* __restrict__ cells, uint32_t slot0) {
+                                                 float4* __restrict__ velr_out, uint32_t* __restrict__ key_out) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     uint32_t src = vs[i];
-    uint32_t k = ks[i];
     posi_out[i] = posi[src];
     velr_out[i] = velr[src];
-    key_out[i] = k;
-    if (CELLS) {
-        if (i == 0 || ks[i - 1] != k) cells[k].x = slot0 + i;
-        if (i + 1 == n || ks[i + 1] != k) cells[k].y = slot0 + i + 1;
-    }
+    key_out[i] = ks[i];
 }
 
 // ---- initial conditions on the device: twin of sph_ic_dam_break (csrc/particleSystem.cpp) ------------------
@@ -283,39 +513,63 @@ int launch_hash(sph_ctx* c) {
     return SPH_OK;
 }
 
-template <int BITS>
-static void sort_pass(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, uint32_t nblocks, uint32_t shift,
-                      bool first, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout) {
-    hipLaunchKernelGGL(k_sort_hist<BITS>, dim3(grid), dim3(SORT_THREADS), 0, c->stream, kin, n, n_dev, shift, nblocks,
-                       c->hist);
-    hipLaunchKernelGGL(k_sort_scan, dim3(1 << BITS), dim3(256), 0, c->stream, c->hist, nblocks, n, n_dev, c->digit_tot);
-    if (first)
-        hipLaunchKernelGGL((k_sort_scatter<BITS, true>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
-                           vout, n, n_dev, shift, nblocks, c->hist, c->digit_tot);
-    else
-        hipLaunchKernelGGL((k_sort_scatter<BITS, false>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout,
-                           vout, n, n_dev, shift, nblocks, c->hist, c->digit_tot);
-}
-
 // LSD radix sort of (key, value) pairs over the context's significant key bits.  `first`: the values of
 // the first pass are the element indices (vin unused).  n_dev != null: the count lives on the device
-// (<= n), `grid` blocks walk the tiles.  Returns through kin/vin the buffers that hold the result.
-static void radix_sort_pairs(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, bool first, uint32_t*& kin,
-                             uint32_t*& vin, uint32_t*& kout, uint32_t*& vout) {
-    const uint32_t nblocks = ceil_div(n, SORT_TILE);          // row stride of the histogram
-    // 9-bit digits when they save a pass over 8-bit ones (27 bits: 3 x 9), else 8-bit digits.  Measured
-    // per pass at 16.7 M keys: 124 us (8 bits), 150 us (9 bits), 220 us (10 bits: never worth it).
-    const uint32_t p8 = (c->key_bits + 7) / 8, p9 = (c->key_bits + 8) / 9;
-    const uint32_t bits = p9 < p8 ? 9u : 8u;
-    const uint32_t passes = bits == 9u ? p9 : p8;
+// (<= n) and `grid` blocks share the tiles by ticket.  Returns through kin/vin the buffers that hold the result.
+template <int BITS>
+static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, bool first, uint32_t passes,
+                           uint32_t*& kin, uint32_t*& vin, uint32_t*& kout, uint32_t*& vout) {
+    constexpr uint32_t RADIX = 1u << BITS;
+    const bool one_group = grid <= OS_ONE_GROUP_TILES;          // `grid` = tiles expected (exact, or from the hint)
+    const uint32_t group_tiles = one_group ? OS_ALL_TILES : OS_GROUP;
+    const uint32_t hist_grid = min(ceil_div(grid, OS_HIST_TILES), 4096u);
+    const uint32_t gcap = c->os_groups_cap;                     // tickets: [pass][group]
+    if (one_group) {                                            // every pass from one histogram of the input
+        hipLaunchKernelGGL(k_os_hist<BITS>, dim3(hist_grid), dim3(SORT_THREADS), 0, c->stream, kin, n, n_dev, 0u, passes,
+                           group_tiles, c->os_hist);
+        hipLaunchKernelGGL(k_os_scan<BITS>, dim3(RADIX / 4, passes), dim3(256), 0, c->stream, c->os_hist, c->os_base, c->os_tot,
+                           n, n_dev, c->os_tickets, gcap, 0u, group_tiles);
+        SPH_HIP(hipGetLastError());
+    }
     for (uint32_t p = 0; p < passes; p++) {
-        const uint32_t shift = p * bits;
-        if (bits == 8) sort_pass<8>(c, n, n_dev, grid, nblocks, shift, first && p == 0, kin, vin, kout, vout);
-        else sort_pass<9>(c, n, n_dev, grid, nblocks, shift, first && p == 0, kin, vin, kout, vout);
+        if (!one_group) {                                       // the groups' counts of the keys as this pass finds them
+            hipLaunchKernelGGL(k_os_hist<BITS>, dim3(hist_grid), dim3(SORT_THREADS), 0, c->stream, kin, n, n_dev, p, 1u,
+                               group_tiles, c->os_hist);
+            hipLaunchKernelGGL(k_os_scan<BITS>, dim3(RADIX / 4, 1), dim3(256), 0, c->stream, c->os_hist, c->os_base, c->os_tot,
+                               n, n_dev, c->os_tickets, gcap, p, group_tiles);
+            SPH_HIP(hipGetLastError());
+        }
+        // the epoch tags the look-back words of this pass: 19 bits in the grouped form (never 0: that is what a cleared
+        // table holds); when they wrap the table is cleared so that no word of 2^19 passes ago can be taken for new
+        c->os_epoch++;
+        if ((c->os_epoch & 0x7FFFFu) == 0u) {
+            c->os_epoch++;
+            SPH_HIP(hipMemsetAsync(c->os_status32, 0, (size_t)512 * c->sort_blocks_cap * sizeof(uint32_t), c->stream));
+        }
+        const uint32_t epoch = one_group ? (c->os_epoch & 0x7FFFFFFFu) : (c->os_epoch & 0x7FFFFu);
+        uint32_t* tk = c->os_tickets + (size_t)p * gcap;
+#define SPH_OS_LAUNCH(F, G)                                                                                             \
+        hipLaunchKernelGGL((k_os_pass<BITS, F, G>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout, vout, n, \
+                           n_dev, p * BITS, c->os_base + p * 512u, c->os_tot + p * 512u, group_tiles, c->os_status,         \
+                           c->os_status32, tk, epoch,                                                                    \
+                           c->os_err_dev)
+        if (first && p == 0) { if (one_group) SPH_OS_LAUNCH(true, false); else SPH_OS_LAUNCH(true, true); }
+        else { if (one_group) SPH_OS_LAUNCH(false, false); else SPH_OS_LAUNCH(false, true); }
+#undef SPH_OS_LAUNCH
+        SPH_HIP(hipGetLastError());
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
     }
+    return SPH_OK;
+}
+
+static int radix_sort_pairs(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, bool first,
+                            uint32_t*& kin, uint32_t*& vin, uint32_t*& kout, uint32_t*& vout) {
+    // 9-bit digits when they save a pass over 8-bit ones (27 bits: 3 x 9), else 8-bit digits
+    const uint32_t p8 = (c->key_bits + 7) / 8, p9 = (c->key_bits + 8) / 9;
+    if (p9 < p8) return radix_sort_bits<9>(c, n, n_dev, grid, first, p9, kin, vin, kout, vout);
+    return radix_sort_bits<8>(c, n, n_dev, grid, first, p8, kin, vin, kout, vout);
 }
 
 // ---- the sort as a merge: only the particles whose cell changed are sorted -----------------------------------
@@ -325,8 +579,10 @@ static void radix_sort_pairs(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint
 // sorted on their own, and both sequences get their merged positions by rank:
 //   non-mover i :  (i - #movers before i) + #movers with (key, slot) < (A[i], i)
 //   mover r     :  r + #non-movers with (key, slot) < (B, slot)
-// The result is the (key, slot) sequence of the full stable sort, element for element, for ANY number of
-// movers; launch_sort only prefers the full sort when the last known mover count makes it cheaper.
+// The result is the particle order of the full stable sort, element for element, for ANY number of movers;
+// launch_sort only prefers the full sort when the last known mover count makes it cheaper.  Every particle
+// is moved ONCE, straight to its final slot: the non-movers stream through k_mm_scatter (coalesced reads,
+// writes to slots that rise with the source slot), the movers are placed one by one.
 
 __global__ __launch_bounds__(256) void k_mm_mark(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B,
                                                  uint32_t n, uint64_t* __restrict__ mask,
@@ -399,8 +655,8 @@ __global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__
         mk[at] = B[i];
         mi[at] = i;
         at++;
-        // only a cell a mover left can have become empty: clear those, the reorder pass rewrites every
-        // cell that is still occupied (replaces the walk over all old keys, k_cells_clear)
+        // only a cell a mover left can have become empty: clear those, the cell pass after the merge rewrites
+        // every cell that is still occupied (replaces the walk over all old keys, k_cells_clear)
         if (cells) cells[A[i]] = make_uint2(0u, 0u);
     }
 }
@@ -417,22 +673,44 @@ __device__ __forceinline__ uint32_t mm_lower_bound(const uint32_t* __restrict__ 
     return lo;
 }
 
-// non-movers: one thread per slot.  The bracket [L0, L1] of a whole wave is found with wave-uniform
-// (scalar) searches; it is a single point unless a mover lands inside the wave's key span.
-__global__ __launch_bounds__(256) void k_mm_place(const uint32_t* __restrict__ A, uint32_t n,
-                                                  const uint64_t* __restrict__ mask, const uint32_t* __restrict__ M64,
-                                                  const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
-                                                  const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ ks,
-                                                  uint32_t* __restrict__ vs) {
+// Coarse ranks: tileL[t] = #movers with (key, slot) < (A[t * 4096], t * 4096), tileL[ntiles] = m.  The per-wave
+// searches of k_mm_scatter then run inside [tileL[t], tileL[t+1]] -- a handful of movers instead of all of them
+// (16 dependent loads per search at 40 K movers made the placement latency-bound: 180 us at C3).
+constexpr uint32_t MM_RANK_TILE = 4096;
+__global__ __launch_bounds__(256) void k_mm_tile_rank(const uint32_t* __restrict__ A, uint32_t n,
+                                                      const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
+                                                      const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ tileL) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t ntiles = (n + MM_RANK_TILE - 1) / MM_RANK_TILE;
+    if (t > ntiles) return;
+    const uint32_t m = *m_dev;
+    const uint32_t slot = t * MM_RANK_TILE;
+    tileL[t] = t == ntiles ? m : mm_lower_bound(mk, mi, 0u, m, A[slot], slot);
+}
+
+// non-movers: one thread per slot, the particle goes straight to its final slot.  The bracket [L0, L1] of a
+// whole wave is found with wave-uniform (scalar) searches inside the tile's coarse bracket; it is a single
+// point unless a mover lands inside the wave's key span.
+__global__ __launch_bounds__(256) void k_mm_scatter(const uint32_t* __restrict__ A, uint32_t n,
+                                                    const uint64_t* __restrict__ mask, const uint32_t* __restrict__ M64,
+                                                    const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
+                                                    const uint32_t* __restrict__ tileL, const float4* __restrict__ posi,
+                                                    const float4* __restrict__ velr, float4* __restrict__ posi_out,
+                                                    float4* __restrict__ velr_out, uint32_t* __restrict__ key_out,
+                                                    uint32_t* __restrict__ perm_out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t first = __builtin_amdgcn_readfirstlane(i);          // slot of lane 0
     if (first >= n) return;                                            // wave-uniform
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t chunk = first >> 6;
-    const uint32_t m = *m_dev;
     const uint32_t last = min(first + 63u, n - 1u);
-    const uint32_t L0 = mm_lower_bound(mk, mi, 0u, m, A[first], first);
-    const uint32_t L1 = mm_lower_bound(mk, mi, L0, m, A[last], last);
+    const uint32_t tile = first / MM_RANK_TILE;
+    const uint32_t b0 = tileL[tile], b1 = tileL[tile + 1];
+    uint32_t L0 = b0, L1 = b0;
+    if (b0 != b1) {                                                    // wave-uniform
+        L0 = mm_lower_bound(mk, mi, b0, b1, A[first], first);
+        L1 = mm_lower_bound(mk, mi, L0, b1, A[last], last);
+    }
     if (i >= n) return;
     const uint64_t bits = mask[chunk];
     if ((bits >> lane) & 1ull) return;                                 // a mover: placed by k_mm_place_movers
@@ -440,8 +718,10 @@ __global__ __launch_bounds__(256) void k_mm_place(const uint32_t* __restrict__ A
     const uint32_t before = M64[chunk] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
     const uint32_t L = L0 == L1 ? L0 : mm_lower_bound(mk, mi, L0, L1, key, i);
     const uint32_t dst = i - before + L;
-    ks[dst] = key;
-    vs[dst] = i;
+    posi_out[dst] = posi[i];
+    velr_out[dst] = velr[i];
+    key_out[dst] = key;
+    if (perm_out) perm_out[dst] = i;
 }
 
 __global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restrict__ A, uint32_t n,
@@ -449,8 +729,10 @@ __global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restr
                                                          const uint32_t* __restrict__ M64,
                                                          const uint32_t* __restrict__ mk,
                                                          const uint32_t* __restrict__ mi,
-                                                         const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ ks,
-                                                         uint32_t* __restrict__ vs) {
+                                                         const uint32_t* __restrict__ m_dev,
+                                                         const float4* __restrict__ posi, const float4* __restrict__ velr,
+                                                         float4* __restrict__ posi_out, float4* __restrict__ velr_out,
+                                                         uint32_t* __restrict__ key_out, uint32_t* __restrict__ perm_out) {
     const uint32_t m = *m_dev;
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < m; r += gridDim.x * 256u) {
         const uint32_t key = mk[r], slot = mi[r];
@@ -464,8 +746,10 @@ __global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restr
         uint32_t before = m;                           // movers among the slots [0, j)
         if (j < n) before = M64[j >> 6] + (uint32_t)__popcll(mask[j >> 6] & ((1ull << (j & 63u)) - 1ull));
         const uint32_t dst = r + (j - before);
-        ks[dst] = key;
-        vs[dst] = slot;
+        posi_out[dst] = posi[slot];
+        velr_out[dst] = velr[slot];
+        key_out[dst] = key;
+        if (perm_out) perm_out[dst] = slot;
     }
 }
 
@@ -481,38 +765,67 @@ static void mm_tilescan(sph_ctx* c, uint32_t n, bool counted) {
                        c->mm_count_host_dev, counted ? c->mm_total : (unsigned long long*)nullptr);
 }
 
+// Called right after the integrate epilogue has marked the movers: count them at the END of the step, so that
+// the next sort finds the number ready (a caller in lockstep with the device can then skip a sort that has
+// nothing to do without ever waiting for the device).
+void mm_scan_marks(sph_ctx* c) {
+    if (!c->mm_marked || c->mm_scanned) return;
+    mm_tilescan(c, c->mm_marked_n, true);
+    hipEventRecord(c->mm_counted, c->stream);
+    c->mm_scanned = true;
+}
+
 // forget the marks the integrate epilogue left (the scan re-zeroes the tile counts they added to)
 void mm_drop_marks(sph_ctx* c) {
     if (!c->mm_marked) return;
-    mm_tilescan(c, c->mm_marked_n, false);
+    if (!c->mm_scanned) mm_tilescan(c, c->mm_marked_n, false);
     c->mm_marked = false;
+    c->mm_scanned = false;
 }
 
-// (ks, vs) of the stable sort by B, from the current order (sorted by A); see the block comment above
 // step 1 of the merge: the movers are marked (by the integrate epilogue, or here) and counted
 static void launch_merge_count(sph_ctx* c, uint32_t n) {
     if (c->mm_marked && !(c->mm_marked_off == c->own_off && c->mm_marked_n == n)) mm_drop_marks(c);   // another range
-    if (!c->mm_marked)                           // else: the fused integrate epilogue compared the keys already
+    if (!c->mm_marked) {                         // else: the fused integrate epilogue compared the keys already
         hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, c->keyS + c->own_off, c->k0, n,
                            c->mm_mask, c->mm_tile_cnt);
+        c->mm_scanned = false;
+    }
+    if (!c->mm_scanned) {
+        mm_tilescan(c, n, true);
+        hipEventRecord(c->mm_counted, c->stream);
+    }
     c->mm_marked = false;
-    mm_tilescan(c, n, true);
+    c->mm_scanned = false;
 }
 
-static void launch_sort_merge(sph_ctx* c, uint32_t n, bool table_live, uint32_t*& ks, uint32_t*& vs) {
+// the merged order, written straight into posi2 / velr2 / keyS at the canonical offset gcap
+static int launch_sort_merge(sph_ctx* c, uint32_t n, bool table_live) {
     const uint32_t* A = c->keyS + c->own_off;
     const uint32_t* B = c->k0;
     const uint32_t nchunks = ceil_div(n, 64u), nt = ceil_div(nchunks, MM_TILE_CHUNKS);
     uint32_t* mk = c->mm_k0; uint32_t* mi = c->v0; uint32_t* mk2 = c->mm_k1; uint32_t* mi2 = c->mm_v1;
     hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, c->mm_tile_off, A, B,
                        c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr);
-    const uint32_t hint = *c->mm_count_host;                 // whatever step last reported: sizes the grid only
-    radix_sort_pairs(c, n, c->mm_count, merge_grid_for(hint, n), false, mk, mi, mk2, mi2);
-    ks = c->k1; vs = c->v1;
-    hipLaunchKernelGGL(k_mm_place, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, A, n, c->mm_mask, c->mm_M64, mk, mi,
-                       c->mm_count, ks, vs);
+    SPH_HIP(hipGetLastError());
+    const uint32_t hint = *c->mm_count_host;                 // whatever step last reported: sizes the grids only
+    int rc = radix_sort_pairs(c, n, c->mm_count, merge_grid_for(hint, n), false, mk, mi, mk2, mi2);
+    if (rc) return rc;
+    const uint32_t rank_tiles = ceil_div(n, MM_RANK_TILE) + 1u;
+    hipLaunchKernelGGL(k_mm_tile_rank, dim3(ceil_div(rank_tiles, 256u)), dim3(256), 0, c->stream, A, n, mk, mi, c->mm_count,
+                       c->mm_tileL);
+    SPH_HIP(hipGetLastError());
+    uint32_t* perm = c->keep_perm ? c->v1 : (uint32_t*)nullptr;
+    const float4* ps = c->posi + c->own_off; const float4* vs = c->velr + c->own_off;
+    float4* po = c->posi2 + c->gcap; float4* vo = c->velr2 + c->gcap; uint32_t* ko = c->keyS2 + c->gcap;
     hipLaunchKernelGGL(k_mm_place_movers, dim3(min(ceil_div(2u * hint + 1u, 256u) + 15u, 65535u)), dim3(256), 0, c->stream,
-                       A, n, c->mm_mask, c->mm_M64, mk, mi, c->mm_count, ks, vs);
+                       A, n, c->mm_mask, c->mm_M64, mk, mi, c->mm_count, ps, vs, po, vo, ko, perm);
+    SPH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_mm_scatter, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, A, n, c->mm_mask, c->mm_M64, mk, mi,
+                       c->mm_tileL, ps, vs, po, vo, ko, perm);
+    SPH_HIP(hipGetLastError());
+    c->last_perm = perm;
+    return SPH_OK;
 }
 
 int launch_sort(sph_ctx* c) {
@@ -521,8 +834,6 @@ int launch_sort(sph_ctx* c) {
     const uint32_t nblocks = ceil_div(n, SORT_TILE);
     SPH_REQUIRE(nblocks <= c->sort_blocks_cap, SPH_E_CAPACITY, "sort: %u blocks > capacity %u", nblocks,
                 c->sort_blocks_cap);
-    uint32_t* kin = c->k0; uint32_t* vin = c->v0;
-    uint32_t* kout = c->k1; uint32_t* vout = c->v1;
     // The merge needs the order of the last sort to be intact; it is correct for any number of movers but
     // only cheaper than the full sort while they are few (last known count: a hint, never a condition).
     // The mover count the host reads below is whatever the device last reported.  A caller that queues many
@@ -537,18 +848,17 @@ int launch_sort(sph_ctx* c) {
     // sort could take the merge path, which clears only the cells the movers left
     const bool table_live = c->cells_clear_deferred && c->cells_valid;
     c->cells_clear_deferred = false;
-    bool table_kept = false;               // the merge path keeps the live table and clears it sparsely
-    if (can_merge && *c->mm_count_host <= n / 8u) {
+    if (can_merge && (*c->mm_count_host <= n / 8u || c->sort_merge_always)) {
         const bool was_still = *c->mm_count_host == 0u;
         launch_merge_count(c, n);
         if (was_still && table_live && c->own_off == c->gcap) {
             // Nothing moved last time (a fluid at rest: no particle crosses a cell face for many steps).  If that
             // is still so, the order, the keys and the cell table are already those of this step and the whole
-            // sort -- 0.3 ms of copying at C3 -- can be left out.  Only the device knows, and the host does not
-            // wait for it: the count is looked at only if the device has ALREADY produced it (a caller in
-            // lockstep with the device, e.g. one update() per frame); a host that runs ahead of the device
-            // queues the merge, which does the same job for 0 movers.  sph_step stays asynchronous.
-            SPH_HIP(hipEventRecord(c->mm_counted, c->stream));
+            // sort -- 0.25 ms of copying at C3 -- can be left out.  Only the device knows, and the host does not
+            // wait for it: the count is looked at only if the device has ALREADY produced it (it is queued at the
+            // end of the previous step, so a caller in lockstep with the device -- one update() per frame --
+            // finds it); a host that runs ahead of the device queues the merge, which does the same job for 0
+            // movers.  sph_step stays asynchronous.
             if (hipEventQuery(c->mm_counted) == hipSuccess && *c->mm_count_host == 0u) {
                 c->sort_merges++;
                 c->sort_skips++;
@@ -559,50 +869,58 @@ int launch_sort(sph_ctx* c) {
                 return SPH_OK;
             }
         }
-        launch_sort_merge(c, n, table_live, kin, vin);
+        int rc = launch_sort_merge(c, n, table_live);
+        if (rc) return rc;
         c->sort_merges++;
-        table_kept = table_live;
+        if (c->cells_valid && !table_live) {       // a table nobody cleared (e.g. sph_sort without sph_hash): start clean
+            rc = launch_cells_clear(c);
+            if (rc) return rc;
+        }
     } else {
-        if (table_live) {
+        if (c->cells_valid) {                      // live or not: the full sort rebuilds the table from nothing
             int rc = launch_cells_clear(c);
             if (rc) return rc;
         }
         // keep the hint alive, or it would stay high for ever: for free when the integrate epilogue marked
         // the movers (the scan also re-zeroes the tile counts those marks added to), else every 8th sort
         if (c->mm_marked) {
-            mm_tilescan(c, c->mm_marked_n, true);
+            if (!c->mm_scanned) mm_tilescan(c, c->mm_marked_n, true);
             c->mm_marked = false;
+            c->mm_scanned = false;
         } else if (can_merge && (c->sort_calls & 7u) == 0) {
             hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, c->keyS + c->own_off, c->k0, n,
                                c->mm_mask, c->mm_tile_cnt);
             mm_tilescan(c, n, true);
         }
-        radix_sort_pairs(c, n, nullptr, nblocks, true, kin, vin, kout, vout);
-    }
-    // (kin, vin) now hold the sorted pairs; gather the payload to the canonical offset gcap and write the cell
-    // table of the owned slots in the same pass.  A slab context adds the cells of its ghost layers later
-    // (launch_cells_build), and drops those of the particles that leave (sph_migrants_pack).
-    if (c->cells_valid && !table_kept) {   // a table nobody cleared (e.g. sph_sort without sph_hash): start clean
-        int rc = launch_cells_clear(c);
+        uint32_t* kin = c->k0; uint32_t* vin = c->v0;
+        uint32_t* kout = c->k1; uint32_t* vout = c->v1;
+        int rc = radix_sort_pairs(c, n, nullptr, nblocks, true, kin, vin, kout, vout);
         if (rc) return rc;
+        // (kin, vin) now hold the sorted pairs; gather the payload to the canonical offset gcap
+        hipLaunchKernelGGL(k_reorder, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, kin, vin, n, c->posi + c->own_off,
+                           c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap, c->keyS2 + c->gcap);
+        SPH_HIP(hipGetLastError());
+        c->last_perm = vin;
     }
-    hipLaunchKernelGGL(k_reorder<true>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, kin, vin, n,
-                       c->posi + c->own_off, c->velr + c->own_off, c->posi2 + c->gcap, c->velr2 + c->gcap,
-                       c->keyS + c->gcap, c->cells, c->gcap);
-    SPH_HIP(hipGetLastError());
-    if (c->sort_merge) SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
     float4* t4;
     t4 = c->posi; c->posi = c->posi2; c->posi2 = t4;
     t4 = c->velr; c->velr = c->velr2; c->velr2 = t4;
+    uint32_t* tk = c->keyS; c->keyS = c->keyS2; c->keyS2 = tk;
     c->own_off = c->gcap;
-    c->last_perm = vin;
+    // the cell table of the owned slots from boundary flags on the new keys (no atomics, no scan, no host sync).
+    // A slab context adds the cells of its ghost layers later (launch_cells_build), and drops those of the
+    // particles that leave (sph_migrants_pack).
+    c->cells_valid = false;
+    int rc = launch_cells_build_range(c, c->gcap, c->gcap + n);
+    if (rc) return rc;
+    if (c->sort_merge) SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
     c->order_valid = true;
     c->cells_lo = c->gcap; c->cells_hi = c->gcap + n; c->cells_valid = true;
     return SPH_OK;
 }
 
-// sorted slot -> slot before the sort (valid until the next sph_hash); used by the compat seam to
-// move the caller's AoS structs the way thrust::sort would
+// sorted slot -> slot before the sort (valid until the next sph_hash; null = identity); used by the compat
+// seam to move the caller's AoS structs the way thrust::sort would (it sets keep_perm)
 const uint32_t* last_sort_permutation(sph_ctx* c) { return c->last_perm; }
 
 }  // namespace sph

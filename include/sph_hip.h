@@ -114,6 +114,16 @@ int sph_sync(sph_ctx* c);                           /* threadSync, particleSyste
 uint32_t sph_num_particles(const sph_ctx* c);       /* owned particles */
 uint32_t sph_capacity(const sph_ctx* c);
 
+/* Arithmetic of the neighbour passes.  SPH_PRECISION_F32 (default): everything in fp32, the reference's
+ * precision.  SPH_PRECISION_MIXED_F16 (BASELINE config 5): positions, velocities, densities and forces are
+ * stored and integrated in fp32; inside the density and force traversals the per-pair arithmetic and the per-row
+ * accumulators are packed fp16 (two candidates per lane-instruction) on coordinates relative to a wave-local
+ * reference in units of h, with NORMALISED kernel sums (the reference's densities ~2e6 do not fit fp16); row sums
+ * are added up in fp32 and scaled once.  The collision pass stays fp32.  Looser tolerance: DESIGN.md section 4. */
+enum { SPH_PRECISION_F32 = 0, SPH_PRECISION_MIXED_F16 = 1 };
+int sph_set_precision(sph_ctx* c, int precision);
+int sph_get_precision(const sph_ctx* c);
+
 /* ---- state transfer ------------------------------------------------------------------- */
 /* Replace the particle set: n particles, xyz triples; index[i] is the immutable creation
  * index (Particle::index), NULL = 0..n-1.  Replaces copyArrayToDevice of the AoS array
@@ -203,8 +213,10 @@ int sph_timing_reset(sph_ctx* c);
  * Any pointer may be NULL. */
 int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers,
                    uint64_t* movers_total);
-/* merge != 0 (default): the sort may take the merge path; 0: the full radix sort every step (what
- * SPH_SORT_MERGE=0 in the environment selects at sph_create time).  Takes effect at the next sort. */
+/* merge = 1 (default): the sort takes the merge path while few particles change cell (up to 1/8 of them, by
+ * the count the device last reported); 0: the full radix sort every step (what SPH_SORT_MERGE=0 in the
+ * environment selects at sph_create time); 2: the merge path whenever the previous order is intact, whatever
+ * the count (it is exact for any count; for tests).  Takes effect at the next sort. */
 int sph_set_sort_mode(sph_ctx* c, int merge);
 /* 1 if the last sph_sort found that no particle had changed cell and left everything as it was (then
  * every count derived from the sorted order -- sph_slab_counts, sph_halo_count -- is that of the step

@@ -48,6 +48,18 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, in
             REP16(asm volatile("v_fma_f32 %0, -%0, %8, s30\n v_fma_f32 %1, -%1, %8, s30\n v_fma_f32 %2, -%2, %8, s30\n v_fma_f32 %3, -%3, %8, s30\n"
                                "v_fma_f32 %4, -%4, %8, s30\n v_fma_f32 %5, -%5, %8, s30\n v_fma_f32 %6, -%6, %8, s30\n v_fma_f32 %7, -%7, %8, s30\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+        } else if (KIND == 8) {   // v_pk_fma_f16 (two fp16 FMAs per lane): the mixed-precision density kernel's workhorse
+            REP16(asm volatile("v_pk_fma_f16 %0, %0, %8, %9\n v_pk_fma_f16 %1, %1, %8, %9\n v_pk_fma_f16 %2, %2, %8, %9\n v_pk_fma_f16 %3, %3, %8, %9\n"
+                               "v_pk_fma_f16 %4, %4, %8, %9\n v_pk_fma_f16 %5, %5, %8, %9\n v_pk_fma_f16 %6, %6, %8, %9\n v_pk_fma_f16 %7, %7, %8, %9\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 9) {   // v_pk_add_f16 / v_pk_max_f16 / v_pk_mul_f16 mix
+            REP16(asm volatile("v_pk_add_f16 %0, %8, %0\n v_pk_max_f16 %1, %9, %1\n v_pk_mul_f16 %2, %8, %2\n v_pk_add_f16 %3, %8, %3\n"
+                               "v_pk_max_f16 %4, %9, %4\n v_pk_mul_f16 %5, %8, %5\n v_pk_add_f16 %6, %8, %6\n v_pk_max_f16 %7, %9, %7\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 10) {  // v_fma_f16 (one fp16 FMA per lane, VOP3)
+            REP16(asm volatile("v_fma_f16 %0, %0, %8, %9\n v_fma_f16 %1, %1, %8, %9\n v_fma_f16 %2, %2, %8, %9\n v_fma_f16 %3, %3, %8, %9\n"
+                               "v_fma_f16 %4, %4, %8, %9\n v_fma_f16 %5, %5, %8, %9\n v_fma_f16 %6, %6, %8, %9\n v_fma_f16 %7, %7, %8, %9\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -90,5 +102,8 @@ int main() {
     run<3>("v_fma_f32 dependent chain", 128);
     run<4>("v_pk_fma_f32 independent", 128);
     run<5>("v_cmp_ge_f32 + v_addc_co_u32", 128);
+    run<8>("v_pk_fma_f16 independent", 128);
+    run<9>("v_pk_add/max/mul_f16 mix", 128);
+    run<10>("v_fma_f16 independent", 128);
     return 0;
 }

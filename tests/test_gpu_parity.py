@@ -19,12 +19,17 @@ pytestmark = pytest.mark.gpu
 
 # ---- stated fp32 tolerance (north star: "within a stated fp32 tolerance on positions/velocities") ----
 REL_TOL = 1e-5               # density, velocity (relative to the largest magnitude in the array)
-# The collision term is discontinuous (a pair counts or not: d <= 2R and r.v < 0, and the count divides
-# the whole delta-v).  Phase by phase the GPU agrees with the oracle to ~1e-7 with identical counts
-# (scratch lockstep runs: 40 steps, zero count mismatches), but over a free run of 100 steps a 1e-7
-# difference can flip one borderline pair, which moves a handful of particles by ~1e-5 of |v|max.
-# The reference's own CUDA build (FMA contraction on) stands in the same relation to its OpenMP build.
-OUTLIER_FRACTION = 5e-3      # at most this share of the particles may exceed REL_TOL in velocity ...
+# The collision term is discontinuous (a pair counts or not: d <= 2R and r.v < 0, and the count divides the whole
+# delta-v).  From IDENTICAL inputs the GPU decides every pair like the reference (both predicates are evaluated in
+# the reference's operation order: counts bit-exact in test_phases_vs_oracle and in the developed-flow lockstep
+# tests, velocity within REL_TOL for EVERY particle).  In a FREE run the inputs of step k differ by ~1e-7 after
+# k-1 steps, and a pair sitting on d = 2R or r.v = 0 can then be counted on one side only: measured on c1_jitter,
+# the first such pair appears at step 42 and at step 100 one particle of 4096 carries count 2 instead of 3, i.e. a
+# delta-v of 3.4e-4 instead of 2.55e-4 = 1.19e-5 of |v|max (test_free_run_outliers_are_collision_count_flips pins
+# exactly that: every particle beyond REL_TOL has a flipped count).  The same C code built with FMA contraction
+# shows the same flips on the CPU.  Free-run comparisons therefore allow a few particles
+# beyond REL_TOL, none beyond OUTLIER_REL_TOL.
+OUTLIER_FRACTION = 1e-3      # at most this share of the particles may exceed REL_TOL in velocity (free runs only) ...
 OUTLIER_REL_TOL = 1e-4       # ... and none may exceed this
 POS_TOL_PER_BOX = 1e-6       # position: absolute, times the box edge
 FORCE_REL_TOL = 2e-5         # per-phase force arrays, relative to the largest force magnitude
@@ -170,6 +175,40 @@ def test_developed_flow_phase_records_vs_reference_golden(name):
         assert np.array_equal(f["count"], coll[:, 3].astype(np.int32)), "collision counts"
         assert int((coll[:, 3] > 0).sum()) > 0.5 * coll.shape[0]          # the fixture really is full of collisions
         _assert_close("delta_v", f["dv"], coll[:, 0:3], FORCE_REL_TOL, float(np.abs(coll[:, 0:3]).max()))
+
+
+def test_free_run_outliers_are_collision_count_flips():
+    """GPU and oracle both run FREELY for 100 steps from c1_jitter; the collision counts of every step are compared.
+    Until the first count differs every particle is within REL_TOL; afterwards a particle may leave REL_TOL only
+    if its own collision count (or that of a particle within collision range of it) has differed at some step."""
+    g = load_golden("c1_jitter")
+    dt, n = float(g["dt"]), g["pos"].shape[0]
+    flipped = np.zeros(n, dtype=bool)
+    with _ctx(g) as c:
+        c.upload(g["pos"], g["vel"])
+        o = _oracle_linear(g)
+        for s in range(1, 101):
+            c.hash(); c.sort(); c.build_cells(); c.density(); c.force(); c.collide()
+            o.map_zindex(); o.sort(); o.apply_order(c.order()); o.construct_bgrid()
+            o.compute_densities(); o.compute_forces(); o.particle_collisions()
+            mism = c.download_forces(force=False)["count"] != o.by_index("collision_count")
+            flipped |= mism
+            c.integrate(dt); o.integrate(dt)
+            if s % 10 == 0 or mism.any():
+                st, so = c.download(want=("pos", "vel")), o.state()
+                ev = np.abs(st["vel"] - so["vel"]).max(axis=1) / np.abs(so["vel"]).max()
+                if not flipped.any():
+                    assert ev.max() <= REL_TOL, f"step {s}: {ev.max():.2e} with identical collision histories"
+                else:
+                    # partners of a flipped particle feel it through their own delta-v one step later
+                    near = np.zeros(n, dtype=bool)
+                    for k in np.nonzero(flipped)[0]:
+                        near |= np.linalg.norm(so["pos"] - so["pos"][k], axis=1) <= 4.0 / 64.0
+                    bad = ev > REL_TOL
+                    assert not (bad & ~near).any(), f"step {s}: a particle without a flipped pair is off by {ev[bad & ~near].max():.2e}"
+                    assert ev.max() <= OUTLIER_REL_TOL and bad.mean() <= OUTLIER_FRACTION
+        o.close()
+    assert flipped.sum() <= 8, f"{flipped.sum()} particles with a flipped collision count in 100 steps"
 
 
 def test_random_clump_vs_reference_golden():

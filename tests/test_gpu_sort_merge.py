@@ -27,9 +27,11 @@ def _ctx(n, box, grid, merge):
             os.environ["SPH_SORT_MERGE"] = old
 
 
-def _lockstep(pos, vel, box, grid, dt, steps, fused, full_table=False):
+def _lockstep(pos, vel, box, grid, dt, steps, fused, full_table=False, always=False):
     n = pos.shape[0]
     a, b = _ctx(n, box, grid, False), _ctx(n, box, grid, True)
+    if always:
+        b.set_sort_mode(2)                 # the merge path whatever the mover count
     movers = []
     try:
         for c in (a, b):
@@ -74,13 +76,17 @@ def test_few_movers_dam_break(fused):
 
 
 def test_many_movers_and_the_fallback():
-    """Half of the particles change cell every step: the merge is still exact (its grids loop), and once
-    the device has reported the count the full sort takes over (the hint is refreshed every 8th sort)."""
+    """Half of the particles change cell every step: the merge is still exact (its grids loop) when it is forced;
+    left to itself the sort falls back to the full radix sort as soon as the device has reported such a count
+    (the integrate epilogue of every step counts the movers of the next sort)."""
     box, grid = (2.0, 2.0, 2.0), (32, 32, 32)
     pos, vel = ic.random_box(20000, box, speed=60.0, fill=0.45)
+    st, movers = _lockstep(pos, vel, box, grid, 5e-4, 20, True, always=True)
+    assert max(movers) > pos.shape[0] // 8
+    assert st["merges"] == 19
     st, movers = _lockstep(pos, vel, box, grid, 5e-4, 20, True)
     assert max(movers) > pos.shape[0] // 8
-    assert 1 <= st["merges"] < 19
+    assert st["merges"] < 19
 
 
 def test_clump_and_empty_cells():
@@ -95,14 +101,36 @@ def test_clump_and_empty_cells():
 
 
 def test_no_movers_at_all():
-    """A lattice at rest: no particle changes cell, so from the third sort on (the first is the full sort, the
-    second reports "0 movers") the merge path finds nothing to do and leaves order, keys and cell table as they
-    are -- and they still equal what the full sort produces every step."""
+    """A lattice at rest: no particle changes cell, so from the second sort on (the first is the full sort; the
+    integrate epilogue of every step counts the movers of the next sort) the merge path finds nothing to do and
+    leaves order, keys and cell table as they are -- and they still equal what the full sort produces every step.
+    (_lockstep reads the keys back after every step, i.e. the host is in lockstep with the device: the count is
+    only looked at when it is already there, the host never waits for it.)"""
     box, grid = (2.0, 2.0, 2.0), (32, 32, 32)
     pos, vel = ic.dam_break_lattice((8, 8, 8), box, jitter=False)
     st, movers = _lockstep(pos, vel, box, grid, 5e-7, 8, True, full_table=True)
     assert movers == [0] * 8
     assert st["merges"] == 7 and st["skips"] == 7
+
+
+def test_queued_steps_at_rest_never_wait_and_stay_exact():
+    """A host that queues many steps at once runs ahead of the device: the mover count is not there yet when a
+    sort is issued, so nothing is skipped (and nothing is waited for) -- the merge path does the work for 0 movers."""
+    box, grid = (2.0, 2.0, 2.0), (32, 32, 32)
+    pos, vel = ic.dam_break_lattice((8, 8, 8), box, jitter=False)
+    a, b = _ctx(pos.shape[0], box, grid, False), _ctx(pos.shape[0], box, grid, True)
+    try:
+        for c in (a, b):
+            c.upload(pos, vel)
+            c.step(5e-7, 12)
+        st = b.sort_stats()
+        assert st["merges"] == 11 and st["movers_total"] == 0
+        assert np.array_equal(a.keys(), b.keys()) and np.array_equal(a.order(), b.order())
+        sa, sb = a.download(), b.download()
+        for k in ("pos", "vel", "density", "pressure"):
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+    finally:
+        a.close(); b.close()
 
 
 def test_rest_then_motion():
@@ -116,7 +144,8 @@ def test_rest_then_motion():
     try:
         for c in (a, b):
             c.upload(pos, vel)
-            c.step(5e-7, 5)
+            for _ in range(5):                    # a caller in lockstep with the device (one update per frame):
+                c.step(5e-7, 1); c.sync()         # the mover count of the last step is there when the next sort starts
         assert b.sort_stats()["skips"] >= 3
         for c in (a, b):
             c.set_by_index(0, vel=kick)
