@@ -216,6 +216,9 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(ic.CONFIGS) + ["C4"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="--gpus N > 1: weak = 16.7 M particles per GPU; strong = BASELINE config 4 (67,108,864 in total)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="--gpus N > 1: rccl = the library's own RCCL communicator (one rank per GPU); host = host-staged "
+                         "messages over gloo (rehearsal: several ranks on one GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
     args = ap.parse_args()

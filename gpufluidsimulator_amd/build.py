@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsph_hip.so")
-HIP_SOURCES = ["sph_capi.hip", "sph_sort.hip", "sph_pairs.hip", "sph_halo.hip", "sph_compat.hip"]
+HIP_SOURCES = ["sph_capi.hip", "sph_sort.hip", "sph_pairs.hip", "sph_halo.hip", "sph_slab.hip", "sph_compat.hip"]
 CXX_SOURCES = ["particleSystem.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: hipcc's SLP pass packs neighbouring fp32 adds/multiplies into v_pk_*_f32, which on
@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-ldl"])
     # headless driver with the reference's command line (SPH/particles.cpp)
     exe, main_src = os.path.join(HERE, "sph_headless"), os.path.join(CSRC, "sph_headless.cpp")
     if os.path.exists(main_src) and (force or _stale(exe, [main_src, LIB] + headers)):

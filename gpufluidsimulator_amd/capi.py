@@ -21,6 +21,17 @@ class SphError(RuntimeError):
     pass
 
 
+# int exchange(void* self, int tag, const void* send_lo, size_t, void* recv_lo, size_t, const void* send_hi, size_t,
+#              void* recv_hi, size_t, void* hip_stream)   -- `sph_transport.exchange` of include/sph_hip.h
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                          C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Transport(C.Structure):
+    """`sph_transport` of include/sph_hip.h."""
+    _fields_ = [("self", C.c_void_p), ("exchange", EXCHANGE_FN), ("host_buffers", C.c_int)]
+
+
 class Params(C.Structure):
     """`sph_params` of include/sph_hip.h."""
     _fields_ = [("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("grid", C.c_uint32 * 3),
@@ -96,6 +107,14 @@ SIGNATURES = {
     "sph_halo_pack_density": (C.c_int, [_P, C.POINTER(_P), _U32]),
     "sph_halo_unpack_density": (C.c_int, [_P, _P, _P]),
     "sph_layer_histogram": (C.c_int, [_P, _P, _U32]),
+    "sph_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "sph_rccl_transport_create": (C.c_int, [C.POINTER(C.POINTER(Transport)), C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "sph_rccl_transport_destroy": (None, [C.POINTER(Transport)]),
+    "sph_slab_create": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int, C.POINTER(Transport), _U32]),
+    "sph_slab_destroy": (None, [_P]),
+    "sph_slab_step": (C.c_int, [_P, C.c_float, _U32]),
+    "sph_slab_sync": (C.c_int, [_P]),
+    "sph_slab_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     # include/particleSystem.h: host-only twins of ic.py (used by the C++ class's reset())
     "sph_ic_dam_break": (None, [C.POINTER(_U32), C.POINTER(C.c_float), C.c_int, C.c_uint64, C.c_uint64, _P, _P]),
     "sph_ic_random_box": (None, [C.c_uint64, C.POINTER(C.c_float), C.c_float, _U32, C.c_float, _P, _P]),

@@ -323,6 +323,10 @@ static int do_cells(sph_ctx* c) {
     return SPH_OK;
 }
 
+int step_hash(sph_ctx* c) { return do_hash(c); }
+int step_sort(sph_ctx* c) { return do_sort(c); }
+int step_cells(sph_ctx* c) { return do_cells(c); }
+
 static int do_density(sph_ctx* c) {
     PhaseTimer t(c, SPH_PH_DENS);
     int rc = launch_density(c);

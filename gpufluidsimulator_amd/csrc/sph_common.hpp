@@ -176,6 +176,15 @@ int launch_cells_build_range(sph_ctx* c, uint32_t lo, uint32_t hi);
 int launch_cells_build(sph_ctx* c);
 int launch_density(sph_ctx* c);
 int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt);
+// sub-range forms for the slab driver (interior first, boundary layers once the ghosts are in)
+int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi);
+bool force_begin(sph_ctx* c, bool integrate);
+int launch_force_range(sph_ctx* c, uint32_t lo, uint32_t hi, bool force, bool collide, bool integrate, float dt, bool mark);
+void force_finish(sph_ctx* c, bool integrate, bool mark);
+// phase bodies of sph_capi.hip (with their bookkeeping), for the slab driver
+int step_hash(sph_ctx* c);
+int step_sort(sph_ctx* c);
+int step_cells(sph_ctx* c);
 int launch_integrate(sph_ctx* c, float dt);
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }

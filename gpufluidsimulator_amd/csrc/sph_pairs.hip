@@ -437,17 +437,10 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
     }
 }
 
+int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi);
 int launch_density(sph_ctx* c) {
     if (c->n == 0) return SPH_OK;
-    uint32_t lo = c->own_off, hi = c->own_off + c->n;
-    if (c->precision == SPH_PRECISION_MIXED_F16)
-        hipLaunchKernelGGL(k_density_h, dim3(ceil_div(c->n, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
-                           c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
-    else
-        hipLaunchKernelGGL(k_density, dim3(ceil_div(c->n, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
-                           c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
-    SPH_HIP(hipGetLastError());
-    return SPH_OK;
+    return launch_density_range(c, c->own_off, c->own_off + c->n);
 }
 
 // ---- integrate one particle (kernelIntegrate, particleSystem.cu:375-420) ------------------------------
@@ -488,8 +481,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     const uint32_t* __restrict__ keyS, const uint2* __restrict__ cells, float4* __restrict__ fpress,
     float4* __restrict__ fvisc, float4* __restrict__ dvel, float4* __restrict__ posi_out,
     float4* __restrict__ velr_out, float4* __restrict__ pos_by_index, uint32_t* __restrict__ keys_out,
-    uint64_t* __restrict__ mm_mask, uint32_t* __restrict__ mm_tile_cnt, uint32_t tgt_lo, uint32_t tgt_hi, float dt,
-    GridDesc g, Phys ph) {
+    uint64_t* __restrict__ mm_mask, uint32_t* __restrict__ mm_tile_cnt, uint32_t tgt_lo, uint32_t tgt_hi,
+    uint32_t slot0, float dt, GridDesc g, Phys ph) {
     // One candidate = 4 float2 {x,y} {z,vx} {vy,vz} {cp,w} at a 40-byte stride (5 float2, the fifth is
     // padding): one address register serves all four ds_read_b64 through immediate offsets, and the
     // 8-entry (one cell) distance between the lane groups of a wave is 80 dwords = 16 banks, so the four
@@ -661,7 +654,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             if (pos_by_index) pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
             // the next step's cell hash (kernelGetZIndex) while the new position is still in registers
             const uint32_t key = cell_key(g, pi.x, pi.y, pi.z);
-            keys_out[i - tgt_lo] = key;
+            keys_out[i - slot0] = key;                      // slot0: first owned slot (the launch may cover a sub-range)
             if (mm_mask) moved = key != keyS[i];
         } else {
             if (FORCE) {
@@ -673,27 +666,27 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     }
     if (INTEG && mm_mask) {
         // movers of the next sort (sph_sort.hip: the merge path), one bit per slot: this wave IS one 64-slot chunk
+        // (a sub-range launch starts on a chunk boundary: tgt_lo - slot0 is a multiple of 64)
         const uint64_t m = __ballot(moved);
-        const uint32_t chunk = xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave;
-        if (lane == 0 && chunk * WAVE < tgt_hi - tgt_lo) {
+        const uint32_t wave_first = tgt_lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE;
+        const uint32_t chunk = (wave_first - slot0) >> 6;
+        if (lane == 0 && wave_first < tgt_hi) {
             mm_mask[chunk] = m;
             if (m) atomicAdd(&mm_tile_cnt[chunk / MM_TILE_CHUNKS], (uint32_t)__popcll(m));
         }
     }
 }
 
-int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt) {
-    if (c->n == 0) return SPH_OK;
-    const uint32_t lo = c->own_off, hi = c->own_off + c->n;
-    dim3 grid(ceil_div(c->n, PAIR_THREADS)), block(PAIR_THREADS);
-    // the integrate epilogue marks the movers of the next sort; marks of an earlier launch that no sort
-    // consumed are dropped first (they would be counted twice)
-    if (integrate) mm_drop_marks(c);
-    const bool mark = integrate && c->sort_merge && c->order_valid;
+// One launch of the pair kernel over the owned slots [lo, hi) (lo - own_off a multiple of 64).  The fused form
+// (integrate) writes the ping-pong arrays; force_finish() swaps them once every sub-range has been launched.
+int launch_force_range(sph_ctx* c, uint32_t lo, uint32_t hi, bool force, bool collide, bool integrate, float dt, bool mark) {
+    if (hi <= lo) return SPH_OK;
+    SPH_REQUIRE(((lo - c->own_off) & 63u) == 0u, SPH_E_INVALID, "force sub-range does not start on a 64-slot chunk");
+    dim3 grid(ceil_div(hi - lo, PAIR_THREADS)), block(PAIR_THREADS);
 #define SPH_LAUNCH_FORCE(F, C, I)                                                                              \
     hipLaunchKernelGGL((k_force<F, C, I>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->keyS, c->cells, \
                        c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, c->k0,              \
-                       mark ? c->mm_mask : nullptr, c->mm_tile_cnt, lo, hi, dt, c->grid, c->phys)
+                       mark ? c->mm_mask : nullptr, c->mm_tile_cnt, lo, hi, c->own_off, dt, c->grid, c->phys)
     if (force && collide && integrate) SPH_LAUNCH_FORCE(true, true, true);
     else if (force && !collide && !integrate) SPH_LAUNCH_FORCE(true, false, false);
     else if (!force && collide && !integrate) SPH_LAUNCH_FORCE(false, true, false);
@@ -703,16 +696,47 @@ int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt)
     }
 #undef SPH_LAUNCH_FORCE
     SPH_HIP(hipGetLastError());
-    if (integrate) {
-        float4* t;
-        t = c->posi; c->posi = c->posi2; c->posi2 = t;
-        t = c->velr; c->velr = c->velr2; c->velr2 = t;
-        c->keys_fresh = true;
-        if (mark) {
-            c->mm_marked = true; c->mm_scanned = false; c->mm_marked_off = lo; c->mm_marked_n = c->n;
-            mm_scan_marks(c);          // count them now: the next sort finds the number ready
-        }
+    return SPH_OK;
+}
+
+// the integrate epilogue marks the movers of the next sort; marks of an earlier launch that no sort
+// consumed are dropped first (they would be counted twice)
+bool force_begin(sph_ctx* c, bool integrate) {
+    if (integrate) mm_drop_marks(c);
+    return integrate && c->sort_merge && c->order_valid;
+}
+
+void force_finish(sph_ctx* c, bool integrate, bool mark) {
+    if (!integrate) return;
+    float4* t;
+    t = c->posi; c->posi = c->posi2; c->posi2 = t;
+    t = c->velr; c->velr = c->velr2; c->velr2 = t;
+    c->keys_fresh = true;
+    if (mark) {
+        c->mm_marked = true; c->mm_scanned = false; c->mm_marked_off = c->own_off; c->mm_marked_n = c->n;
+        mm_scan_marks(c);          // count them now: the next sort finds the number ready
     }
+}
+
+int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt) {
+    if (c->n == 0) return SPH_OK;
+    const bool mark = force_begin(c, integrate);
+    int rc = launch_force_range(c, c->own_off, c->own_off + c->n, force, collide, integrate, dt, mark);
+    if (rc) return rc;
+    force_finish(c, integrate, mark);
+    return SPH_OK;
+}
+
+// density over the owned slots [lo, hi)
+int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi) {
+    if (hi <= lo) return SPH_OK;
+    if (c->precision == SPH_PRECISION_MIXED_F16)
+        hipLaunchKernelGGL(k_density_h, dim3(ceil_div(hi - lo, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
+                           c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
+    else
+        hipLaunchKernelGGL(k_density, dim3(ceil_div(hi - lo, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
+                           c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
+    SPH_HIP(hipGetLastError());
     return SPH_OK;
 }
 

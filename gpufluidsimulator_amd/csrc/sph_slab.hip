@@ -1,0 +1,510 @@
+// sph_slab.hip -- one time step of a z-slab with its two neighbours, under the C ABI (sph_slab_step).
+//
+// No counterpart in the reference (single GPU).  Round 1 drove this protocol from Python over
+// torch.distributed with three host round trips per step; here the whole step is queued by C++ on two HIP
+// streams with ONE host wait:
+//
+//   main stream                                   comm stream (high priority)
+//   -----------                                   -----------
+//   hash + sort owned particles
+//   layer bounds (device), pack leavers+header -> exchange MIGRANTS (fixed size, counts in-band)
+//   ............ host waits here for {own bounds, neighbours' headers}: the only wait of the step ..........
+//   [arrivals: append, hash, sort again]
+//   pack boundary layers                       -> exchange HALO A (positions, velocities; exact size)
+//   density of the INTERIOR layers                unpack ghosts, cell table of the ghost layers
+//   density of the two boundary layers  <-(event)
+//   pack (rho, p) of the boundary layers       -> exchange HALO B
+//   force+collision+integrate, interior           unpack ghost (rho, p)
+//   force+collision+integrate, boundary <-(event)
+//
+// The interior layers (all but the first and last owned layer) never look at a ghost, so their passes run while
+// the halos travel.  Messages go point to point to the two z-neighbours only: RCCL ncclSend/ncclRecv in one group
+// on the comm stream (sph_rccl_transport_create; over the direct xGMI link), or through a caller-supplied
+// transport (tests: host-staged, several slabs of one GPU or several processes over gloo).
+#include "sph_device.hpp"
+
+#include <dlfcn.h>
+
+#include <cstring>
+#include <new>
+
+namespace sph {
+
+// slot of the first key >= target, for 4 targets (one thread each): the layer bounds of the owned range
+__global__ void k_slab_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t layer, uint32_t zl,
+                              uint32_t* __restrict__ out, volatile uint32_t* __restrict__ out_host) {
+    const uint32_t t = threadIdx.x;
+    if (t >= 4) return;
+    const uint32_t targets[4] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer};
+    uint32_t v = targets[t], lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    out[t] = lo;
+    out_host[t] = lo;
+}
+
+// Leavers sit at the two ends of the sorted owned range: [0, lb0) go down, [lb3, n) go up.  Record 0 of a
+// message is the header {#leavers, #particles that stay in the boundary layer on that side}.
+__global__ __launch_bounds__(256) void k_slab_pack_migrants(const float4* __restrict__ posi, const float4* __restrict__ velr,
+                                                            uint32_t n, const uint32_t* __restrict__ lb, uint32_t cap,
+                                                            float4* __restrict__ out_lo, float4* __restrict__ out_hi) {
+    const uint32_t m_lo = lb[0], m_hi = n - lb[3];
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k == 0) {
+        out_lo[0] = make_float4(__uint_as_float(m_lo), __uint_as_float(lb[1] - lb[0]), 0.f, 0.f);
+        out_lo[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        out_hi[0] = make_float4(__uint_as_float(m_hi), __uint_as_float(lb[3] - lb[2]), 0.f, 0.f);
+        out_hi[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (k < m_lo && k < cap) { out_lo[2 + 2 * k] = posi[k]; out_lo[3 + 2 * k] = velr[k]; }
+    if (k < m_hi && k < cap) { out_hi[2 + 2 * k] = posi[lb[3] + k]; out_hi[3 + 2 * k] = velr[lb[3] + k]; }
+}
+
+__global__ __launch_bounds__(256) void k_slab_pack(const float4* __restrict__ posi, const float4* __restrict__ velr,
+                                                   uint32_t n, float4* __restrict__ rec) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    rec[2 * i] = posi[i];
+    rec[2 * i + 1] = velr[i];
+}
+
+__global__ __launch_bounds__(256) void k_slab_unpack(const float4* __restrict__ rec, uint32_t n, float4* __restrict__ posi,
+                                                     float4* __restrict__ velr, uint32_t* __restrict__ key, GridDesc g) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = rec[2 * i];
+    posi[i] = p;
+    velr[i] = rec[2 * i + 1];
+    if (key) key[i] = cell_key(g, p.x, p.y, p.z);
+}
+
+}  // namespace sph
+
+using namespace sph;
+
+// ---- transports ------------------------------------------------------------------------------------------------
+namespace {
+
+// RCCL through dlopen: libsph_hip.so does not depend on librccl for single-GPU users, and a process that already
+// carries a copy (PyTorch bundles one) keeps using that one.
+struct Id128 { char bytes[128]; };          // ncclUniqueId
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128 /* by value */, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return SPH_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD); if (h) break; }     // a copy already in the process
+    for (const char* nm : names) { if (h) break; h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); }
+    SPH_REQUIRE(h, SPH_E_DEVICE, "librccl not found (%s)", dlerror());
+#define SPH_SYM(field, name)                                                           \
+    *(void**)(&g_rccl.field) = dlsym(h, name);                                          \
+    SPH_REQUIRE(g_rccl.field, SPH_E_DEVICE, "librccl lacks %s", name)
+    SPH_SYM(GetUniqueId, "ncclGetUniqueId");
+    SPH_SYM(CommInitRank, "ncclCommInitRank");
+    SPH_SYM(CommDestroy, "ncclCommDestroy");
+    SPH_SYM(Send, "ncclSend");
+    SPH_SYM(Recv, "ncclRecv");
+    SPH_SYM(GroupStart, "ncclGroupStart");
+    SPH_SYM(GroupEnd, "ncclGroupEnd");
+    SPH_SYM(GetErrorString, "ncclGetErrorString");
+#undef SPH_SYM
+    g_rccl.lib = h;
+    return SPH_OK;
+}
+
+struct RcclLink {
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+#define SPH_NCCL(call)                                                                                   \
+    do {                                                                                                 \
+        int r__ = (call);                                                                                \
+        if (r__ != 0) { set_error("RCCL error %d (%s): %s", r__, g_rccl.GetErrorString(r__), #call); return SPH_E_DEVICE; } \
+    } while (0)
+
+// both neighbours in one group: no ordering between the four transfers, no deadlock
+int rccl_exchange(void* self, int, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
+                  const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes, void* stream) {
+    RcclLink* L = (RcclLink*)self;
+    hipStream_t s = (hipStream_t)stream;
+    const int ncclChar = 0;
+    SPH_NCCL(g_rccl.GroupStart());
+    if (L->rank > 0) {
+        if (send_lo_bytes) SPH_NCCL(g_rccl.Send(send_lo, send_lo_bytes, ncclChar, L->rank - 1, L->comm, s));
+        if (recv_lo_bytes) SPH_NCCL(g_rccl.Recv(recv_lo, recv_lo_bytes, ncclChar, L->rank - 1, L->comm, s));
+    }
+    if (L->rank + 1 < L->world) {
+        if (send_hi_bytes) SPH_NCCL(g_rccl.Send(send_hi, send_hi_bytes, ncclChar, L->rank + 1, L->comm, s));
+        if (recv_hi_bytes) SPH_NCCL(g_rccl.Recv(recv_hi, recv_hi_bytes, ncclChar, L->rank + 1, L->comm, s));
+    }
+    SPH_NCCL(g_rccl.GroupEnd());
+    return SPH_OK;
+}
+
+}  // namespace
+
+struct sph_slab {
+    sph_ctx* c = nullptr;
+    int rank = 0, world = 1;
+    bool has_lo = false, has_hi = false;
+    sph_transport tr{};
+    bool host_staged = false;            // the transport wants host buffers (tests); else device pointers on the comm stream
+    hipStream_t comm = nullptr;
+    hipEvent_t ev_main = nullptr, ev_comm = nullptr, ev_sync = nullptr;
+    uint32_t gcap = 0, mcap = 0;         // halo / migrant capacity per side, in records
+    uint32_t* d_lb = nullptr;            // 4 layer bounds of the owned range (device)
+    uint32_t* h_lb = nullptr;            // pinned: the same 4 + 2 x 4 header words received
+    uint32_t* h_lb_dev = nullptr;        // its device view
+    float4* mig_send[2] = {nullptr, nullptr};   // (1 + mcap) records of 2 float4
+    float4* mig_recv[2] = {nullptr, nullptr};
+    float4* halo_send[2] = {nullptr, nullptr};  // gcap records
+    float4* halo_recv[2] = {nullptr, nullptr};
+    float2* dens_send[2] = {nullptr, nullptr};
+    float2* dens_recv[2] = {nullptr, nullptr};
+    char* stage_send[2] = {nullptr, nullptr};   // pinned staging for host-staged transports
+    char* stage_recv[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0;
+};
+
+namespace {
+
+void slab_free(sph_slab* s) {
+    if (!s) return;
+    for (int k = 0; k < 2; k++) {
+        hipFree(s->mig_send[k]); hipFree(s->mig_recv[k]); hipFree(s->halo_send[k]); hipFree(s->halo_recv[k]);
+        hipFree(s->dens_send[k]); hipFree(s->dens_recv[k]);
+        if (s->stage_send[k]) hipHostFree(s->stage_send[k]);
+        if (s->stage_recv[k]) hipHostFree(s->stage_recv[k]);
+    }
+    hipFree(s->d_lb);
+    if (s->h_lb) hipHostFree(s->h_lb);
+    if (s->ev_main) hipEventDestroy(s->ev_main);
+    if (s->ev_comm) hipEventDestroy(s->ev_comm);
+    if (s->ev_sync) hipEventDestroy(s->ev_sync);
+    if (s->comm) hipStreamDestroy(s->comm);
+    delete s;
+}
+
+// hand the four buffers to the transport.  Device transports get device pointers and the comm stream; host-staged
+// ones get pinned host copies (the comm stream is drained first: a test transport, not the product path).
+int slab_exchange(sph_slab* s, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
+                  const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes) {
+    if (!s->has_lo) send_lo_bytes = recv_lo_bytes = 0;
+    if (!s->has_hi) send_hi_bytes = recv_hi_bytes = 0;
+    if (!s->host_staged) {
+        int rc = s->tr.exchange(s->tr.self, tag, send_lo, send_lo_bytes, recv_lo, recv_lo_bytes, send_hi, send_hi_bytes, recv_hi,
+                                recv_hi_bytes, (void*)s->comm);
+        if (rc < 0 && sph_last_error()[0] == 0) set_error("slab transport failed (tag %d)", tag);
+        return rc;
+    }
+    SPH_REQUIRE(send_lo_bytes <= s->stage_bytes && send_hi_bytes <= s->stage_bytes && recv_lo_bytes <= s->stage_bytes &&
+                    recv_hi_bytes <= s->stage_bytes, SPH_E_CAPACITY, "slab message exceeds the staging buffers");
+    if (send_lo_bytes) SPH_HIP(hipMemcpyAsync(s->stage_send[0], send_lo, send_lo_bytes, hipMemcpyDeviceToHost, s->comm));
+    if (send_hi_bytes) SPH_HIP(hipMemcpyAsync(s->stage_send[1], send_hi, send_hi_bytes, hipMemcpyDeviceToHost, s->comm));
+    SPH_HIP(hipStreamSynchronize(s->comm));
+    int rc = s->tr.exchange(s->tr.self, tag, s->stage_send[0], send_lo_bytes, s->stage_recv[0], recv_lo_bytes, s->stage_send[1],
+                            send_hi_bytes, s->stage_recv[1], recv_hi_bytes, nullptr);
+    if (rc < 0) { if (sph_last_error()[0] == 0) set_error("slab transport failed (tag %d)", tag); return rc; }
+    if (recv_lo_bytes) SPH_HIP(hipMemcpyAsync(recv_lo, s->stage_recv[0], recv_lo_bytes, hipMemcpyHostToDevice, s->comm));
+    if (recv_hi_bytes) SPH_HIP(hipMemcpyAsync(recv_hi, s->stage_recv[1], recv_hi_bytes, hipMemcpyHostToDevice, s->comm));
+    return SPH_OK;
+}
+
+// comm stream continues after everything queued on main so far / main after comm
+int after_main(sph_slab* s) {
+    SPH_HIP(hipEventRecord(s->ev_main, s->c->stream));
+    SPH_HIP(hipStreamWaitEvent(s->comm, s->ev_main, 0));
+    return SPH_OK;
+}
+int after_comm(sph_slab* s) {
+    SPH_HIP(hipEventRecord(s->ev_comm, s->comm));
+    SPH_HIP(hipStreamWaitEvent(s->c->stream, s->ev_comm, 0));
+    return SPH_OK;
+}
+
+uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+int slab_step_once(sph_slab* s, float dt) {
+    sph_ctx* c = s->c;
+    int rc;
+    // ---- hash + sort the owned particles (leavers end up at the two ends of the owned range) -----------------------
+    rc = step_hash(c); if (rc) return rc;
+    rc = step_sort(c); if (rc) return rc;
+    const uint32_t layer = c->grid.g[0] * c->grid.g[1];
+    const uint32_t n0 = c->n;
+    // ---- layer bounds on the device; leavers + header into the fixed-size migrant messages -----------------------
+    hipLaunchKernelGGL(k_slab_bounds, dim3(1), dim3(64), 0, c->stream, c->keyS + c->own_off, n0, layer, c->grid.zl, s->d_lb,
+                       s->h_lb_dev);
+    hipLaunchKernelGGL(k_slab_pack_migrants, dim3(ceil_div(s->mcap, 256u)), dim3(256), 0, c->stream, c->posi + c->own_off,
+                       c->velr + c->own_off, n0, s->d_lb, s->mcap, s->mig_send[0], s->mig_send[1]);
+    SPH_HIP(hipGetLastError());
+    rc = after_main(s); if (rc) return rc;
+    const size_t mig_bytes = (size_t)(1 + s->mcap) * 2 * sizeof(float4);
+    rc = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
+                       s->mig_recv[1], mig_bytes);
+    if (rc) return rc;
+    if (s->has_lo) SPH_HIP(hipMemcpyAsync(s->h_lb + 4, s->mig_recv[0], 16, hipMemcpyDeviceToHost, s->comm));
+    if (s->has_hi) SPH_HIP(hipMemcpyAsync(s->h_lb + 8, s->mig_recv[1], 16, hipMemcpyDeviceToHost, s->comm));
+    SPH_HIP(hipEventRecord(s->ev_sync, s->comm));
+    // ---- the one host wait of the step: own bounds (written by k_slab_bounds before the comm stream started) and
+    //      the neighbours' headers -------------------------------------------------------------------------------
+    SPH_HIP(hipEventSynchronize(s->ev_sync));
+    s->host_waits++;
+    const uint32_t lb0 = s->h_lb[0], lb1 = s->h_lb[1], lb2 = s->h_lb[2], lb3 = s->h_lb[3];
+    const uint32_t m_lo = lb0, m_hi = n0 - lb3;
+    uint32_t own_lo = lb1 - lb0, own_hi = lb3 - lb2;
+    const uint32_t in_lo = s->has_lo ? s->h_lb[4] : 0u, peer_own_lo = s->has_lo ? s->h_lb[5] : 0u;
+    const uint32_t in_hi = s->has_hi ? s->h_lb[8] : 0u, peer_own_hi = s->has_hi ? s->h_lb[9] : 0u;
+    SPH_REQUIRE(s->has_lo || m_lo == 0, SPH_E_STATE, "rank %d: %u particles below the lowest slab", s->rank, m_lo);
+    SPH_REQUIRE(s->has_hi || m_hi == 0, SPH_E_STATE, "rank %d: %u particles above the highest slab", s->rank, m_hi);
+    SPH_REQUIRE(m_lo <= s->mcap && m_hi <= s->mcap && in_lo <= s->mcap && in_hi <= s->mcap, SPH_E_CAPACITY,
+                "rank %d: a burst of %u/%u leaving, %u/%u arriving particles exceeds the migrant capacity %u", s->rank, m_lo, m_hi,
+                in_lo, in_hi, s->mcap);
+    // ---- drop the leavers (their cells hold nothing else until the ghosts arrive) ------------------------------------
+    if (m_lo || m_hi) {
+        if (c->cells_valid && c->cells_lo == c->own_off && c->cells_hi == c->own_off + c->n) {
+            rc = launch_cells_clear_range(c, c->own_off, c->own_off + m_lo);
+            if (!rc) rc = launch_cells_clear_range(c, c->own_off + c->n - m_hi, c->own_off + c->n);
+            if (rc) return rc;
+            c->cells_lo += m_lo;
+            c->cells_hi -= m_hi;
+        }
+        c->own_off += m_lo;
+        c->n -= m_lo + m_hi;
+        s->migrants += m_lo + m_hi;
+    }
+    // ---- arrivals become owned particles: appended behind the owned range and merged by a second sort.  They land in
+    //      the boundary layer next to the cut they crossed, so the boundary counts are known without counting again ------
+    if (in_lo || in_hi) {
+        SPH_REQUIRE(c->n + in_lo + in_hi <= c->cap && c->own_off + c->n + in_lo + in_hi <= c->tot, SPH_E_CAPACITY,
+                    "rank %d: %u + %u arriving particles exceed the capacity %u", s->rank, c->n, in_lo + in_hi, c->cap);
+        rc = after_comm(s); if (rc) return rc;                  // the received records are in mig_recv
+        for (int side = 0; side < 2; side++) {
+            const uint32_t cnt = side == 0 ? in_lo : in_hi;
+            if (!cnt) continue;
+            const uint32_t at = c->own_off + c->n;
+            hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(cnt, 256u)), dim3(256), 0, c->stream, s->mig_recv[side] + 2, cnt,
+                               c->posi + at, c->velr + at, (uint32_t*)nullptr, c->grid);
+            c->n += cnt;
+        }
+        SPH_HIP(hipGetLastError());
+        c->keys_fresh = false;
+        c->order_valid = false;
+        c->stage = sph_ctx::ST_LOADED;
+        rc = step_hash(c); if (rc) return rc;
+        rc = step_sort(c); if (rc) return rc;
+        own_lo += in_lo;
+        own_hi += in_hi;
+        s->resorts++;
+    }
+    const uint32_t n = c->n;
+    const uint32_t g_lo = s->has_lo ? peer_own_lo + m_lo : 0u;   // ghosts I receive = what stayed in the neighbour's
+    const uint32_t g_hi = s->has_hi ? peer_own_hi + m_hi : 0u;   // boundary layer + what I just sent there
+    const uint32_t h_lo = s->has_lo ? own_lo : 0u, h_hi = s->has_hi ? own_hi : 0u;
+    SPH_REQUIRE(own_lo <= n && own_hi <= n, SPH_E_STATE, "rank %d: inconsistent boundary counts", s->rank);
+    SPH_REQUIRE(h_lo <= s->gcap && h_hi <= s->gcap && g_lo <= s->gcap && g_hi <= s->gcap && g_lo <= c->own_off &&
+                    c->own_off + n + g_hi <= c->tot, SPH_E_CAPACITY,
+                "rank %d: a boundary layer of %u/%u (ghosts %u/%u) exceeds the ghost capacity %u", s->rank, h_lo, h_hi, g_lo, g_hi,
+                s->gcap);
+    // ---- halo A: boundary layers -> neighbours' ghost layers; the interior density runs meanwhile ------------------
+    if (h_lo) hipLaunchKernelGGL(k_slab_pack, dim3(ceil_div(h_lo, 256u)), dim3(256), 0, c->stream, c->posi + c->own_off,
+                                 c->velr + c->own_off, h_lo, s->halo_send[0]);
+    if (h_hi) hipLaunchKernelGGL(k_slab_pack, dim3(ceil_div(h_hi, 256u)), dim3(256), 0, c->stream, c->posi + c->own_off + n - h_hi,
+                                 c->velr + c->own_off + n - h_hi, h_hi, s->halo_send[1]);
+    SPH_HIP(hipGetLastError());
+    rc = after_main(s); if (rc) return rc;                      // the comm stream may start once the slices are packed
+    // interior = everything but the two boundary layers, in whole 64-slot chunks (the fused force pass marks the
+    // movers of the next sort per chunk).  Queued BEFORE the transfers are handed to the transport: the main stream
+    // has the bulk of the step's work in its queue while the halo travels.
+    uint32_t a = c->own_off + ((h_lo + 63u) & ~63u), b = c->own_off + ((n - h_hi) & ~63u);
+    if (b < a || a > c->own_off + n) { a = c->own_off; b = c->own_off; }     // a thin slab: everything is "boundary"
+    rc = launch_density_range(c, a, b); if (rc) return rc;
+    const size_t rec = 2 * sizeof(float4);
+    rc = slab_exchange(s, SPH_TAG_HALO_A, s->halo_send[0], h_lo * rec, s->halo_recv[0], g_lo * rec, s->halo_send[1], h_hi * rec,
+                       s->halo_recv[1], g_hi * rec);
+    if (rc) return rc;
+    // ghosts go directly in front of / behind the owned range, already in key order; their cells join the table of
+    // the owned slots (comm stream: none of it is touched by the interior passes)
+    if (g_lo) hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(g_lo, 256u)), dim3(256), 0, s->comm, s->halo_recv[0], g_lo,
+                                 c->posi + c->own_off - g_lo, c->velr + c->own_off - g_lo, c->keyS + c->own_off - g_lo, c->grid);
+    if (g_hi) hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(g_hi, 256u)), dim3(256), 0, s->comm, s->halo_recv[1], g_hi,
+                                 c->posi + c->own_off + n, c->velr + c->own_off + n, c->keyS + c->own_off + n, c->grid);
+    SPH_HIP(hipGetLastError());
+    c->n_glo = g_lo; c->n_ghi = g_hi;
+    s->ghosts += g_lo + g_hi;
+    {
+        hipStream_t main = c->stream;
+        c->stream = s->comm;                                     // the ghost cells are built on the comm stream
+        rc = launch_cells_build_range(c, c->own_off - g_lo, c->own_off);
+        if (!rc) rc = launch_cells_build_range(c, c->own_off + n, c->own_off + n + g_hi);
+        c->stream = main;
+        if (rc) return rc;
+        c->cells_lo = c->own_off - g_lo; c->cells_hi = c->own_off + n + g_hi; c->cells_valid = true;
+        c->stage = sph_ctx::ST_CELLS;
+    }
+    rc = after_comm(s); if (rc) return rc;
+    rc = launch_density_range(c, c->own_off, a); if (rc) return rc;
+    rc = launch_density_range(c, b, c->own_off + n); if (rc) return rc;
+    c->have_dens = true;
+    // ---- halo B: (density, pressure) of the same boundary particles, same order; interior forces meanwhile ---------
+    if (h_lo) SPH_HIP(hipMemcpyAsync(s->dens_send[0], c->dp + c->own_off, h_lo * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+    if (h_hi) SPH_HIP(hipMemcpyAsync(s->dens_send[1], c->dp + c->own_off + n - h_hi, h_hi * sizeof(float2), hipMemcpyDeviceToDevice,
+                                     c->stream));
+    rc = after_main(s); if (rc) return rc;
+    const bool mark = force_begin(c, true);
+    rc = launch_force_range(c, a, b, true, true, true, dt, mark); if (rc) return rc;       // interior: queued before the transfer
+    rc = slab_exchange(s, SPH_TAG_HALO_B, s->dens_send[0], h_lo * sizeof(float2), s->dens_recv[0], g_lo * sizeof(float2),
+                       s->dens_send[1], h_hi * sizeof(float2), s->dens_recv[1], g_hi * sizeof(float2));
+    if (rc) return rc;
+    if (g_lo) SPH_HIP(hipMemcpyAsync(c->dp + c->own_off - g_lo, s->dens_recv[0], g_lo * sizeof(float2), hipMemcpyDeviceToDevice, s->comm));
+    if (g_hi) SPH_HIP(hipMemcpyAsync(c->dp + c->own_off + n, s->dens_recv[1], g_hi * sizeof(float2), hipMemcpyDeviceToDevice, s->comm));
+    rc = after_comm(s); if (rc) return rc;
+    rc = launch_force_range(c, c->own_off, a, true, true, true, dt, mark); if (rc) return rc;
+    rc = launch_force_range(c, b, c->own_off + n, true, true, true, dt, mark); if (rc) return rc;
+    force_finish(c, true, mark);
+    c->have_force = c->have_coll = false;
+    // the comm stream must not start the next step's transfers into buffers the main stream still reads
+    rc = after_main(s); if (rc) return rc;
+    s->steps++;
+    return SPH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sph_rccl_unique_id(uint8_t id[128]) {
+    SPH_REQUIRE(id, SPH_E_INVALID, "null argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    SPH_NCCL(g_rccl.GetUniqueId(id));
+    return SPH_OK;
+}
+
+int sph_rccl_transport_create(sph_transport** out, const uint8_t id[128], int rank, int world, int device) {
+    SPH_REQUIRE(out && id && world >= 1 && rank >= 0 && rank < world, SPH_E_INVALID, "bad argument");
+    *out = nullptr;
+    int rc = rccl_load();
+    if (rc) return rc;
+    if (device < 0) device = sph_selected_device();
+    SPH_HIP(hipSetDevice(device));
+    RcclLink* L = new (std::nothrow) RcclLink();
+    sph_transport* t = new (std::nothrow) sph_transport();
+    if (!L || !t) { delete L; delete t; set_error("out of host memory"); return SPH_E_NOMEM; }
+    L->rank = rank; L->world = world;
+    Id128 uid;
+    memcpy(uid.bytes, id, 128);
+    int r = g_rccl.CommInitRank(&L->comm, world, uid, rank);
+    if (r != 0) {
+        set_error("ncclCommInitRank failed: %d (%s)", r, g_rccl.GetErrorString(r));
+        delete L; delete t;
+        return SPH_E_DEVICE;
+    }
+    t->self = L;
+    t->exchange = rccl_exchange;
+    t->host_buffers = 0;
+    *out = t;
+    return SPH_OK;
+}
+
+void sph_rccl_transport_destroy(sph_transport* t) {
+    if (!t) return;
+    RcclLink* L = (RcclLink*)t->self;
+    if (L) { if (L->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(L->comm); delete L; }
+    delete t;
+}
+
+int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph_transport* transport,
+                    uint32_t migrant_capacity) {
+    SPH_REQUIRE(out && ctx && transport && transport->exchange, SPH_E_INVALID, "null argument");
+    *out = nullptr;
+    SPH_REQUIRE(ctx->slab, SPH_E_INVALID, "sph_slab_create needs a context made by sph_create_slab");
+    SPH_REQUIRE(world >= 1 && rank >= 0 && rank < world, SPH_E_INVALID, "bad rank %d of %d", rank, world);
+    SPH_REQUIRE(world == 1 || ctx->z_hi - ctx->z_lo >= 2, SPH_E_INVALID,
+                "a slab needs at least two cell layers (its two boundary layers must be different layers)");
+    SPH_HIP(hipSetDevice(ctx->device));
+    sph_slab* s = new (std::nothrow) sph_slab();
+    SPH_REQUIRE(s, SPH_E_NOMEM, "out of host memory");
+    s->c = ctx; s->rank = rank; s->world = world;
+    s->has_lo = rank > 0; s->has_hi = rank + 1 < world;
+    s->tr = *transport;
+    s->host_staged = transport->host_buffers != 0;
+    s->gcap = ctx->gcap;
+    s->mcap = migrant_capacity ? migrant_capacity : (ctx->gcap / 8u + 1024u);
+    if (s->mcap > ctx->gcap) s->mcap = ctx->gcap;
+    int lo_pri = 0, hi_pri = 0;
+    hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);
+    bool ok = hipStreamCreateWithPriority(&s->comm, hipStreamNonBlocking, hi_pri) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_sync, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc((void**)&s->d_lb, 16 * sizeof(uint32_t)) == hipSuccess &&
+              hipHostMalloc((void**)&s->h_lb, 16 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer((void**)&s->h_lb_dev, s->h_lb, 0) == hipSuccess;
+    const size_t mig_bytes = (size_t)(1 + s->mcap) * 2 * sizeof(float4), halo_bytes = (size_t)(s->gcap + 1) * 2 * sizeof(float4);
+    for (int k = 0; k < 2 && ok; k++)
+        ok = hipMalloc((void**)&s->mig_send[k], mig_bytes) == hipSuccess && hipMalloc((void**)&s->mig_recv[k], mig_bytes) == hipSuccess &&
+             hipMalloc((void**)&s->halo_send[k], halo_bytes) == hipSuccess && hipMalloc((void**)&s->halo_recv[k], halo_bytes) == hipSuccess &&
+             hipMalloc((void**)&s->dens_send[k], (size_t)(s->gcap + 1) * sizeof(float2)) == hipSuccess &&
+             hipMalloc((void**)&s->dens_recv[k], (size_t)(s->gcap + 1) * sizeof(float2)) == hipSuccess &&
+             hipMemset(s->mig_send[k], 0, mig_bytes) == hipSuccess && hipMemset(s->mig_recv[k], 0, mig_bytes) == hipSuccess;
+    if (ok && s->host_staged) {
+        s->stage_bytes = mig_bytes > halo_bytes ? mig_bytes : halo_bytes;
+        for (int k = 0; k < 2 && ok; k++)
+            ok = hipHostMalloc((void**)&s->stage_send[k], s->stage_bytes) == hipSuccess &&
+                 hipHostMalloc((void**)&s->stage_recv[k], s->stage_bytes) == hipSuccess;
+    }
+    if (!ok) { set_error("sph_slab_create: allocation failed"); slab_free(s); return SPH_E_NOMEM; }
+    memset(s->h_lb, 0, 16 * sizeof(uint32_t));
+    *out = s;
+    return SPH_OK;
+}
+
+void sph_slab_destroy(sph_slab* s) {
+    if (!s) return;
+    hipSetDevice(s->c->device);
+    hipStreamSynchronize(s->comm);
+    hipStreamSynchronize(s->c->stream);
+    slab_free(s);
+}
+
+int sph_slab_step(sph_slab* s, float dt, uint32_t n_steps) {
+    SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
+    SPH_HIP(hipSetDevice(s->c->device));
+    for (uint32_t k = 0; k < n_steps; k++) {
+        int rc = slab_step_once(s, dt);
+        if (rc) return rc;
+    }
+    return SPH_OK;
+}
+
+int sph_slab_sync(sph_slab* s) {
+    SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
+    SPH_HIP(hipSetDevice(s->c->device));
+    SPH_HIP(hipStreamSynchronize(s->comm));
+    return sph_sync(s->c);
+}
+
+int sph_slab_stats(const sph_slab* s, uint64_t out[5]) {
+    SPH_REQUIRE(s && out, SPH_E_INVALID, "null argument");
+    out[0] = s->steps; out[1] = s->migrants; out[2] = s->resorts; out[3] = s->ghosts; out[4] = s->host_waits;
+    return SPH_OK;
+}
+
+}  // extern "C"

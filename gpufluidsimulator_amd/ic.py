@@ -119,6 +119,9 @@ CONFIGS = {
     "C1": dict(lattice=(16, 16, 16), box=(4.0, 4.0, 4.0), grid=(64, 64, 64), steps=100),
     "C2": dict(lattice=(64, 64, 64), box=(8.0, 8.0, 8.0), grid=(128, 128, 128), steps=20),
     "C3": dict(lattice=(256, 256, 256), box=(32.0, 32.0, 32.0), grid=(512, 512, 512), steps=20),
+    # BASELINE config 4: 67,108,864 particles in total, cut into z-slabs over 2 -> 4 -> 8 GPUs (strong scaling);
+    # long axis = z, the slab axis
+    "C4": dict(lattice=(256, 512, 512), box=(64.0, 64.0, 64.0), grid=(1024, 1024, 1024), steps=20),
 }
 
 

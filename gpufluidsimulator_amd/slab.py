@@ -26,6 +26,7 @@ from __future__ import annotations
 import json
 import os
 import queue
+import sys
 import threading
 import time
 
@@ -127,6 +128,15 @@ class TorchDistComm:
 
     def barrier(self):
         self.dist.barrier()
+
+    def broadcast_bytes(self, data):
+        """rank 0's bytes on every rank (the RCCL unique id)."""
+        n = self.torch.tensor([len(data) if data is not None else 0], dtype=self.torch.int64, device=self.wire)
+        self.dist.broadcast(n, 0)
+        buf = (self.torch.frombuffer(bytearray(data), dtype=self.torch.uint8).to(self.wire) if data is not None
+               else self.torch.zeros(int(n.item()), dtype=self.torch.uint8, device=self.wire))
+        self.dist.broadcast(buf, 0)
+        return bytes(buf.cpu().numpy().tobytes())
 
 
 class LocalComm:
@@ -466,6 +476,138 @@ class SlabSimulation:
 
 
 # ------------------------------------------------------------------------------------------------
+# the native step: csrc/sph_slab.hip under the C ABI (sph_slab_step); Python is launcher and set-up only
+# ------------------------------------------------------------------------------------------------
+def host_transport(comm):
+    """A `sph_transport` that moves the library's pinned HOST staging buffers through `comm.exchange`
+    (LocalComm: several slabs of one GPU in one process; TorchDistComm over gloo: several processes on one
+    GPU).  For rehearsals and tests -- the product transport is RCCL (rccl_transport)."""
+    import ctypes as C
+
+    import torch
+
+    def view(ptr, nbytes):
+        return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr))) if nbytes else None
+
+    lo = comm.rank - 1 if comm.rank > 0 else None
+    hi = comm.rank + 1 if comm.rank + 1 < comm.world else None
+
+    def exchange(_self, _tag, send_lo, n_send_lo, recv_lo, n_recv_lo, send_hi, n_send_hi, recv_hi, n_recv_hi, _stream):
+        try:
+            sends, recvs = [], []
+            if lo is not None:
+                if n_send_lo: sends.append((lo, view(send_lo, n_send_lo)))
+                if n_recv_lo: recvs.append((lo, view(recv_lo, n_recv_lo)))
+            if hi is not None:
+                if n_send_hi: sends.append((hi, view(send_hi, n_send_hi)))
+                if n_recv_hi: recvs.append((hi, view(recv_hi, n_recv_hi)))
+            comm.exchange(sends, recvs)
+            return 0
+        except BaseException as e:     # noqa: BLE001 -- an exception must not unwind through the C caller
+            import traceback
+            traceback.print_exc()
+            host_transport.last_error = e
+            return -2
+
+    fn = capi.EXCHANGE_FN(exchange)
+    t = capi.Transport(None, fn, 1)
+    t._keepalive = fn
+    return t
+
+
+def rccl_transport(rank, world, device_index, broadcast_id):
+    """The product transport: RCCL send/recv on the library's comm stream.  `broadcast_id(bytes|None) -> bytes`
+    hands rank 0's 128-byte id to every rank (the launcher's job: torch.distributed broadcast, a file, ...)."""
+    import ctypes as C
+    L = capi.load()
+    buf = (C.c_uint8 * 128)()
+    if rank == 0:
+        capi._check(L.sph_rccl_unique_id(buf))
+    raw = broadcast_id(bytes(buf) if rank == 0 else None)
+    buf = (C.c_uint8 * 128).from_buffer_copy(raw)
+    t = C.POINTER(capi.Transport)()
+    capi._check(L.sph_rccl_transport_create(C.byref(t), buf, rank, world, device_index))
+    return t
+
+
+class NativeSlabSimulation(SlabSimulation):
+    """Set-up (cuts, slab-by-slab lattice, upload, re-balancing, gathering) as SlabSimulation; the time step is ONE
+    call into libsph_hip.so per rank: sph_slab_step queues sort, migrants, halo A, density, halo B and the fused
+    force pass on two HIP streams and waits for the device once (csrc/sph_slab.hip)."""
+
+    def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, **kw):
+        self._device_index = device_index
+        self._transport_kind = transport
+        self._migrant_capacity = migrant_capacity
+        self._slab = None
+        self._tr = None
+        super().__init__(comm, lambda cap, gcap, p, z0, z1: HipEngine(cap, gcap, p, z0, z1, device_index), box, grid, **kw)
+        self._bind()
+
+    def _alloc_buffers(self):          # the library owns the message buffers
+        pass
+
+    def _bind(self):
+        import ctypes as C
+        L = capi.load()
+        self._unbind()
+        if self._transport_kind == "rccl":
+            if self._tr is None:       # one communicator for the life of the run (re-balancing keeps it)
+                self._tr = rccl_transport(self.rank, self.world, self._device_index, self.comm.broadcast_bytes)
+            tr = self._tr
+        else:
+            self._tr = host_transport(self.comm)
+            tr = C.pointer(self._tr)
+        h = C.c_void_p()
+        capi._check(L.sph_slab_create(C.byref(h), self.engine.ctx.h, self.rank, self.world, tr, int(self._migrant_capacity)))
+        self._slab = h
+
+    def _unbind(self):
+        if self._slab:
+            capi.load().sph_slab_destroy(self._slab)
+            self._slab = None
+
+    def step(self, dt):
+        self.run(dt, 1)
+
+    def run(self, dt, steps, rebalance_every=0):
+        L = capi.load()
+        done = 0
+        while done < steps:
+            k = steps - done if not rebalance_every else min(steps - done, rebalance_every - done % rebalance_every)
+            capi._check(L.sph_slab_step(self._slab, float(dt), int(k)))
+            done += k
+            if rebalance_every and done % rebalance_every == 0:
+                self.rebalance()
+        self._pull_stats()
+
+    def _pull_stats(self):
+        import ctypes as C
+        out = (C.c_uint64 * 5)()
+        capi._check(capi.load().sph_slab_stats(self._slab, out))
+        base = getattr(self, "_stats_base", {"migrants": 0, "resorts": 0, "ghosts": 0, "host_waits": 0, "steps": 0})
+        self.stats.update(steps=base["steps"] + int(out[0]), migrants=base["migrants"] + int(out[1]),
+                          resorts=base["resorts"] + int(out[2]), ghosts=base["ghosts"] + int(out[3]),
+                          host_waits=base["host_waits"] + int(out[4]))
+
+    def sync(self):
+        capi._check(capi.load().sph_slab_sync(self._slab))
+
+    def rebalance(self, tolerance=0.02):
+        self.sync()
+        self._pull_stats()
+        self._stats_base = {k: self.stats.get(k, 0) for k in ("migrants", "resorts", "ghosts", "host_waits", "steps")}
+        self._unbind()                 # the engine (context) is replaced when the cuts move
+        moved = super().rebalance(tolerance)
+        self._bind()
+        return moved
+
+    def close(self):
+        self._unbind()
+        self.engine.close()
+
+
+# ------------------------------------------------------------------------------------------------
 # bench entry (bench.py --gpus N, one rank per GPU under torch.distributed.run)
 # ------------------------------------------------------------------------------------------------
 def bench_main(args):
@@ -477,49 +619,71 @@ def bench_main(args):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")     # only a direct single-rank run gets here without a launcher
+    transport = getattr(args, "transport", "rccl")
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    comm = TorchDistComm(torch.device("cuda", local))
-    cfg = ic.weak_scaling_config(world)
-    sim = SlabSimulation(comm, lambda cap, gcap, p, z0, z1: HipEngine(cap, gcap, p, z0, z1, local),
-                         cfg["box"], cfg["grid"], lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"])
+    # torch.distributed is the launcher's plumbing: rendezvous, the RCCL id, barriers and the max over ranks.  The
+    # data path (migrants, halos) is the library's own RCCL communicator on its comm stream -- or, with
+    # --transport host, host-staged messages over the process group (several ranks sharing one GPU: rehearsals).
+    if transport == "rccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        comm = TorchDistComm(torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = TorchDistComm(torch.device("cpu"))
+    strong = getattr(args, "scaling", "weak") == "strong"
+    if strong:
+        cfg = dict(ic.CONFIGS["C4"], jitter_dims=ic.CONFIGS["C4"]["box"])
+    else:
+        cfg = ic.weak_scaling_config(world)
+    sim = NativeSlabSimulation(comm, cfg["box"], cfg["grid"], device_index=local, transport=transport,
+                               lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"])
     dt = float(ic.DEFAULT_DT)
+    runup = args.runup if getattr(args, "runup", None) is not None else 6000
+    t0 = time.perf_counter()
+    left = runup
+    while left > 0:                                    # state preparation: the flowing dam (as in the 1-GPU bench)
+        k = min(left, 2000)
+        sim.run(dt, k); sim.sync()
+        left -= k
+        if rank == 0:
+            print(f"[bench] run-up {runup - left}/{runup} steps, {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
     sim.run(dt, args.warmup)
-    sim.engine.sync(); torch.cuda.synchronize(); comm.barrier()
+    sim.sync(); torch.cuda.synchronize(); comm.barrier()
+    s0 = sim.engine.ctx.sort_stats()
     t0 = time.perf_counter()
     sim.run(dt, args.steps)
-    sim.engine.sync(); torch.cuda.synchronize(); comm.barrier()
+    sim.sync(); torch.cuda.synchronize(); comm.barrier()
     wall = comm.allreduce_max(time.perf_counter() - t0)
+    s1 = sim.engine.ctx.sort_stats()
     n_own = sim.engine.n
-    counts = comm.allreduce_sum(np.array([n_own], dtype=np.int64))
+    counts = comm.allreduce_sum(np.array([n_own, s1["movers_total"] - s0["movers_total"], s1["skips"] - s0["skips"]],
+                                         dtype=np.int64))
     # per-phase device times of this rank's kernels (HIP events on the library's stream), outside the timed region
     ctx = sim.engine.ctx
     ctx.timing(True); ctx.timing_reset()
     probe = max(2, min(args.steps, 5))
     sim.run(dt, probe)
-    sim.engine.sync(); comm.barrier()
+    sim.sync(); comm.barrier()
     ph, _ = ctx.timing_get()
     ctx.timing(False)
     phases_ms = {k: v / probe for k, v in ph.items()}
     if rank == 0:
         total = sim.total
-        fbytes, t_force = 84 * n_own, max(phases_ms["force"], 1e-9) * 1e-3
-        roofline = {"bound": "hbm", "kernel": "k_force<force+collision+integrate> (rank 0)",
-                    "achieved": fbytes / t_force / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "frac": fbytes / t_force / 1e9 / 8000.0, "traffic": None,
-                    "algorithmic_bytes_per_particle": 84, "avg_launch_ms": phases_ms["force"],
-                    "valu": {"achieved_tflops": 216 * 34 * n_own / t_force / 1e12, "peak_tflops": 157.3}}
         out = {
             "metric": "particle-steps/sec", "value": total * args.steps / wall, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"dam-break, {cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} = {total} "
-                                   f"particles ({total // world} per GPU), grid {cfg['grid']}, z-slabs with ghost layers "
-                                   f"over RCCL send/recv",
-                       "particles": total, "grid": list(cfg["grid"]), "cuts": sim.cuts,
-                       "parallelism": f"{world} z-slabs, one per GPU"},
-            "roofline": roofline, "phases_ms_rank0": phases_ms,
-            "slab_stats": sim.stats, "owned_sum": int(counts[0]),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"dam-break {'C4 (strong scaling)' if strong else 'C3 per GPU (weak scaling)'}: "
+                                   f"{cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} = {total} particles "
+                                   f"({total // world} per GPU), grid {list(cfg['grid'])}, dt 5e-7, FLOWING: timed after {runup} "
+                                   f"run-up steps; z-slabs, ghost layers and migrants over "
+                                   f"{'RCCL send/recv (library comm stream)' if transport == 'rccl' else 'host-staged messages'}",
+                       "particles": total, "grid": list(cfg["grid"]), "cuts": sim.cuts, "state": "flow", "runup_steps": runup,
+                       "parallelism": f"{world} z-slabs, one per GPU", "transport": transport},
+            "phases_ms_rank0": phases_ms, "slab_stats_rank0": sim.stats, "owned_sum": int(counts[0]),
+            "movers_per_step": float(counts[1]) / max(args.steps, 1), "sort_skips": int(counts[2]),
         }
         print(json.dumps(out), flush=True)
+    sim.close()
     dist.destroy_process_group()

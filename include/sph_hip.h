@@ -250,6 +250,43 @@ int sph_halo_unpack_density(sph_ctx* c, const void* lo_dev, const void* hi_dev);
 /* per z cell layer histogram of owned particles (global layer ids), for count-balanced cuts */
 int sph_layer_histogram(sph_ctx* c, uint32_t* hist, uint32_t n_layers);
 
+/* ---- the slab step under the C ABI: one call = one time step of this rank's slab, with its neighbours ------- */
+/* How the messages of a step reach the two z-neighbours.  `exchange` moves four buffers at once: send_lo goes to
+ * rank-1 (and arrives there in its recv_hi), send_hi to rank+1, recv_lo / recv_hi are filled by the neighbours;
+ * a size of 0 means "nothing on that side" (domain ends, empty layers) -- both ends of a link compute the same sizes.
+ *   host_buffers = 0 (product): the pointers are DEVICE pointers and the call enqueues the transfers on hip_stream
+ *                    without blocking the host (RCCL: ncclSend/ncclRecv inside one group);
+ *   host_buffers = 1 (tests): the pointers are pinned HOST buffers the library staged, the call blocks until its
+ *                    receives are complete (several slabs of one GPU in one process; processes over gloo).
+ * Return 0 or a negative SPH_E* code. */
+enum { SPH_TAG_MIGRANTS = 1, SPH_TAG_HALO_A = 2, SPH_TAG_HALO_B = 3 };
+typedef struct sph_transport {
+    void* self;
+    int (*exchange)(void* self, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
+                    const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes, void* hip_stream);
+    int host_buffers;
+} sph_transport;
+
+/* RCCL transport over the direct xGMI links (librccl is loaded on first use): rank 0 makes the id, every rank gets
+ * the same 128 bytes (the launcher broadcasts them) and joins the communicator with its rank. */
+int sph_rccl_unique_id(uint8_t id[128]);
+int sph_rccl_transport_create(sph_transport** out, const uint8_t id[128], int rank, int world, int device);
+void sph_rccl_transport_destroy(sph_transport* t);
+
+typedef struct sph_slab sph_slab;
+/* Bind a slab context (sph_create_slab, particles uploaded) to its place in the chain of `world` slabs.  The halo
+ * capacity is the context's ghost capacity; migrant_capacity (records per side and step, 0 = a default) sizes the
+ * fixed-size migrant message.  The transport struct is copied. */
+int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph_transport* transport,
+                    uint32_t migrant_capacity);
+void sph_slab_destroy(sph_slab* s);
+/* n time steps: sort, migrants, halo A, density, halo B, force + collision + integrate (csrc/sph_slab.hip), queued
+ * on the context's stream and a second, high-priority stream; the host waits ONCE per step (for the layer counts). */
+int sph_slab_step(sph_slab* s, float dt, uint32_t n_steps);
+int sph_slab_sync(sph_slab* s);
+/* {steps, particles sent away, second sorts (steps with arrivals), ghosts received, host waits} */
+int sph_slab_stats(const sph_slab* s, uint64_t out[5]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,14 +28,16 @@ def main():
     try:
         pos, vel, box, grid = make_case(a.case)
         comm = slab.TorchDistComm(torch.device("cuda", 0))
-        sim = slab.SlabSimulation(comm, lambda cap, gcap, p, z0, z1: slab.HipEngine(cap, gcap, p, z0, z1, 0),
-                                  box, grid, particles=(pos, vel))
+        # the product step (sph_slab_step); two ranks cannot share a GPU under RCCL, so the messages travel host-staged
+        # over gloo -- on an N-GPU node the transport is "rccl"
+        sim = slab.NativeSlabSimulation(comm, box, grid, device_index=0, transport="host", particles=(pos, vel))
         sim.run(5e-7, a.steps)
         st = sim.gather_state()
+        assert sim.stats["host_waits"] == a.steps
         stats = comm.allreduce_sum(np.array([sim.stats["migrants"], sim.stats["resorts"], sim.engine.n], dtype=np.int64))
         if dist.get_rank() == 0:
             np.savez(a.out, cuts=np.array(sim.cuts), stats=stats, **st)
-        sim.engine.close()
+        sim.close()
     finally:
         dist.destroy_process_group()
 

@@ -1,6 +1,7 @@
-"""GPU: the z-slab path with the PRODUCT engine (HipEngine -> libsph_hip.so).  Several slabs share the
-one GPU of the test box as in-process ranks (LocalComm); the wire protocol, the pack/unpack kernels,
-ghost layers, migration and the density halo are the same code the N-GPU run uses over RCCL."""
+"""GPU: the z-slab path through its product entry point, sph_slab_step (csrc/sph_slab.hip, C ABI): one call per rank
+and step queues sort, migrants, halo A, density, halo B and the fused force pass on two HIP streams.  Several slabs
+share the one GPU of the test box as in-process ranks (one thread each); the transport is the host-staged test
+transport over LocalComm -- on an N-GPU node the same step runs over RCCL (sph_rccl_transport_create)."""
 import threading
 
 import numpy as np
@@ -19,11 +20,11 @@ def _run_slabs(world, box, grid, steps, particles=None, lattice=None):
 
     def rank_main(r):
         try:
-            sim = slab.SlabSimulation(slab.LocalComm(hub, r), lambda cap, gcap, p, z0, z1: slab.HipEngine(cap, gcap, p, z0, z1, 0),
-                                      box, grid, particles=particles, lattice=lattice)
+            sim = slab.NativeSlabSimulation(slab.LocalComm(hub, r), box, grid, device_index=0, transport="host",
+                                            particles=particles, lattice=lattice)
             sim.run(DT, steps)
             results[r] = (sim.gather_state(), dict(sim.stats), sim.cuts, sim.engine.n)
-            sim.engine.close()
+            sim.close()
         except BaseException as e:     # noqa: BLE001
             errors.append(e)
             hub.bar.abort()
@@ -51,9 +52,38 @@ def test_slabs_with_migration_match_whole_domain(case, world):
     ref = _whole_domain(pos, vel, box, grid, steps)
     assert sum(r[1]["migrants"] for r in res) > 0
     assert sum(r[3] for r in res) == pos.shape[0]
+    assert all(r[1]["host_waits"] == steps for r in res), "one host wait per step and rank"
     assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
     assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
     assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def test_python_driven_protocol_still_matches():
+    """SlabSimulation.step (the Python statement of the protocol that the CPU tests run with the oracle engine) with
+    the product engine: same physics as the native step."""
+    pos, vel, box, grid = make_case("up")
+    steps, world = 12, 3
+    hub = slab.LocalComm.Hub(world)
+    results, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            sim = slab.SlabSimulation(slab.LocalComm(hub, r), lambda cap, gcap, p, z0, z1: slab.HipEngine(cap, gcap, p, z0, z1, 0),
+                                      box, grid, particles=(pos, vel))
+            sim.run(DT, steps)
+            results[r] = sim.gather_state()
+            sim.engine.close()
+        except BaseException as e:     # noqa: BLE001
+            errors.append(e)
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=900)
+    assert not errors, errors
+    ref = _whole_domain(pos, vel, box, grid, steps)
+    assert np.abs(results[0]["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert np.abs(results[0]["density"] / ref["density"] - 1).max() <= 1e-5
 
 
 def test_c2_in_four_slabs_matches_whole_domain():
@@ -82,12 +112,11 @@ def test_weak_scaling_geometry_in_four_slabs():
 
     def rank_main(r):
         try:
-            sim = slab.SlabSimulation(slab.LocalComm(hub, r), lambda cap, gcap, p, z0, z1: slab.HipEngine(cap, gcap, p, z0, z1, 0),
-                                      cfg["box"], cfg["grid"], lattice=cfg["lattice"], jitter=True,
-                                      jitter_dims=cfg["jitter_dims"])
+            sim = slab.NativeSlabSimulation(slab.LocalComm(hub, r), cfg["box"], cfg["grid"], device_index=0, transport="host",
+                                            lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"])
             sim.run(DT, steps)
             results[r] = (sim.gather_state(), sim.cuts, sim.engine.n)
-            sim.engine.close()
+            sim.close()
         except BaseException as e:     # noqa: BLE001
             errors.append(e)
             hub.bar.abort()
@@ -157,12 +186,12 @@ def test_rebalance_on_gpu_engines():
 
     def rank_main(r):
         try:
-            sim = slab.SlabSimulation(slab.LocalComm(hub, r), lambda cap, gcap, p, z0, z1: slab.HipEngine(cap, gcap, p, z0, z1, 0),
-                                      box, grid, particles=(pos, vel))
+            sim = slab.NativeSlabSimulation(slab.LocalComm(hub, r), box, grid, device_index=0, transport="host",
+                                            particles=(pos, vel))
             cuts0 = list(sim.cuts)
             sim.run(DT, steps, rebalance_every=20)
             results[r] = (sim.gather_state(), dict(sim.stats), cuts0, list(sim.cuts), sim.engine.n)
-            sim.engine.close()
+            sim.close()
         except BaseException as e:     # noqa: BLE001
             errors.append(e)
             hub.bar.abort()
