@@ -139,3 +139,42 @@ def test_add_sphere_moves_only_its_own_particles():
     assert np.array_equal(raw[0, :, :3].view(np.uint32), st["pos"].view(np.uint32))
     assert np.array_equal(raw[1, :, :3].view(np.uint32), st["vel"].view(np.uint32))
     assert np.abs(raw[0, :k, :3] - ball).max() < 1e-3 and raw[0, :k, 1].min() > 1.5      # the ball sits at the top
+
+
+def test_driver_flags_device_grid_ic_and_snapshot_size():
+    """The reference's -device=N (findCudaDevice), plus -grid= and -ic=; an out-of-range device is refused like
+    cudaSetDevice would; -load= takes the particle count from the snapshot, not from -n."""
+    text = _run("-benchmark", "-n=4096", "-box=4", "-i=2", "-device=0", "-grid=32", "-ic=random")
+    assert "grid 32x32x32" in text and "Throughput = " in text
+    bad = subprocess.run([EXE, "-n=512", "-box=4", "-i=1", "-device=99"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "device" in bad.stderr.lower()
+    bad = subprocess.run([EXE, "-n=512", "-box=4", "-i=1", "-ic=spiral"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0
+    with tempfile.TemporaryDirectory() as d:
+        snap, out = os.path.join(d, "s.sph"), os.path.join(d, "o.bin")
+        _run("-n=4096", "-box=4", "-i=2", f"-save={snap}")
+        text = _run("-n=262144", "-box=4", "-i=1", f"-load={snap}", f"-out={out}")    # a wrong -n must not over-read
+        assert np.fromfile(out, dtype=np.float32).size == 2 * 4096 * 4
+
+
+def test_snapshot_with_bad_indices_is_rejected():
+    """A snapshot is external input: creation indices out of range or repeated must not reach the by-index buffers."""
+    pos, vel = ic.dam_break_lattice((8, 8, 8), (2.0, 2.0, 2.0), jitter=True)
+    with tempfile.TemporaryDirectory() as d, capi.Context(512, box=(2.0,) * 3, grid=(32,) * 3) as a:
+        snap = os.path.join(d, "state.sph")
+        a.upload(pos, vel)
+        a.save(snap)
+        raw = bytearray(open(snap, "rb").read())
+        hdr = 16 + 80                                            # 4 u32 + sizeof(sph_params)
+        for bad_index in (600, 5):                               # >= n ; a duplicate of particle 5 (record 7 is index 7)
+            blob = bytearray(raw)
+            blob[hdr + 7 * 16 + 12: hdr + 7 * 16 + 16] = np.uint32(bad_index).tobytes()
+            bad = os.path.join(d, f"bad{bad_index}.sph")
+            open(bad, "wb").write(blob)
+            with pytest.raises(capi.SphError):
+                a.load_snapshot(bad)
+        # download windows never write outside the caller's arrays
+        a.load_snapshot(snap)
+        st = a.download(index_base=100, count=50)
+        assert st["pos"].shape == (50, 3) and np.isfinite(st["pos"]).all()
+        assert np.array_equal(st["pos"], pos[100:150])
