@@ -90,12 +90,22 @@ def cpu_baseline(budget_s=24.0):
             o.step(dt, steps)
             return n * steps / (time.perf_counter() - t0)
         return run
-    o.L.orc_set_num_threads(cores)
-    t0 = time.perf_counter(); o.step(dt, 1); per = time.perf_counter() - t0
+    # a 262144-particle step is small for a many-core host (serial sort, one OpenMP region per phase): probe a few
+    # team sizes, one step each, and keep the best -- as for the reference below
+    best_t, per = 1, float("inf")
+    for t in sorted({1, 8, 16, 32, 64, cores}):
+        if t > cores:
+            continue
+        o.L.orc_set_num_threads(t)
+        o.step(dt, 1)                                   # the first region of a new team pays for its threads
+        t0 = time.perf_counter(); o.step(dt, 1); dtp = time.perf_counter() - t0
+        if dtp < per:
+            best_t, per = t, dtp
     steps_all = int(max(1, min(50, share / 3.0 / max(per, 1e-3))))
-    rate, rates = _median_rate(port_run(cores, steps_all))
-    legs["port"] = {"value": rate, "cores": cores, "steps_per_run": steps_all, "runs": rates,
-                    "build": "oracle/sph_oracle.c, gcc -O3 -march=native -fopenmp (compiled on this host)"}
+    rate, rates = _median_rate(port_run(best_t, steps_all))
+    legs["port"] = {"value": rate, "cores": best_t, "steps_per_run": steps_all, "runs": rates,
+                    "build": "oracle/sph_oracle.c, gcc -O3 -march=native -fopenmp (compiled on this host); team size = "
+                             f"best of a probe over {{1,8,16,32,64,{cores}}} threads"}
     rate1, rates1 = _median_rate(port_run(1, 1))
     legs["port"]["one_thread"] = {"value": rate1, "runs": rates1, "steps_per_run": 1}
     o.close()
