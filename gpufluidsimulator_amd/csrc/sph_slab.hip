@@ -9,7 +9,7 @@
 //   hash + sort owned particles
 //   layer bounds (device), pack leavers+header -> exchange MIGRANTS (fixed size, counts in-band)
 //   ............ host waits here for {own bounds, neighbours' headers}: the only wait of the step ..........
-//   [arrivals: append, hash, sort again]
+//   [arrivals: appended behind the sorted range and merged in as movers]
 //   pack boundary layers                       -> exchange HALO A (positions, velocities; exact size)
 //   density of the INTERIOR layers                unpack ghosts, cell table of the ghost layers
 //   density of the two boundary layers  <-(event)
@@ -295,20 +295,30 @@ int slab_step_once(sph_slab* s, float dt) {
         SPH_REQUIRE(c->n + in_lo + in_hi <= c->cap && c->own_off + c->n + in_lo + in_hi <= c->tot, SPH_E_CAPACITY,
                     "rank %d: %u + %u arriving particles exceed the capacity %u", s->rank, c->n, in_lo + in_hi, c->cap);
         rc = after_comm(s); if (rc) return rc;                  // the received records are in mig_recv
+        // behind the sorted owned range, with their cell keys: the merge path takes them in as movers without an old
+        // slot (one pass over the particles; a full radix sort when the merge path is switched off)
+        const bool merge = c->sort_merge && c->order_valid && c->cells_valid && c->cells_lo == c->own_off &&
+                           c->cells_hi == c->own_off + c->n;
+        uint32_t appended = 0;
         for (int side = 0; side < 2; side++) {
             const uint32_t cnt = side == 0 ? in_lo : in_hi;
             if (!cnt) continue;
-            const uint32_t at = c->own_off + c->n;
+            const uint32_t at = c->own_off + c->n + appended;
             hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(cnt, 256u)), dim3(256), 0, c->stream, s->mig_recv[side] + 2, cnt,
-                               c->posi + at, c->velr + at, (uint32_t*)nullptr, c->grid);
-            c->n += cnt;
+                               c->posi + at, c->velr + at, merge ? c->k0 + c->n + appended : (uint32_t*)nullptr, c->grid);
+            appended += cnt;
         }
         SPH_HIP(hipGetLastError());
-        c->keys_fresh = false;
-        c->order_valid = false;
-        c->stage = sph_ctx::ST_LOADED;
-        rc = step_hash(c); if (rc) return rc;
-        rc = step_sort(c); if (rc) return rc;
+        if (merge) {
+            rc = launch_merge_arrivals(c, appended); if (rc) return rc;
+        } else {
+            c->n += appended;
+            c->keys_fresh = false;
+            c->order_valid = false;
+            c->stage = sph_ctx::ST_LOADED;
+            rc = step_hash(c); if (rc) return rc;
+            rc = step_sort(c); if (rc) return rc;
+        }
         own_lo += in_lo;
         own_hi += in_hi;
         s->resorts++;

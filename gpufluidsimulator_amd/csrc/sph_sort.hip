@@ -629,7 +629,7 @@ __global__ __launch_bounds__(1024) void k_mm_tilescan(uint32_t* __restrict__ til
 }
 
 // thread per chunk: movers before the chunk (M64) and the stable list of movers (new key, slot)
-__global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__ mask, uint32_t nchunks,
+__global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__ mask, uint32_t nchunks, uint32_t n_old,
                                                     const uint32_t* __restrict__ tile_off,
                                                     const uint32_t* __restrict__ A, const uint32_t* __restrict__ B,
                                                     uint32_t* __restrict__ M64, uint32_t* __restrict__ mk,
@@ -657,7 +657,8 @@ __global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__
         at++;
         // only a cell a mover left can have become empty: clear those, the cell pass after the merge rewrites
         // every cell that is still occupied (replaces the walk over all old keys, k_cells_clear)
-        if (cells) cells[A[i]] = make_uint2(0u, 0u);
+        // (slots from n_old on hold particles that just arrived from another slab: they have no old cell)
+        if (cells && i < n_old) cells[A[i]] = make_uint2(0u, 0u);
     }
 }
 
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(256) void k_mm_scatter(const uint32_t* __restrict__
     if (perm_out) perm_out[dst] = i;
 }
 
-__global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restrict__ A, uint32_t n,
+__global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restrict__ A, uint32_t n, uint32_t nchunks,
                                                          const uint64_t* __restrict__ mask,
                                                          const uint32_t* __restrict__ M64,
                                                          const uint32_t* __restrict__ mk,
@@ -743,8 +744,8 @@ __global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restr
         while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (A[mid] <= key) lo = mid + 1; else hi = mid; }
         const uint32_t e = lo;
         const uint32_t j = min(max(slot, s), e);       // non-movers of cell `key` below `slot` end here
-        uint32_t before = m;                           // movers among the slots [0, j)
-        if (j < n) before = M64[j >> 6] + (uint32_t)__popcll(mask[j >> 6] & ((1ull << (j & 63u)) - 1ull));
+        uint32_t before = m;                           // movers among the slots [0, j)  (j <= n: the slots with an old key)
+        if ((j >> 6) < nchunks) before = M64[j >> 6] + (uint32_t)__popcll(mask[j >> 6] & ((1ull << (j & 63u)) - 1ull));
         const uint32_t dst = r + (j - before);
         posi_out[dst] = posi[slot];
         velr_out[dst] = velr[slot];
@@ -799,17 +800,33 @@ static void launch_merge_count(sph_ctx* c, uint32_t n) {
     c->mm_scanned = false;
 }
 
-// the merged order, written straight into posi2 / velr2 / keyS at the canonical offset gcap
-static int launch_sort_merge(sph_ctx* c, uint32_t n, bool table_live) {
+// every slot from n_old on is a mover, none below (particles appended behind a sorted range)
+__global__ __launch_bounds__(256) void k_mm_mark_tail(uint32_t n_old, uint32_t n_tot, uint64_t* __restrict__ mask,
+                                                      uint32_t* __restrict__ tile_cnt) {
+    const uint32_t chunk = blockIdx.x * 256u + threadIdx.x;
+    if (chunk * 64u >= n_tot) return;
+    const uint32_t lo = chunk * 64u, hi = min(lo + 64u, n_tot);
+    uint64_t m = 0ull;
+    if (hi > n_old) {
+        const uint32_t first = max(lo, n_old) - lo, cnt = hi - lo;
+        m = (cnt == 64u ? ~0ull : ((1ull << cnt) - 1ull)) & ~((1ull << first) - 1ull);
+        atomicAdd(&tile_cnt[chunk / MM_TILE_CHUNKS], (uint32_t)__popcll(m));
+    }
+    mask[chunk] = m;
+}
+
+// The merged order, written straight into posi2 / velr2 / keyS2 at the canonical offset gcap.  Slots [0, n) carry
+// an old key (A) and a new one (B); slots [n, n_tot) -- particles that arrived from a neighbouring slab -- only a
+// new one, and all of them are movers.
+static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_live, uint32_t hint) {
     const uint32_t* A = c->keyS + c->own_off;
     const uint32_t* B = c->k0;
-    const uint32_t nchunks = ceil_div(n, 64u), nt = ceil_div(nchunks, MM_TILE_CHUNKS);
+    const uint32_t nchunks = ceil_div(n_tot, 64u), nt = ceil_div(nchunks, MM_TILE_CHUNKS);
     uint32_t* mk = c->mm_k0; uint32_t* mi = c->v0; uint32_t* mk2 = c->mm_k1; uint32_t* mi2 = c->mm_v1;
-    hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, c->mm_tile_off, A, B,
+    hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, n, c->mm_tile_off, A, B,
                        c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr);
     SPH_HIP(hipGetLastError());
-    const uint32_t hint = *c->mm_count_host;                 // whatever step last reported: sizes the grids only
-    int rc = radix_sort_pairs(c, n, c->mm_count, merge_grid_for(hint, n), false, mk, mi, mk2, mi2);
+    int rc = radix_sort_pairs(c, n_tot, c->mm_count, merge_grid_for(hint, n_tot), false, mk, mi, mk2, mi2);
     if (rc) return rc;
     const uint32_t rank_tiles = ceil_div(n, MM_RANK_TILE) + 1u;
     hipLaunchKernelGGL(k_mm_tile_rank, dim3(ceil_div(rank_tiles, 256u)), dim3(256), 0, c->stream, A, n, mk, mi, c->mm_count,
@@ -819,7 +836,7 @@ static int launch_sort_merge(sph_ctx* c, uint32_t n, bool table_live) {
     const float4* ps = c->posi + c->own_off; const float4* vs = c->velr + c->own_off;
     float4* po = c->posi2 + c->gcap; float4* vo = c->velr2 + c->gcap; uint32_t* ko = c->keyS2 + c->gcap;
     hipLaunchKernelGGL(k_mm_place_movers, dim3(min(ceil_div(2u * hint + 1u, 256u) + 15u, 65535u)), dim3(256), 0, c->stream,
-                       A, n, c->mm_mask, c->mm_M64, mk, mi, c->mm_count, ps, vs, po, vo, ko, perm);
+                       A, n, nchunks, c->mm_mask, c->mm_M64, mk, mi, c->mm_count, ps, vs, po, vo, ko, perm);
     SPH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_mm_scatter, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, A, n, c->mm_mask, c->mm_M64, mk, mi,
                        c->mm_tileL, ps, vs, po, vo, ko, perm);
@@ -869,7 +886,7 @@ int launch_sort(sph_ctx* c) {
                 return SPH_OK;
             }
         }
-        int rc = launch_sort_merge(c, n, table_live);
+        int rc = launch_sort_merge(c, n, n, table_live, *c->mm_count_host);   // hint: whatever step last reported
         if (rc) return rc;
         c->sort_merges++;
         if (c->cells_valid && !table_live) {       // a table nobody cleared (e.g. sph_sort without sph_hash): start clean
@@ -916,6 +933,43 @@ int launch_sort(sph_ctx* c) {
     if (c->sort_merge) SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
     c->order_valid = true;
     c->cells_lo = c->gcap; c->cells_hi = c->gcap + n; c->cells_valid = true;
+    return SPH_OK;
+}
+
+// `n_in` particles were appended behind the SORTED owned range (positions, velocities and their new keys in
+// k0[n ...]): merge them in -- the movers are exactly the appended slots, everybody else keeps rank and key.  One
+// pass over the particles instead of a full radix sort (the slab step, csrc/sph_slab.hip, every time a neighbour
+// sends particles).  The cell table of the owned range must be valid; it is rebuilt for the new order.
+int launch_merge_arrivals(sph_ctx* c, uint32_t n_in) {
+    const uint32_t n = c->n, n_tot = n + n_in;
+    SPH_REQUIRE(c->order_valid && c->cells_valid && c->cells_lo == c->own_off && c->cells_hi == c->own_off + n, SPH_E_STATE,
+                "launch_merge_arrivals needs the sorted owned range and its cell table");
+    SPH_REQUIRE(ceil_div(n_tot, SORT_TILE) <= c->sort_blocks_cap, SPH_E_CAPACITY, "sort: capacity exceeded");
+    mm_drop_marks(c);
+    const uint32_t nchunks = ceil_div(n_tot, 64u);
+    hipLaunchKernelGGL(k_mm_mark_tail, dim3(ceil_div(nchunks, 256u)), dim3(256), 0, c->stream, n, n_tot, c->mm_mask,
+                       c->mm_tile_cnt);
+    const uint32_t nt = ceil_div(nchunks, MM_TILE_CHUNKS);
+    hipLaunchKernelGGL(k_mm_tilescan, dim3(1), dim3(1024), 0, c->stream, c->mm_tile_cnt, nt, c->mm_tile_off, c->mm_count,
+                       c->mm_count_host_dev, (unsigned long long*)nullptr);
+    SPH_HIP(hipGetLastError());
+    int rc = launch_sort_merge(c, n, n_tot, true, n_in);
+    if (rc) return rc;
+    float4* t4;
+    t4 = c->posi; c->posi = c->posi2; c->posi2 = t4;
+    t4 = c->velr; c->velr = c->velr2; c->velr2 = t4;
+    uint32_t* tk = c->keyS; c->keyS = c->keyS2; c->keyS2 = tk;
+    c->own_off = c->gcap;
+    c->n = n_tot;
+    c->cells_valid = false;
+    rc = launch_cells_build_range(c, c->gcap, c->gcap + n_tot);
+    if (rc) return rc;
+    c->cells_lo = c->gcap; c->cells_hi = c->gcap + n_tot; c->cells_valid = true;
+    c->order_valid = true;
+    c->keys_fresh = false;
+    c->n_glo = c->n_ghi = 0;
+    c->stage = sph_ctx::ST_SORTED;
+    c->have_dens = c->have_force = c->have_coll = false;
     return SPH_OK;
 }
 
