@@ -16,11 +16,12 @@ constexpr int SORT_THREADS = 256;            // 4 waves
 // 1: the ranked pairs of a tile are parked in LDS in digit order and written out with neighbouring threads on
 // neighbouring addresses; 0: every lane stores its pair straight from registers (uncoalesced, but 8 KB of LDS
 // per block instead of 40: three times the waves per CU)
+// (tried: keys and values taking turns in ONE 16 KB buffer, 26 KB of LDS per block -- the registers that hold the
+// tile positions meanwhile cost more waves than the LDS frees: 137-177 us per pass against 106)
 #ifndef SPH_SORT_STAGE
 #define SPH_SORT_STAGE 1
 #endif
 constexpr int SORT_KPT = SPH_SORT_KPT;       // keys per thread
-constexpr int SORT_WAVE_TILE = WAVE * SORT_KPT;          // 1024 consecutive keys per wave
 constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;       // 4096 keys per block
 
 // ---- hash: key per owned particle ------------------------------------------------------------------
@@ -64,13 +65,31 @@ constexpr uint32_t OS_GROUP = SPH_OS_GROUP;
 constexpr uint32_t OS_ONE_GROUP_TILES = 64;
 constexpr uint32_t OS_ALL_TILES = 0xFFFFFFFFu;           // group_tiles value for "one group"
 constexpr uint32_t OS_SPIN_LIMIT = 1u << 22;
+// A big pass runs with twice the blocks that fit the chip at once (3 per CU: LDS); every block takes tiles until none is
+// left, its next ticket always drawn while it works on the tile in hand.
+#ifndef SPH_OS_PASS_GRID_MAX
+#define SPH_OS_PASS_GRID_MAX 1536
+#endif
+constexpr uint32_t OS_PASS_GRID_MAX = SPH_OS_PASS_GRID_MAX;
+// Block of a pass kernel.  A tile is 4096 keys whatever the block: with 512 threads a thread holds 8 pairs instead of
+// 16 and a CU keeps twice the waves in flight at the same LDS per tile -- measured 119 us per pass against 107 with
+// 256 threads (1024: 153): what a tile waits for is its own chain (ticket, loads, the predecessors' counts:
+// profiles/r02_os_pass_stages.txt), not a lack of waves.
+#ifndef SPH_OS_PASS_THREADS
+#define SPH_OS_PASS_THREADS 256
+#endif
+constexpr int PASS_THREADS = SPH_OS_PASS_THREADS;
+constexpr int PASS_WAVES = PASS_THREADS / WAVE;
+constexpr int PASS_KPT = OS_TILE / PASS_THREADS;         // pairs per thread
+constexpr int PASS_WAVE_TILE = WAVE * PASS_KPT;          // consecutive keys per wave
 
 __device__ __forceinline__ uint32_t sort_count(uint32_t n, const uint32_t* __restrict__ n_dev) {
     return n_dev ? min(*n_dev, n) : n;
 }
 
-// exclusive scan of one value per thread over a 256-thread block (wave shuffles + 4 wave totals in LDS)
-__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_wtot /*[4]*/, uint32_t* total) {
+// exclusive scan of one value per thread over a block of NW waves (wave shuffles + NW wave totals in LDS)
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wtot /*[NW]*/, uint32_t* total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t inc = v;
 #pragma unroll
@@ -82,7 +101,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < 4; w++) { const uint32_t t = s_wtot[w]; if (w < wave) base += t; tot += t; }
+    for (uint32_t w = 0; w < (uint32_t)NW; w++) { const uint32_t t = s_wtot[w]; if (w < wave) base += t; tot += t; }
     if (total) *total = tot;
     __syncthreads();                                     // s_wtot may be reused by the caller
     return base + inc - v;
@@ -182,6 +201,13 @@ __global__ __launch_bounds__(256) void k_os_scan(uint32_t* __restrict__ hist, ui
 }
 
 typedef unsigned long long os_word;
+typedef volatile __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+// one wave's LDS operations are processed in issue order; only the compiler must not move them
+__device__ __forceinline__ void os_wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ void os_publish(os_word* w, uint32_t epoch, bool prefix, uint32_t value) {
     __hip_atomic_store(w, ((os_word)((epoch << 1) | (prefix ? 1u : 0u)) << 32) | value, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
@@ -194,8 +220,23 @@ __device__ __forceinline__ void os_publish(os_word* w, uint32_t epoch, bool pref
 constexpr uint32_t OS_CNT_BITS = 13;                     // a tile holds at most 4096 = 2^12 keys of one digit
 __device__ __forceinline__ uint32_t os_pack32(uint32_t epoch, uint32_t count) { return (epoch << OS_CNT_BITS) | count; }
 
+#ifdef SPH_OS_STATS
+__device__ unsigned long long g_os_stats[10];   // debug build only: ticks per stage of k_os_pass, summed over tiles (thread 0)
+#define OS_STAT(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                        atomicAdd(&g_os_stats[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
+extern "C" void sph_debug_os_stats(unsigned long long* out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_os_stats), sizeof(g_os_stats));
+    if (reset) { unsigned long long z[10] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_os_stats), z, sizeof(z)); }
+}
+#else
+#define OS_STAT(k) do { } while (0)
+#endif
+#ifndef SPH_OS_PASS_OCC
+#define SPH_OS_PASS_OCC 3                        // waves per SIMD asked of the register allocator
+#endif
 template <int BITS, bool FIRST, bool GROUPED>
-__global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+__global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                           uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                           uint32_t n_arg, const uint32_t* __restrict__ n_dev,
                                                           uint32_t shift, const uint32_t* __restrict__ group_base,
@@ -205,61 +246,78 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __rest
                                                           uint32_t* __restrict__ ticket, uint32_t epoch,
                                                           uint32_t* __restrict__ err) {
     constexpr int RADIX = 1 << BITS;
-    constexpr int DPT = RADIX / SORT_THREADS;       // digits per thread: 1 or 2 (consecutive digits)
-    __shared__ uint32_t wh[4][RADIX];               // per-wave digit counts -> running positions inside the tile
+    constexpr int DPT = RADIX > PASS_THREADS ? RADIX / PASS_THREADS : 1;   // digits per thread: 1 or 2 (consecutive digits)
+    static_assert(DPT <= 2, "a thread publishes at most two digits in one store");
+    __shared__ uint32_t wh[PASS_WAVES][RADIX];      // per-wave digit counts -> running positions inside the tile
     __shared__ uint32_t s_delta[RADIX];             // global position minus LDS position of a digit's keys of this tile
 #if SPH_SORT_STAGE
     __shared__ uint32_t s_key[OS_TILE], s_val[OS_TILE];
 #endif
-    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_wtot[PASS_WAVES];
     __shared__ uint32_t s_tile;
-    __shared__ uint32_t s_round;
-    if (threadIdx.x == 0) s_round = 0;
     const uint32_t n = sort_count(n_arg, n_dev);
     const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const bool has_d = threadIdx.x * DPT < RADIX;   // more threads than digits: the rest only move pairs
     // first output position of every digit: exclusive scan of the pass's totals (thread t owns digits t*DPT ..)
     uint32_t dbase[DPT];
     {
         uint32_t tot[DPT], sum = 0;
 #pragma unroll
-        for (int k = 0; k < DPT; k++) { tot[k] = digit_tot[threadIdx.x * DPT + k]; sum += tot[k]; }
-        uint32_t run = block_excl_scan_256(sum, s_wtot, nullptr);
+        for (int k = 0; k < DPT; k++) { tot[k] = has_d ? digit_tot[threadIdx.x * DPT + k] : 0u; sum += tot[k]; }
+        uint32_t run = block_excl_scan<PASS_WAVES>(sum, s_wtot, nullptr);
 #pragma unroll
         for (int k = 0; k < DPT; k++) { dbase[k] = run; run += tot[k]; }
     }
-    for (;;) {
-        if (threadIdx.x == 0) {
-            if (GROUPED) {
-                // block b of round r belongs to group (b + r * grid) / OS_GROUP and takes the next tile of THAT group:
-                // a tile only ever waits for tiles whose ticket was drawn before its own, i.e. by running blocks
-                const uint32_t vb = blockIdx.x + s_round * gridDim.x;
-                s_round++;
-                const uint32_t g = vb / OS_GROUP;
-                s_tile = g * OS_GROUP + (g * OS_GROUP < ntiles ? atomicAdd(ticket + g, 1u) : 0u);
-                if (g * OS_GROUP >= ntiles) s_tile = 0xFFFFFFFFu;
-            } else {
-                s_tile = atomicAdd(ticket, 1u);
-            }
+#ifdef SPH_OS_STATS
+    unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
+    // Tickets are drawn one tile AHEAD (thread 0): the atomic's trip to memory and back hides behind the tile in
+    // hand.  The blocks b, b + 8, b + 16 .. share an XCD (blocks are dealt round-robin over the 8 XCDs; speed only).
+    // GROUPED: a group's tiles are taken by OS_GROUP blocks of ONE XCD -- neighbouring tiles write neighbouring
+    // pieces of every digit's run (a piece is 4096 / RADIX keys: 32 B), and one L2 can put them together before they
+    // go to memory; the grid is a multiple of 8; a block takes the next tile of ITS group.  No deadlock: a tile only
+    // waits for tiles of its group with a smaller ticket; a block's next tile has a larger ticket than (or a later
+    // group than) the tile it has in hand, so the smallest unfinished tile of the earliest unfinished group is
+    // always in some running block's hands, not in its pocket.
+    uint32_t round = 0, next_tile = 0;
+    auto draw = [&]() -> uint32_t {
+        if (GROUPED) {
+            const uint32_t idx = (blockIdx.x >> 3) + round * (gridDim.x >> 3);
+            round++;
+            const uint32_t g = (idx / OS_GROUP) * 8u + (blockIdx.x & 7u);
+            return g * OS_GROUP < ntiles ? g * OS_GROUP + atomicAdd(ticket + g, 1u) : 0xFFFFFFFFu;
         }
-        for (int w = 0; w < 4; w++)
-            for (int d = threadIdx.x; d < RADIX; d += SORT_THREADS) wh[w][d] = 0;
+        return atomicAdd(ticket, 1u);
+    };
+    if (threadIdx.x == 0) next_tile = draw();
+    for (;;) {
+        OS_STAT(0);                                 // between tiles (first: the prologue)
+        if (threadIdx.x == 0) s_tile = next_tile;
+        for (int d = threadIdx.x; d < PASS_WAVES * RADIX; d += PASS_THREADS) (&wh[0][0])[d] = 0;
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= ntiles) return;                 // block-uniform
+        if (threadIdx.x == 0) next_tile = draw();
+        OS_STAT(1);                                 // ticket
 
         // this wave's 1024 consecutive keys (registers), counted per wave
-        const uint32_t wbase = tile * OS_TILE + wave * SORT_WAVE_TILE;
-        uint32_t key[SORT_KPT], val[SORT_KPT];
+        const uint32_t wbase = tile * OS_TILE + wave * PASS_WAVE_TILE;
+        uint32_t key[PASS_KPT], val[PASS_KPT];
+        // every load is issued before the first key is looked at (one loop would wait for each pair in turn: the LDS
+        // atomics of the count keep the compiler from moving the later loads up)
 #pragma unroll
-        for (int t = 0; t < SORT_KPT; t++) {
+        for (int t = 0; t < PASS_KPT; t++) {
             const uint32_t i = wbase + t * WAVE + lane;
             key[t] = i < n ? kin[i] : 0xFFFFFFFFu;
             val[t] = FIRST ? i : (i < n ? vin[i] : 0u);
-            wave_count_digit(wh[wave], (key[t] >> shift) & (RADIX - 1), i < n);
         }
+#pragma unroll
+        for (int t = 0; t < PASS_KPT; t++)
+            wave_count_digit(wh[wave], (key[t] >> shift) & (RADIX - 1), wbase + t * WAVE + lane < n);
         __syncthreads();
+        OS_STAT(2);                                 // load + count
 
         // per digit: count of the tile and exclusive offsets of the four waves; publish the count at once
         const uint32_t grp = group_tiles == OS_ALL_TILES ? 0u : tile / group_tiles;
@@ -269,12 +327,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __rest
         for (int k = 0; k < DPT; k++) {
             const uint32_t d = threadIdx.x * DPT + k;
             uint32_t o = 0;
+            if (has_d) {
 #pragma unroll
-            for (int w = 0; w < 4; w++) { const uint32_t c = wh[w][d]; wh[w][d] = o; o += c; }
+                for (int w = 0; w < PASS_WAVES; w++) { const uint32_t c = wh[w][d]; wh[w][d] = o; o += c; }
+            }
             cnt[k] = o;
-            if (!GROUPED) os_publish(status + (size_t)tile * RADIX + d, epoch, tile == gstart, o);
+            if (!GROUPED && has_d) os_publish(status + (size_t)tile * RADIX + d, epoch, tile == gstart, o);
         }
-        if (GROUPED) {
+        if (GROUPED && has_d) {
             uint32_t* st32 = status32 + (size_t)tile * RADIX + threadIdx.x * DPT;
             if (DPT == 2)
                 __hip_atomic_store(reinterpret_cast<os_word*>(st32),
@@ -288,25 +348,46 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __rest
             uint32_t sum = 0;
 #pragma unroll
             for (int k = 0; k < DPT; k++) sum += cnt[k];
-            uint32_t run = block_excl_scan_256(sum, s_wtot, nullptr);
+            uint32_t run = block_excl_scan<PASS_WAVES>(sum, s_wtot, nullptr);
 #pragma unroll
             for (int k = 0; k < DPT; k++) {
                 const uint32_t d = threadIdx.x * DPT + k;
                 tstart[k] = run;
+                if (has_d) {
 #pragma unroll
-                for (int w = 0; w < 4; w++) wh[w][d] += run;      // wave-exclusive offset + start of the digit
+                    for (int w = 0; w < PASS_WAVES; w++) wh[w][d] += run;      // wave-exclusive offset + start of the digit
+                }
                 run += cnt[k];
             }
         }
         __syncthreads();
+        OS_STAT(3);                                 // publish + scan
+
+        // GROUPED: the counts of the earlier tiles of the group are requested now, every load in flight at once, and
+        // looked at after the ranking: their trip to memory and back (the words are written through, the loads pass
+        // the L2) hides behind it.  A word that is not there yet is asked for again below.
+        const uint32_t npred = tile - gstart;
+        const uint32_t* st32 = status32 + (size_t)gstart * RADIX + threadIdx.x * DPT;
+        os_word w[OS_GROUP - 1];
+        if (GROUPED && has_d) {
+#pragma unroll
+            for (uint32_t q = 0; q < OS_GROUP - 1; q++)
+                if (q < npred) {
+                    if (DPT == 2) w[q] = __hip_atomic_load(reinterpret_cast<const os_word*>(st32 + (size_t)q * RADIX),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else w[q] = __hip_atomic_load(st32 + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
 
         // rank: rows of 64 keys in order; equal digits of a row by ballot match-any + popcount of the lower lanes
-        volatile uint32_t* pos = wh[wave];
+        // an LDS-typed pointer: a generic `volatile uint32_t*` made every access a flat_load/flat_store with sc0 sc1
+        // and a full s_waitcnt behind it
+        const lds_u32_ptr pos = (lds_u32_ptr)wh[wave];
 #if !SPH_SORT_STAGE
-        uint32_t lpos[SORT_KPT];                            // position of the key inside the tile (digit order)
+        uint32_t lpos[PASS_KPT];                            // position of the key inside the tile (digit order)
 #endif
 #pragma unroll
-        for (int t = 0; t < SORT_KPT; t++) {
+        for (int t = 0; t < PASS_KPT; t++) {
             const uint32_t i = wbase + t * WAVE + lane;
             const bool valid = i < n;
             const uint32_t d = (key[t] >> shift) & (RADIX - 1);
@@ -320,9 +401,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __rest
             const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
             uint32_t base = 0;
             if (valid) base = pos[d];                       // every peer reads the same word
-            __builtin_amdgcn_wave_barrier();
+            os_wave_lds_order();
             if (valid && rank == 0) pos[d] = base + (uint32_t)__popcll(peers);   // LDS is in order per wave
-            __builtin_amdgcn_wave_barrier();
+            os_wave_lds_order();
 #if SPH_SORT_STAGE
             if (valid) { s_key[base + rank] = key[t]; s_val[base + rank] = val[t]; }
 #else
@@ -330,24 +411,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __rest
 #endif
         }
 
+        OS_STAT(4);                                 // rank (thread 0's wave)
         // keys with the same digit in the EARLIER tiles of the group: decoupled look-back, AFTER the ranking -- by
         // now the predecessors have long published, so the walk rarely meets an unfinished tile
         {
             uint32_t excl[DPT];
 #pragma unroll
             for (int k = 0; k < DPT; k++) excl[k] = 0;
-            if (GROUPED) {
-                // the counts of the earlier tiles of the group: every load is issued before the first is looked at
-                const uint32_t npred = tile - gstart;
-                const uint32_t* st32 = status32 + (size_t)gstart * RADIX + threadIdx.x * DPT;
-                os_word w[OS_GROUP - 1];
-#pragma unroll
-                for (uint32_t q = 0; q < OS_GROUP - 1; q++)
-                    if (q < npred) {
-                        if (DPT == 2) w[q] = __hip_atomic_load(reinterpret_cast<const os_word*>(st32 + (size_t)q * RADIX),
-                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        else w[q] = __hip_atomic_load(st32 + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+            if (GROUPED && has_d) {
+                // the counts of the earlier tiles of the group (requested before the ranking, see above)
                 uint32_t spins = 0;
 #pragma unroll
                 for (uint32_t q = 0; q < OS_GROUP - 1; q++)
@@ -365,7 +437,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __rest
                         excl[0] += (uint32_t)w[q] & ((1u << OS_CNT_BITS) - 1u);
                         if (DPT == 2) excl[DPT - 1] += (uint32_t)(w[q] >> 32) & ((1u << OS_CNT_BITS) - 1u);
                     }
-            } else if (tile != gstart) {
+            } else if (!GROUPED && has_d && tile != gstart) {
                 bool open[DPT];
 #pragma unroll
                 for (int k = 0; k < DPT; k++) open[k] = true;
@@ -395,17 +467,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __rest
 #pragma unroll
             for (int k = 0; k < DPT; k++) {
                 const uint32_t d = threadIdx.x * DPT + k;
-                s_delta[d] = dbase[k] + group_base[(grp * 4u) * 512u + d] + excl[k] - tstart[k];
+                if (has_d) s_delta[d] = dbase[k] + group_base[(grp * 4u) * 512u + d] + excl[k] - tstart[k];
             }
         }
+        OS_STAT(5);                                 // look-back (thread 0)
         __syncthreads();
+        OS_STAT(6);                                 // waiting for the slowest wave
 
 #if SPH_SORT_STAGE
         // write out in LDS (= digit) order: a digit's keys go to consecutive addresses
         const uint32_t tile_n = min((uint32_t)OS_TILE, n - tile * OS_TILE);
 #pragma unroll 4
-        for (int t = 0; t < SORT_KPT; t++) {
-            const uint32_t q = t * SORT_THREADS + threadIdx.x;
+        for (int t = 0; t < PASS_KPT; t++) {
+            const uint32_t q = t * PASS_THREADS + threadIdx.x;
             if (q < tile_n) {
                 const uint32_t k = s_key[q];
                 const uint32_t d = (k >> shift) & (RADIX - 1);
@@ -416,7 +490,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __rest
         }
 #else
 #pragma unroll
-        for (int t = 0; t < SORT_KPT; t++) {
+        for (int t = 0; t < PASS_KPT; t++) {
             const uint32_t i = wbase + t * WAVE + lane;
             if (i < n) {
                 const uint32_t dst = s_delta[(key[t] >> shift) & (RADIX - 1)] + lpos[t];
@@ -425,7 +499,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_os_pass(const uint32_t* __rest
             }
         }
 #endif
+        OS_STAT(7);                                 // write-out issued
         __syncthreads();                                    // LDS is re-used by the next tile
+        OS_STAT(8);
     }
 }
 
@@ -549,7 +625,7 @@ static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32
         const uint32_t epoch = one_group ? (c->os_epoch & 0x7FFFFFFFu) : (c->os_epoch & 0x7FFFFu);
         uint32_t* tk = c->os_tickets + (size_t)p * gcap;
 #define SPH_OS_LAUNCH(F, G)                                                                                             \
-        hipLaunchKernelGGL((k_os_pass<BITS, F, G>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, kin, vin, kout, vout, n, \
+        hipLaunchKernelGGL((k_os_pass<BITS, F, G>), dim3(G ? min((grid + 7u) & ~7u, OS_PASS_GRID_MAX) : grid), dim3(PASS_THREADS), 0, c->stream, kin, vin, kout, vout, n, \
                            n_dev, p * BITS, c->os_base + p * 512u, c->os_tot + p * 512u, group_tiles, c->os_status,         \
                            c->os_status32, tk, epoch,                                                                    \
                            c->os_err_dev)
