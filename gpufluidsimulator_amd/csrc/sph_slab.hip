@@ -238,8 +238,6 @@ int after_comm(sph_slab* s) {
     return SPH_OK;
 }
 
-uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-
 int slab_step_once(sph_slab* s, float dt) {
     sph_ctx* c = s->c;
     int rc;
@@ -264,7 +262,13 @@ int slab_step_once(sph_slab* s, float dt) {
     SPH_HIP(hipEventRecord(s->ev_sync, s->comm));
     // ---- the one host wait of the step: own bounds (written by k_slab_bounds before the comm stream started) and
     //      the neighbours' headers -------------------------------------------------------------------------------
-    SPH_HIP(hipEventSynchronize(s->ev_sync));
+    //      Polled, not slept on: hipEventSynchronize hands the thread to the kernel and comes back tens of
+    //      microseconds after the event -- with an empty queue behind it, that is device idle time.
+    {
+        hipError_t q;
+        while ((q = hipEventQuery(s->ev_sync)) == hipErrorNotReady) __builtin_ia32_pause();
+        SPH_HIP(q);
+    }
     s->host_waits++;
     const uint32_t lb0 = s->h_lb[0], lb1 = s->h_lb[1], lb2 = s->h_lb[2], lb3 = s->h_lb[3];
     const uint32_t m_lo = lb0, m_hi = n0 - lb3;

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Kernel trace of the default bench command (run on the GPU box from the repo root):
+#   bash profiles/collect_trace.sh
+# rocprofv3 --kernel-trace --stats over `python bench.py --steps 100 --warmup 20 --no-cpu`; profiles/trace_window.py cuts the
+# timed windows out of the trace (bench.py steps the dam 6000 times before it times anything):
+#   steps 6021..6120  the flowing dam, merge sort      -> profiles/r02_c3_flow_kernel_stats.csv
+#   steps 6224..6323  the same state, full radix sort   -> profiles/r02_c3_fullsort_kernel_stats.csv
+# and the JSON line the bench printed under the profiler -> profiles/r02_c3_flow_bench_under_rocprof.json
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_trace; rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o c3 -- python bench.py --steps 100 --warmup 20 --no-cpu > $OUT/bench.log 2>&1
+python - <<PY
+import re
+txt = open("$OUT/bench.log").read()
+m = re.findall(r'^\{"metric".*\}$', txt, flags=re.M)
+open("gpurun_out/r02_c3_flow_bench_under_rocprof.json", "w").write(m[-1] + "\n")
+PY
+python profiles/trace_window.py $OUT/c3_kernel_trace.csv 6020 100 gpurun_out/r02_c3_flow_kernel_stats.csv > /dev/null
+python profiles/trace_window.py $OUT/c3_kernel_trace.csv 6223 100 gpurun_out/r02_c3_fullsort_kernel_stats.csv > /dev/null
+cp $OUT/c3_kernel_stats.csv gpurun_out/r02_c3_whole_run_kernel_stats.csv
+rm -rf $OUT
+tail -2 gpurun_out/r02_c3_flow_kernel_stats.csv
