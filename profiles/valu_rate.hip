@@ -60,6 +60,22 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, in
             REP16(asm volatile("v_fma_f16 %0, %0, %8, %9\n v_fma_f16 %1, %1, %8, %9\n v_fma_f16 %2, %2, %8, %9\n v_fma_f16 %3, %3, %8, %9\n"
                                "v_fma_f16 %4, %4, %8, %9\n v_fma_f16 %5, %5, %8, %9\n v_fma_f16 %6, %6, %8, %9\n v_fma_f16 %7, %7, %8, %9\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 11) {  // v_fma_mix_f32: fp16 sources (low halves) read in place, fp32 accumulator
+            REP16(asm volatile("v_fma_mix_f32 %0, %8, %9, %0 op_sel_hi:[1,1,0]\n v_fma_mix_f32 %1, %8, %9, %1 op_sel_hi:[1,1,0]\n"
+                               "v_fma_mix_f32 %2, %8, %9, %2 op_sel_hi:[1,1,0]\n v_fma_mix_f32 %3, %8, %9, %3 op_sel_hi:[1,1,0]\n"
+                               "v_fma_mix_f32 %4, %8, %9, %4 op_sel_hi:[1,1,0]\n v_fma_mix_f32 %5, %8, %9, %5 op_sel_hi:[1,1,0]\n"
+                               "v_fma_mix_f32 %6, %8, %9, %6 op_sel_hi:[1,1,0]\n v_fma_mix_f32 %7, %8, %9, %7 op_sel_hi:[1,1,0]\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 12) {  // v_fma_mix_f32 with one fp16 source (high half) and two fp32 sources
+            REP16(asm volatile("v_fma_mix_f32 %0, %8, %9, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %9, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                               "v_fma_mix_f32 %2, %8, %9, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %8, %9, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                               "v_fma_mix_f32 %4, %8, %9, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %9, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                               "v_fma_mix_f32 %6, %8, %9, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %9, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 13) {  // v_cvt_f32_f16 (what a plain conversion of a staged half would cost)
+            REP16(asm volatile("v_cvt_f32_f16 %0, %8\n v_cvt_f32_f16 %1, %9\n v_cvt_f32_f16 %2, %8\n v_cvt_f32_f16 %3, %9\n"
+                               "v_cvt_f32_f16 %4, %8\n v_cvt_f32_f16 %5, %9\n v_cvt_f32_f16 %6, %8\n v_cvt_f32_f16 %7, %9\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -105,5 +121,8 @@ int main() {
     run<8>("v_pk_fma_f16 independent", 128);
     run<9>("v_pk_add/max/mul_f16 mix", 128);
     run<10>("v_fma_f16 independent", 128);
+    run<11>("v_fma_mix_f32 (2 fp16 srcs)", 128);
+    run<12>("v_fma_mix_f32 (1 fp16 hi src)", 128);
+    run<13>("v_cvt_f32_f16", 128);
     return 0;
 }
