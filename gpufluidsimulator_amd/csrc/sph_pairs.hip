@@ -475,6 +475,20 @@ __device__ __forceinline__ void integrate_one(const Phys& ph, float dt, float4& 
 //   dv += m (1 + e) (r.v / d^2) r, count++ ; finally dv = -dv / (m (1 + count)).
 // The reference runs three separate traversals plus an integrate pass; FORCE, COLL and INTEG select
 // what this instantiation does so that the phase API can still run them one at a time.
+#ifdef SPH_PAIR_STATS
+__device__ unsigned long long g_pair_stats[8];   // debug build only (-DSPH_PAIR_STATS): waves, pieces, walk length, chunks, collision rounds
+__device__ int g_pair_stats_on;
+#define PAIR_STAT(k, v) do { if (lane == 0 && g_pair_stats_on) atomicAdd(&g_pair_stats[k], (unsigned long long)(v)); } while (0)
+extern "C" void sph_debug_pair_stats(unsigned long long* out, int on) {     // read + clear the counters, then count or not
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stats), sizeof(g_pair_stats));
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stats), z, sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stats_on), &on, sizeof(on));
+}
+#else
+#define PAIR_STAT(k, v) do { } while (0)
+#endif
 template <bool FORCE, bool COLL, bool INTEG>
 __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     const float4* __restrict__ posi, const float4* __restrict__ velr, const float2* __restrict__ dp,
@@ -503,6 +517,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     lane_rows(cells, g, keyS[ii], active, R);
     Hulls H;
     wave_hulls(R, H);
+    PAIR_STAT(0, 1);
     float4 q0, q1, w0, w1;
     float2 e0, e1;
     const float cps = ph.spiky_half_mass / ph.visc_coef;   // pressure coefficient relative to the viscous one
@@ -554,6 +569,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             // every lane has at least tmin candidates: that part of the walk needs no per-lane range test
             const uint32_t tmin = tmin_raw & ~(uint32_t)(SPH_FORCE_UNROLL - 1);
             uint32_t near = 0u;
+            PAIR_STAT(1, 1); PAIR_STAT(2, T);
             auto pair = [&](int u, bool valid) {
                 const lds_v2f_ptr e = (lds_v2f_ptr)s_e + (idx + u) * 5;
                 const v2f qa = e[0], qb = e[1];
@@ -588,6 +604,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                 const uint32_t idx0 = idx;
                 uint32_t done = 0u;
                 near = 0u;
+                PAIR_STAT(3, 1);
                 uint32_t t = t0;
                 for (; t < tsafe; t += SPH_FORCE_UNROLL) {
 #pragma unroll
@@ -605,6 +622,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                     // bit (done-1-k) of `near` belongs to the k-th candidate of this chunk; highest bit first
                     // keeps the candidate order of the sums
                     while (__ballot(near != 0u) != 0ull) {
+                        PAIR_STAT(4, 1);
                         if (near != 0u) {
                             const uint32_t hb = 31u - (uint32_t)__clz((int)near);
                             near &= ~(1u << hb);
