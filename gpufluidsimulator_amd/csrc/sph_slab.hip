@@ -22,6 +22,7 @@
 // on the comm stream (sph_rccl_transport_create; over the direct xGMI link), or through a caller-supplied
 // transport (tests: host-staged, several slabs of one GPU or several processes over gloo).
 #include "sph_device.hpp"
+#include <vector>
 
 #include <dlfcn.h>
 
@@ -442,6 +443,57 @@ void sph_rccl_transport_destroy(sph_transport* t) {
     RcclLink* L = (RcclLink*)t->self;
     if (L) { if (L->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(L->comm); delete L; }
     delete t;
+}
+
+// One rank is enough to drive real bytes through the loaded ncclSend/ncclRecv: two messages to SELF in one group (a
+// send to the own rank is matched with the receive from the own rank, in the order they were posted), on a stream of
+// its own, compared on the host.  What a wrong signature, datatype value or struct-by-value convention of the dlopen
+// binding would break shows up here, on a one-GPU box; the neighbour pattern itself needs >= 2 GPUs.
+int sph_rccl_transport_selftest(sph_transport* t, size_t bytes) {
+    SPH_REQUIRE(t && t->self && t->exchange == rccl_exchange, SPH_E_INVALID, "not an RCCL transport");
+    SPH_REQUIRE(bytes >= 16 && bytes <= ((size_t)1 << 30), SPH_E_INVALID, "bad size");
+    RcclLink* L = (RcclLink*)t->self;
+    char *sa = nullptr, *sb = nullptr, *ra = nullptr, *rb = nullptr;
+    hipStream_t st = nullptr;
+    int rc = SPH_OK;
+    std::vector<char> ha(bytes), hb(bytes);
+    auto fail = [&](const char* what, hipError_t e) { set_error("selftest: %s: %s", what, hipGetErrorString(e)); rc = SPH_E_DEVICE; };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&sa, bytes)) || (e = hipMalloc((void**)&sb, bytes)) || (e = hipMalloc((void**)&ra, bytes)) ||
+        (e = hipMalloc((void**)&rb, bytes)) || (e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)))
+        fail("allocation", e);
+    if (!rc) {
+        for (size_t i = 0; i < bytes; i++) { ha[i] = (char)(i * 7u + 1u); hb[i] = (char)(i * 13u + 5u); }
+        if ((e = hipMemcpy(sa, ha.data(), bytes, hipMemcpyHostToDevice)) || (e = hipMemcpy(sb, hb.data(), bytes, hipMemcpyHostToDevice)) ||
+            (e = hipMemset(ra, 0, bytes)) || (e = hipMemset(rb, 0, bytes)))
+            fail("fill", e);
+    }
+    if (!rc) {
+        const int ncclChar = 0;
+        int r = g_rccl.GroupStart();
+        if (!r) r = g_rccl.Send(sa, bytes, ncclChar, L->rank, L->comm, st);
+        if (!r) r = g_rccl.Recv(ra, bytes, ncclChar, L->rank, L->comm, st);
+        if (!r) r = g_rccl.Send(sb, bytes / 2, ncclChar, L->rank, L->comm, st);
+        if (!r) r = g_rccl.Recv(rb, bytes / 2, ncclChar, L->rank, L->comm, st);
+        const int r2 = g_rccl.GroupEnd();
+        if (r || r2) { set_error("selftest: RCCL error %d (%s)", r ? r : r2, g_rccl.GetErrorString(r ? r : r2)); rc = SPH_E_DEVICE; }
+    }
+    if (!rc && (e = hipStreamSynchronize(st))) fail("synchronize", e);
+    if (!rc) {
+        std::vector<char> ga(bytes), gb(bytes);
+        if ((e = hipMemcpy(ga.data(), ra, bytes, hipMemcpyDeviceToHost)) || (e = hipMemcpy(gb.data(), rb, bytes, hipMemcpyDeviceToHost)))
+            fail("read back", e);
+        else if (memcmp(ga.data(), ha.data(), bytes) != 0 || memcmp(gb.data(), hb.data(), bytes / 2) != 0) {
+            set_error("selftest: received bytes differ from the bytes sent");
+            rc = SPH_E_STATE;
+        } else {
+            for (size_t i = bytes / 2; i < bytes; i++)
+                if (gb[i] != 0) { set_error("selftest: a %zu-byte receive wrote past its end", bytes / 2); rc = SPH_E_STATE; break; }
+        }
+    }
+    if (st) hipStreamDestroy(st);
+    hipFree(sa); hipFree(sb); hipFree(ra); hipFree(rb);
+    return rc;
 }
 
 int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph_transport* transport,

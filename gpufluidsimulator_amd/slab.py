@@ -554,6 +554,7 @@ class NativeSlabSimulation(SlabSimulation):
         if self._transport_kind == "rccl":
             if self._tr is None:       # one communicator for the life of the run (re-balancing keeps it)
                 self._tr = rccl_transport(self.rank, self.world, self._device_index, self.comm.broadcast_bytes)
+                capi._check(L.sph_rccl_transport_selftest(self._tr, 1 << 16))    # fail here, loudly, not inside a step
             tr = self._tr
         else:
             self._tr = host_transport(self.comm)

@@ -272,6 +272,9 @@ typedef struct sph_transport {
 int sph_rccl_unique_id(uint8_t id[128]);
 int sph_rccl_transport_create(sph_transport** out, const uint8_t id[128], int rank, int world, int device);
 void sph_rccl_transport_destroy(sph_transport* t);
+/* two messages of `bytes` and `bytes`/2 bytes from this rank to ITSELF through the transport's communicator (one
+ * ncclGroup), compared on the host: checks the dlopen binding of librccl with real traffic on a one-GPU box */
+int sph_rccl_transport_selftest(sph_transport* t, size_t bytes);
 
 typedef struct sph_slab sph_slab;
 /* Bind a slab context (sph_create_slab, particles uploaded) to its place in the chain of `world` slabs.  The halo

@@ -208,3 +208,16 @@ def test_rebalance_on_gpu_engines():
     assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
     assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
     assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def test_rccl_binding_moves_real_bytes_on_one_rank():
+    """The product transport's librccl binding (dlopen, by-value ncclUniqueId, ncclSend/ncclRecv in one group) with real
+    traffic: a one-rank communicator sends two messages to itself and compares what arrives (csrc/sph_slab.hip:
+    sph_rccl_transport_selftest).  The neighbour exchange itself needs >= 2 GPUs (RCCL refuses two ranks on one device)."""
+    tr = slab.rccl_transport(0, 1, 0, lambda raw: raw)
+    try:
+        L = capi.load()
+        for nbytes in (16, 4 << 10, 4 << 20):
+            capi._check(L.sph_rccl_transport_selftest(tr, nbytes))
+    finally:
+        capi.load().sph_rccl_transport_destroy(tr)
