@@ -248,23 +248,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
 }
 
 // ---- device timing --------------------------------------------------------------------------------------
-struct PhaseTimer {
-    sph_ctx* c; int phase; hipEvent_t a = nullptr, b = nullptr;
-    PhaseTimer(sph_ctx* c_, int ph) : c(c_), phase(ph) {
-        if (!c->timing) return;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-        hipEventRecord(a, c->stream);
-    }
-    ~PhaseTimer() {
-        if (!a || !b) return;
-        hipEventRecord(b, c->stream);
-        c->events.push_back(a);
-        c->events.push_back(b);
-        c->events.push_back((hipEvent_t)(intptr_t)phase);   // tag
-    }
-};
-
-static void timing_collect(sph_ctx* c) {
+void timing_collect(sph_ctx* c) {
     for (size_t k = 0; k + 3 <= c->events.size(); k += 3) {
         hipEvent_t a = c->events[k], b = c->events[k + 1];
         int phase = (int)(intptr_t)c->events[k + 2];

@@ -190,4 +190,22 @@ int launch_integrate(sph_ctx* c, float dt);
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// ---- device timing: a pair of HIP events on the context's stream around a phase (only while sph_timing_enable) ----
+struct PhaseTimer {
+    sph_ctx* c; int phase; hipEvent_t a = nullptr, b = nullptr;
+    PhaseTimer(sph_ctx* c_, int ph) : c(c_), phase(ph) {
+        if (!c->timing) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        hipEventRecord(a, c->stream);
+    }
+    ~PhaseTimer() {
+        if (!a || !b) return;
+        hipEventRecord(b, c->stream);
+        c->events.push_back(a);
+        c->events.push_back(b);
+        c->events.push_back((hipEvent_t)(intptr_t)phase);   // tag
+    }
+};
+void timing_collect(sph_ctx* c);      // sph_capi.hip: waits for the recorded events and adds them up per phase
+
 }  // namespace sph

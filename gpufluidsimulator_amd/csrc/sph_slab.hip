@@ -349,7 +349,8 @@ int slab_step_once(sph_slab* s, float dt) {
     // has the bulk of the step's work in its queue while the halo travels.
     uint32_t a = c->own_off + ((h_lo + 63u) & ~63u), b = c->own_off + ((n - h_hi) & ~63u);
     if (b < a || a > c->own_off + n) { a = c->own_off; b = c->own_off; }     // a thin slab: everything is "boundary"
-    rc = launch_density_range(c, a, b); if (rc) return rc;
+    { PhaseTimer t(c, SPH_PH_DENS); rc = launch_density_range(c, a, b); }
+    if (rc) return rc;
     const size_t rec = 2 * sizeof(float4);
     rc = slab_exchange(s, SPH_TAG_HALO_A, s->halo_send[0], h_lo * rec, s->halo_recv[0], g_lo * rec, s->halo_send[1], h_hi * rec,
                        s->halo_recv[1], g_hi * rec);
@@ -374,8 +375,12 @@ int slab_step_once(sph_slab* s, float dt) {
         c->stage = sph_ctx::ST_CELLS;
     }
     rc = after_comm(s); if (rc) return rc;
-    rc = launch_density_range(c, c->own_off, a); if (rc) return rc;
-    rc = launch_density_range(c, b, c->own_off + n); if (rc) return rc;
+    {
+        PhaseTimer t(c, SPH_PH_DENS);
+        rc = launch_density_range(c, c->own_off, a);
+        if (!rc) rc = launch_density_range(c, b, c->own_off + n);
+    }
+    if (rc) return rc;
     c->have_dens = true;
     // ---- halo B: (density, pressure) of the same boundary particles, same order; interior forces meanwhile ---------
     if (h_lo) SPH_HIP(hipMemcpyAsync(s->dens_send[0], c->dp + c->own_off, h_lo * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
@@ -383,20 +388,26 @@ int slab_step_once(sph_slab* s, float dt) {
                                      c->stream));
     rc = after_main(s); if (rc) return rc;
     const bool mark = force_begin(c, true);
-    rc = launch_force_range(c, a, b, true, true, true, dt, mark); if (rc) return rc;       // interior: queued before the transfer
+    { PhaseTimer t(c, SPH_PH_FORCE); rc = launch_force_range(c, a, b, true, true, true, dt, mark); }   // interior: queued before the transfer
+    if (rc) return rc;
     rc = slab_exchange(s, SPH_TAG_HALO_B, s->dens_send[0], h_lo * sizeof(float2), s->dens_recv[0], g_lo * sizeof(float2),
                        s->dens_send[1], h_hi * sizeof(float2), s->dens_recv[1], g_hi * sizeof(float2));
     if (rc) return rc;
     if (g_lo) SPH_HIP(hipMemcpyAsync(c->dp + c->own_off - g_lo, s->dens_recv[0], g_lo * sizeof(float2), hipMemcpyDeviceToDevice, s->comm));
     if (g_hi) SPH_HIP(hipMemcpyAsync(c->dp + c->own_off + n, s->dens_recv[1], g_hi * sizeof(float2), hipMemcpyDeviceToDevice, s->comm));
     rc = after_comm(s); if (rc) return rc;
-    rc = launch_force_range(c, c->own_off, a, true, true, true, dt, mark); if (rc) return rc;
-    rc = launch_force_range(c, b, c->own_off + n, true, true, true, dt, mark); if (rc) return rc;
+    {
+        PhaseTimer t(c, SPH_PH_FORCE);
+        rc = launch_force_range(c, c->own_off, a, true, true, true, dt, mark);
+        if (!rc) rc = launch_force_range(c, b, c->own_off + n, true, true, true, dt, mark);
+    }
+    if (rc) return rc;
     force_finish(c, true, mark);
     c->have_force = c->have_coll = false;
     // the comm stream must not start the next step's transfers into buffers the main stream still reads
     rc = after_main(s); if (rc) return rc;
     s->steps++;
+    if (c->timing) { c->timed_steps++; if (c->events.size() > 3 * 4096) timing_collect(c); }
     return SPH_OK;
 }
 

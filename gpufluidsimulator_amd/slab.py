@@ -682,6 +682,13 @@ def bench_main(args):
                                    f"{'RCCL send/recv (library comm stream)' if transport == 'rccl' else 'host-staged messages'}",
                        "particles": total, "grid": list(cfg["grid"]), "cuts": sim.cuts, "state": "flow", "runup_steps": runup,
                        "parallelism": f"{world} z-slabs, one per GPU", "transport": transport},
+            # rank 0's fused force pass (its interior + boundary launches of one step), algorithmic bytes as at N = 1
+            "roofline": (lambda t: {"bound": "hbm", "kernel": "k_force<force+collision+integrate> (rank 0, launches of one step)",
+                                    "achieved": 84.0 * n_own / t / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                    "frac": 84.0 * n_own / t / 1e9 / 8000.0, "traffic": None,
+                                    "algorithmic_bytes_per_particle": 84, "avg_launch_ms": t * 1e3,
+                                    "particles_rank0": int(n_own)})(max(phases_ms.get("force", 0.0), 1e-9) * 1e-3),
+            "cpu_baseline": None,      # timed at N = 1 only (bench.py without --gpus)
             "phases_ms_rank0": phases_ms, "slab_stats_rank0": sim.stats, "owned_sum": int(counts[0]),
             "movers_per_step": float(counts[1]) / max(args.steps, 1), "sort_skips": int(counts[2]),
         }
