@@ -363,21 +363,14 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
         __syncthreads();
         OS_STAT(3);                                 // publish + scan
 
-        // GROUPED: the counts of the earlier tiles of the group are requested now, every load in flight at once, and
-        // looked at after the ranking: their trip to memory and back (the words are written through, the loads pass
-        // the L2) hides behind it.  A word that is not there yet is asked for again below.
+        // GROUPED: the counts of the earlier tiles of the group are requested HALFWAY through the ranking, every load in
+        // flight at once, and looked at after it: their trip to memory and back (the words are written through, the
+        // loads pass the L2) hides behind the second half, and by then the tiles that started together with this one
+        // have published (asked for right after the own publication, most words came back stale and cost a second
+        // trip).  A word that is still not there is asked for again below.
         const uint32_t npred = tile - gstart;
         const uint32_t* st32 = status32 + (size_t)gstart * RADIX + threadIdx.x * DPT;
         os_word w[OS_GROUP - 1];
-        if (GROUPED && has_d) {
-#pragma unroll
-            for (uint32_t q = 0; q < OS_GROUP - 1; q++)
-                if (q < npred) {
-                    if (DPT == 2) w[q] = __hip_atomic_load(reinterpret_cast<const os_word*>(st32 + (size_t)q * RADIX),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else w[q] = __hip_atomic_load(st32 + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-        }
 
         // rank: rows of 64 keys in order; equal digits of a row by ballot match-any + popcount of the lower lanes
         // an LDS-typed pointer: a generic `volatile uint32_t*` made every access a flat_load/flat_store with sc0 sc1
@@ -388,6 +381,15 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
 #endif
 #pragma unroll
         for (int t = 0; t < PASS_KPT; t++) {
+            if (GROUPED && t == PASS_KPT / 2 && has_d) {
+#pragma unroll
+                for (uint32_t q = 0; q < OS_GROUP - 1; q++)
+                    if (q < npred) {
+                        if (DPT == 2) w[q] = __hip_atomic_load(reinterpret_cast<const os_word*>(st32 + (size_t)q * RADIX),
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else w[q] = __hip_atomic_load(st32 + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            }
             const uint32_t i = wbase + t * WAVE + lane;
             const bool valid = i < n;
             const uint32_t d = (key[t] >> shift) & (RADIX - 1);
@@ -419,21 +421,39 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
 #pragma unroll
             for (int k = 0; k < DPT; k++) excl[k] = 0;
             if (GROUPED && has_d) {
-                // the counts of the earlier tiles of the group (requested before the ranking, see above)
-                uint32_t spins = 0;
+                // the counts of the earlier tiles of the group (requested before the ranking, see above).  Words that
+                // were not there yet are asked for again ALL AT ONCE, round after round: one trip to memory per round,
+                // not one per stale word
+                auto fresh = [&](os_word v) {
+                    return (uint32_t)v >> OS_CNT_BITS == epoch && (DPT == 1 || (uint32_t)(v >> 32) >> OS_CNT_BITS == epoch);
+                };
+                uint32_t pending = 0u;
 #pragma unroll
                 for (uint32_t q = 0; q < OS_GROUP - 1; q++)
-                    if (q < npred) {
-                        for (;;) {
-                            const bool ok = (uint32_t)w[q] >> OS_CNT_BITS == epoch &&
-                                            (DPT == 1 || (uint32_t)(w[q] >> 32) >> OS_CNT_BITS == epoch);
-                            if (ok) break;
-                            if (++spins > OS_SPIN_LIMIT) { *err = 1u; w[q] = 0; break; }      // give up: counts of 0
-                            __builtin_amdgcn_s_sleep(1);
+                    if (q < npred && !fresh(w[q])) pending |= 1u << q;
+                uint32_t spins = 0;
+                while (pending) {
+                    if (++spins > OS_SPIN_LIMIT) {                            // give up: counts of 0
+                        *err = 1u;
+#pragma unroll
+                        for (uint32_t q = 0; q < OS_GROUP - 1; q++) if (pending >> q & 1u) w[q] = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (uint32_t q = 0; q < OS_GROUP - 1; q++)
+                        if (pending >> q & 1u) {
                             if (DPT == 2) w[q] = __hip_atomic_load(reinterpret_cast<const os_word*>(st32 + (size_t)q * RADIX),
                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             else w[q] = __hip_atomic_load(st32 + (size_t)q * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
+#pragma unroll
+                    for (uint32_t q = 0; q < OS_GROUP - 1; q++)
+                        if ((pending >> q & 1u) && fresh(w[q])) pending &= ~(1u << q);
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < OS_GROUP - 1; q++)
+                    if (q < npred) {
                         excl[0] += (uint32_t)w[q] & ((1u << OS_CNT_BITS) - 1u);
                         if (DPT == 2) excl[DPT - 1] += (uint32_t)(w[q] >> 32) & ((1u << OS_CNT_BITS) - 1u);
                     }
