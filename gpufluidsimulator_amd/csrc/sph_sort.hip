@@ -124,7 +124,7 @@ __device__ __forceinline__ void wave_count_digit(uint32_t* counts, uint32_t d, b
 // digit counts of the passes pass0 .. pass0+passes-1 per group of tiles: hist[(group * 4 + pass) * 512 + digit],
 // ACCUMULATED (k_os_scan zeroes what it has read).  A block counts OS_HIST_TILES consecutive tiles (all of one
 // group) in LDS and adds what it found; 16-byte loads.
-constexpr uint32_t OS_HIST_TILES = 4;
+constexpr uint32_t OS_HIST_TILES = 2;
 template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint32_t* __restrict__ keys, uint32_t n_arg,
                                                           const uint32_t* __restrict__ n_dev, uint32_t pass0,
@@ -393,18 +393,25 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
             const uint32_t i = wbase + t * WAVE + lane;
             const bool valid = i < n;
             const uint32_t d = (key[t] >> shift) & (RADIX - 1);
-            uint64_t peers = __ballot(valid);
+            // the lanes whose digit differs from mine, bit by bit, in 32-bit halves: bm = my bit b spread over a word
+            // (one v_bfe_i32), m = the wave's ballot of bit b, and `dif |= m ^ bm` is one three-input bit-op per half
+            // (written with 64-bit per-lane selects the same loop cost twice the instructions, and the pass is bound
+            // by the instructions it issues)
+            uint32_t dif_lo = 0u, dif_hi = 0u;
 #pragma unroll
             for (int b = 0; b < BITS; b++) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t m = __ballot(bit);
-                peers &= bit ? m : ~m;
+                const uint32_t bm = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+                const uint64_t m = __ballot(bm != 0u);
+                dif_lo |= (uint32_t)m ^ bm;
+                dif_hi |= (uint32_t)(m >> 32) ^ bm;
             }
-            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            const uint64_t vmask = __ballot(valid);
+            const uint32_t peers_lo = ~dif_lo & (uint32_t)vmask, peers_hi = ~dif_hi & (uint32_t)(vmask >> 32);
+            const uint32_t rank = (uint32_t)__popc(peers_lo & (uint32_t)lt_mask) + (uint32_t)__popc(peers_hi & (uint32_t)(lt_mask >> 32));
             uint32_t base = 0;
             if (valid) base = pos[d];                       // every peer reads the same word
             os_wave_lds_order();
-            if (valid && rank == 0) pos[d] = base + (uint32_t)__popcll(peers);   // LDS is in order per wave
+            if (valid && rank == 0) pos[d] = base + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi);   // LDS is in order per wave
             os_wave_lds_order();
 #if SPH_SORT_STAGE
             if (valid) { s_key[base + rank] = key[t]; s_val[base + rank] = val[t]; }
