@@ -111,6 +111,7 @@ SIGNATURES = {
     "sph_rccl_transport_create": (C.c_int, [C.POINTER(C.POINTER(Transport)), C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "sph_rccl_transport_destroy": (None, [C.POINTER(Transport)]),
     "sph_rccl_transport_selftest": (C.c_int, [C.POINTER(Transport), C.c_size_t]),
+    "sph_slab_in_place_merges": (C.c_uint64, [C.c_void_p]),
     "sph_slab_create": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int, C.POINTER(Transport), _U32]),
     "sph_slab_destroy": (None, [_P]),
     "sph_slab_step": (C.c_int, [_P, C.c_float, _U32]),

@@ -81,6 +81,54 @@ __global__ __launch_bounds__(256) void k_slab_unpack(const float4* __restrict__ 
     if (key) key[i] = cell_key(g, p.x, p.y, p.z);
 }
 
+// Arrivals join a BOUNDARY LAYER in place.  A particle a neighbour sent lies in the cell layer next to the cut it
+// crossed, i.e. in the first or the last layer of the sorted owned range; the space in front of / behind the owned
+// range is free (the ghosts of the last step are gone, those of this step have not come yet).  So only that layer is
+// re-merged: the layer's nl particles and the k arrivals go, in key order (equal keys: residents first, arrivals in
+// arrival order -- the order the full stable sort of [owned, arrivals] would produce), to the slots [d0, d0 + nl + k)
+// of the scratch arrays, d0 = l0 - k on the low side and l0 on the high side, and are copied back; every other slot of
+// the 16.7 M stays where it is.  One thread per resident (counts the arrivals with a smaller key from LDS) and per
+// arrival (ranks itself among the arrivals, binary search among the residents).
+#ifndef SPH_SLAB_INSERT
+#define SPH_SLAB_INSERT 1            // 0: arrivals always take the pass over all particles (launch_merge_arrivals)
+#endif
+constexpr uint32_t SLAB_INSERT_MAX = 2048;
+__global__ __launch_bounds__(256) void k_slab_insert(const float4* __restrict__ posi, const float4* __restrict__ velr,
+                                                     const uint32_t* __restrict__ keyS, uint32_t l0, uint32_t nl,
+                                                     const float4* __restrict__ rec, uint32_t k, GridDesc g,
+                                                     float4* __restrict__ posi_o, float4* __restrict__ velr_o,
+                                                     uint32_t* __restrict__ key_o, uint32_t d0) {
+    __shared__ uint32_t s_ak[SLAB_INSERT_MAX];
+    for (uint32_t r = threadIdx.x; r < k; r += 256u) {
+        const float4 p = rec[2 * r];
+        s_ak[r] = cell_key(g, p.x, p.y, p.z);
+    }
+    __syncthreads();
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < nl) {
+        const uint32_t key = keyS[l0 + t];
+        uint32_t less = 0;
+        for (uint32_t r = 0; r < k; r++) less += s_ak[r] < key ? 1u : 0u;
+        const uint32_t dst = d0 + t + less;
+        posi_o[dst] = posi[l0 + t];
+        velr_o[dst] = velr[l0 + t];
+        key_o[dst] = key;
+    } else if (t - nl < k) {
+        const uint32_t r = t - nl, key = s_ak[r];
+        uint32_t among = 0;
+        for (uint32_t q = 0; q < k; q++) among += (s_ak[q] < key || (s_ak[q] == key && q < r)) ? 1u : 0u;
+        uint32_t lo = 0, hi = nl;                       // residents with a key <= mine
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (keyS[l0 + mid] <= key) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t dst = d0 + among + lo;
+        posi_o[dst] = rec[2 * r];
+        velr_o[dst] = rec[2 * r + 1];
+        key_o[dst] = key;
+    }
+}
+
 }  // namespace sph
 
 using namespace sph;
@@ -180,7 +228,7 @@ struct sph_slab {
     char* stage_send[2] = {nullptr, nullptr};   // pinned staging for host-staged transports
     char* stage_recv[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
-    uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0;
+    uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0, inserts = 0;
 };
 
 namespace {
@@ -304,6 +352,34 @@ int slab_step_once(sph_slab* s, float dt) {
         // slot (one pass over the particles; a full radix sort when the merge path is switched off)
         const bool merge = c->sort_merge && c->order_valid && c->cells_valid && c->cells_lo == c->own_off &&
                            c->cells_hi == c->own_off + c->n;
+        const bool in_place = SPH_SLAB_INSERT && merge && in_lo <= SLAB_INSERT_MAX && in_hi <= SLAB_INSERT_MAX && in_lo <= c->own_off &&
+                              own_lo + own_hi <= c->n;
+        if (in_place) {
+            // only the two boundary layers are touched (see k_slab_insert): their cells leave the table, the merged
+            // layers come back from the scratch arrays, their cells are built again
+            for (int side = 0; side < 2; side++) {
+                const uint32_t k = side == 0 ? in_lo : in_hi;
+                if (!k) continue;
+                const uint32_t nl = side == 0 ? own_lo : own_hi;
+                const uint32_t l0 = side == 0 ? c->own_off : c->own_off + c->n - own_hi;
+                const uint32_t d0 = side == 0 ? l0 - k : l0;
+                rc = launch_cells_clear_range(c, l0, l0 + nl); if (rc) return rc;
+                hipLaunchKernelGGL(k_slab_insert, dim3(ceil_div(nl + k, 256u)), dim3(256), 0, c->stream, c->posi, c->velr, c->keyS, l0,
+                                   nl, s->mig_recv[side] + 2, k, c->grid, c->posi2, c->velr2, c->keyS2, d0);
+                SPH_HIP(hipGetLastError());
+                SPH_HIP(hipMemcpyAsync(c->posi + d0, c->posi2 + d0, (size_t)(nl + k) * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+                SPH_HIP(hipMemcpyAsync(c->velr + d0, c->velr2 + d0, (size_t)(nl + k) * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+                SPH_HIP(hipMemcpyAsync(c->keyS + d0, c->keyS2 + d0, (size_t)(nl + k) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+                if (side == 0) c->own_off = d0;
+                c->n += k;
+                c->cells_lo = c->own_off; c->cells_hi = c->own_off + c->n;
+                rc = launch_cells_build_range(c, d0, d0 + nl + k); if (rc) return rc;
+            }
+            own_lo += in_lo;
+            own_hi += in_hi;
+            s->inserts++;
+            s->resorts++;
+        } else {
         uint32_t appended = 0;
         for (int side = 0; side < 2; side++) {
             const uint32_t cnt = side == 0 ? in_lo : in_hi;
@@ -327,6 +403,7 @@ int slab_step_once(sph_slab* s, float dt) {
         own_lo += in_lo;
         own_hi += in_hi;
         s->resorts++;
+        }
     }
     const uint32_t n = c->n;
     const uint32_t g_lo = s->has_lo ? peer_own_lo + m_lo : 0u;   // ghosts I receive = what stayed in the neighbour's
@@ -577,6 +654,8 @@ int sph_slab_sync(sph_slab* s) {
     SPH_HIP(hipStreamSynchronize(s->comm));
     return sph_sync(s->c);
 }
+
+uint64_t sph_slab_in_place_merges(const sph_slab* s) { return s ? s->inserts : 0; }
 
 int sph_slab_stats(const sph_slab* s, uint64_t out[5]) {
     SPH_REQUIRE(s && out, SPH_E_INVALID, "null argument");

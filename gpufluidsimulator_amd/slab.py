@@ -589,7 +589,8 @@ class NativeSlabSimulation(SlabSimulation):
         base = getattr(self, "_stats_base", {"migrants": 0, "resorts": 0, "ghosts": 0, "host_waits": 0, "steps": 0})
         self.stats.update(steps=base["steps"] + int(out[0]), migrants=base["migrants"] + int(out[1]),
                           resorts=base["resorts"] + int(out[2]), ghosts=base["ghosts"] + int(out[3]),
-                          host_waits=base["host_waits"] + int(out[4]))
+                          host_waits=base["host_waits"] + int(out[4]),
+                          in_place_merges=base.get("in_place_merges", 0) + int(capi.load().sph_slab_in_place_merges(self._slab)))
 
     def sync(self):
         capi._check(capi.load().sph_slab_sync(self._slab))
@@ -597,7 +598,7 @@ class NativeSlabSimulation(SlabSimulation):
     def rebalance(self, tolerance=0.02):
         self.sync()
         self._pull_stats()
-        self._stats_base = {k: self.stats.get(k, 0) for k in ("migrants", "resorts", "ghosts", "host_waits", "steps")}
+        self._stats_base = {k: self.stats.get(k, 0) for k in ("migrants", "resorts", "ghosts", "host_waits", "steps", "in_place_merges")}
         self._unbind()                 # the engine (context) is replaced when the cuts move
         moved = super().rebalance(tolerance)
         self._bind()

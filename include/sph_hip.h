@@ -287,8 +287,11 @@ void sph_slab_destroy(sph_slab* s);
  * on the context's stream and a second, high-priority stream; the host waits ONCE per step (for the layer counts). */
 int sph_slab_step(sph_slab* s, float dt, uint32_t n_steps);
 int sph_slab_sync(sph_slab* s);
-/* {steps, particles sent away, second sorts (steps with arrivals), ghosts received, host waits} */
+/* {steps, particles sent away, steps with arrivals, ghosts received, host waits} */
 int sph_slab_stats(const sph_slab* s, uint64_t out[5]);
+/* of the steps with arrivals, those that merged them into the two boundary layers in place (the rest ran a pass over
+ * all particles: more than 2048 arrivals on a side, or no valid cell table) */
+uint64_t sph_slab_in_place_merges(const sph_slab* s);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,8 @@ def test_slabs_with_migration_match_whole_domain(case, world):
     assert sum(r[1]["migrants"] for r in res) > 0
     assert sum(r[3] for r in res) == pos.shape[0]
     assert all(r[1]["host_waits"] == steps for r in res), "one host wait per step and rank"
+    arrivals, in_place = sum(r[1]["resorts"] for r in res), sum(r[1]["in_place_merges"] for r in res)
+    assert arrivals > 0 and in_place == arrivals, "arrivals join their boundary layer in place (k_slab_insert)"
     assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
     assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
     assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
