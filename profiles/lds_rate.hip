@@ -58,6 +58,62 @@ __global__ __launch_bounds__(256) void k(const int* __restrict__ entry, int stri
     out[blockIdx.x * 256 + threadIdx.x] = acc0 + acc1 + acc2 + acc3;
 }
 
+// The pair kernels' mix: R ds_read_b64 per candidate + V fp32 VALU instructions that use what was read.
+// READS = 0: the arithmetic alone (operands stay in registers); VALU = 0: the reads alone.
+template <int READS, int VALU>
+__global__ __launch_bounds__(256) void kmix(const int* __restrict__ entry, int stride, int iters, float* out) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < 4864; i += 256) lds[i] = 1.0f + (float)i * 1e-6f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned addr = (unsigned)((wave * 100 + entry[lane]) * stride * 4);
+    const unsigned sb = (unsigned)stride * 4u;
+    float a0 = 1.f + lane, a1 = 2.f, a2 = 3.f, a3 = 4.f, a4 = 5.f, a5 = 6.f;
+    double d0 = 1.0, d1 = 2.0, d2 = 3.0, d3 = 4.0;
+    for (int it = 0; it < iters; it++) {
+        unsigned a = addr;
+        for (int k = 0; k < 16; k++) {              // 16 candidates per row walk
+            if (READS == 4)
+                asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:8\n ds_read_b64 %2, %4 offset:16\n ds_read_b64 %3, %4 offset:24\n s_waitcnt lgkmcnt(0)\n"
+                             : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(a) : "memory");
+            if (READS == 2)
+                asm volatile("ds_read_b64 %0, %2\n ds_read_b32 %1, %2 offset:8\n s_waitcnt lgkmcnt(0)\n"
+                             : "=&v"(d0), "=&v"(a5) : "v"(a) : "memory");
+            a += sb;
+            const float x0 = ((float*)&d0)[0], x1 = ((float*)&d0)[1], x2 = ((float*)&d1)[0], x3 = ((float*)&d1)[1];
+#pragma unroll
+            for (int v = 0; v < VALU / 6; v++) {    // six independent fp32 fmas per round, fed by the loaded values
+                asm volatile("v_fmac_f32 %0, %6, %7\n v_fmac_f32 %1, %7, %8\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %9, %6\n v_fmac_f32 %4, %6, %8\n v_fmac_f32 %5, %7, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+            }
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + (float)(d2 + d3);
+}
+
+template <int READS, int VALU>
+void runmix(const char* name, const std::vector<int>& entry) {
+    int* d_entry; float* out;
+    hipMalloc(&d_entry, 64 * sizeof(int));
+    hipMemcpy(d_entry, entry.data(), 64 * sizeof(int), hipMemcpyHostToDevice);
+    const int iters = 300;
+    for (int w : {3, 5, 8}) {                   // blocks of 4 waves per CU = waves per SIMD (k_force runs 5, k_density 6)
+        const int blocks = 256 * w;
+        hipMalloc(&out, blocks * 256 * sizeof(float));
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL((kmix<READS, VALU>), dim3(blocks), dim3(256), 19456, 0, d_entry, 10, 4, out);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((kmix<READS, VALU>), dim3(blocks), dim3(256), 19456, 0, d_entry, 10, iters, out);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-44s : %6.2f ns per candidate per SIMD at %d waves per SIMD\n", name, ms * 1e6 / ((double)iters * 16 * w), w);
+        hipFree(out);
+    }
+    hipFree(d_entry);
+}
+
 // The s_waitcnt after every read would measure latency, not throughput, for one wave; with W >= 4 waves per SIMD the
 // LDS pipe is kept full by the other waves and the wall time is the pipe's.
 template <int MODE>
@@ -99,6 +155,12 @@ static std::vector<int> cells(const std::vector<int>& lanes_per_cell, const std:
 int main() {
     const std::vector<int> eight(8, 8);
     const auto rest = cells(eight, eight);                                         // 8 lanes per cell, cells 8 entries apart
+    runmix<0, 24>("24 VALU, no LDS", rest);
+    runmix<4, 0>("4 ds_read_b64, no VALU", rest);
+    runmix<4, 24>("4 ds_read_b64 + 24 VALU (force-like)", rest);
+    runmix<0, 12>("12 VALU, no LDS", rest);
+    runmix<2, 0>("b64 + b32, no VALU", rest);
+    runmix<2, 12>("b64 + b32 + 12 VALU (density-like)", rest);
     const auto flow = cells({5, 9, 7, 10, 8, 9, 7, 9}, {7, 9, 7, 10, 8, 9, 7, 9});  // cells c, c+2 are 16 apart inside a 16-lane group
     const auto flow2 = cells({3, 9, 9, 9, 9, 9, 9, 7}, {9, 9, 9, 9, 9, 9, 9, 9});   // 9 per cell: no pair is 16 or 32 apart
     for (int stride : {10, 11}) {
@@ -128,7 +190,7 @@ int main() {
         run<0>("ds_read_b64", cells({4, 7, 7, 7, 7, 8, 8, 8, 8}, {8, 8, 8, 8, 8, 8, 8, 8, 8}), 10, "cells c, c+4 32 apart");
         run<0>("ds_read_b64", cells({4, 7, 7, 7, 7, 8, 8, 8, 8}, {8, 8, 8, 8, 8, 8, 8, 8, 8}), 2, "cells c, c+4 32 apart");
     }
-    for (int stride : {3, 4, 5, 10, 12}) {
+    for (int stride : {4, 12, 3, 5, 10}) {           // 3, 5, 10: not 16-byte aligned, 20+ ns per read
         run<5>("ds_read_b96", rest, stride, "rest (8 per cell)");
         run<5>("ds_read_b96", flow2, stride, "flow (9 per cell)");
         run<4>("ds_read_b128", rest, stride, "rest (8 per cell)");
