@@ -72,6 +72,30 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, in
                                "v_fma_mix_f32 %4, %8, %9, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %9, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
                                "v_fma_mix_f32 %6, %8, %9, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %9, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 14) {  // v_fmaak_f32: fma with a 32-bit literal addend (what hipcc picks for fmaf(a, a, 1e-30f))
+            REP16(asm volatile("v_fmaak_f32 %0, %8, %8, 0xda24260\n v_fmaak_f32 %1, %9, %9, 0xda24260\n v_fmaak_f32 %2, %8, %9, 0xda24260\n v_fmaak_f32 %3, %9, %8, 0xda24260\n"
+                               "v_fmaak_f32 %4, %8, %8, 0xda24260\n v_fmaak_f32 %5, %9, %9, 0xda24260\n v_fmaak_f32 %6, %8, %9, 0xda24260\n v_fmaak_f32 %7, %9, %8, 0xda24260\n"
+                               : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 15) {  // v_alignbit_b32 (the collision mask's shift-in)
+            REP16(asm volatile("v_alignbit_b32 %0, %0, %8, 31\n v_alignbit_b32 %1, %1, %9, 31\n v_alignbit_b32 %2, %2, %8, 31\n v_alignbit_b32 %3, %3, %9, 31\n"
+                               "v_alignbit_b32 %4, %4, %8, 31\n v_alignbit_b32 %5, %5, %9, 31\n v_alignbit_b32 %6, %6, %8, 31\n v_alignbit_b32 %7, %7, %9, 31\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 16) {  // v_alignbit_b32 with the shift in a VGPR
+            REP16(asm volatile("v_alignbit_b32 %0, %0, %8, %9\n v_alignbit_b32 %1, %1, %8, %9\n v_alignbit_b32 %2, %2, %8, %9\n v_alignbit_b32 %3, %3, %8, %9\n"
+                               "v_alignbit_b32 %4, %4, %8, %9\n v_alignbit_b32 %5, %5, %8, %9\n v_alignbit_b32 %6, %6, %8, %9\n v_alignbit_b32 %7, %7, %8, %9\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(m1));)
+        } else if (KIND == 17) {  // v_lshl_or_b32 v, v, 1, v  (near << 1 | bit)
+            REP16(asm volatile("v_lshl_or_b32 %0, %0, 1, %8\n v_lshl_or_b32 %1, %1, 1, %8\n v_lshl_or_b32 %2, %2, 1, %8\n v_lshl_or_b32 %3, %3, 1, %8\n"
+                               "v_lshl_or_b32 %4, %4, 1, %8\n v_lshl_or_b32 %5, %5, 1, %8\n v_lshl_or_b32 %6, %6, 1, %8\n v_lshl_or_b32 %7, %7, 1, %8\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+        } else if (KIND == 18) {  // v_lshl_or_b32 with the shift in a VGPR
+            REP16(asm volatile("v_lshl_or_b32 %0, %0, %9, %8\n v_lshl_or_b32 %1, %1, %9, %8\n v_lshl_or_b32 %2, %2, %9, %8\n v_lshl_or_b32 %3, %3, %9, %8\n"
+                               "v_lshl_or_b32 %4, %4, %9, %8\n v_lshl_or_b32 %5, %5, %9, %8\n v_lshl_or_b32 %6, %6, %9, %8\n v_lshl_or_b32 %7, %7, %9, %8\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(m1));)
+        } else if (KIND == 19) {  // v_max_f32 with inline constant 0 (VOP2) and v_fma_f32 with an inline constant (VOP3)
+            REP16(asm volatile("v_max_f32 %0, 0, %0\n v_fma_f32 %1, %1, %8, 1.0\n v_max_f32 %2, 0, %2\n v_fma_f32 %3, %3, %8, 1.0\n"
+                               "v_max_f32 %4, 0, %4\n v_fma_f32 %5, %5, %8, 1.0\n v_max_f32 %6, 0, %6\n v_fma_f32 %7, %7, %8, 1.0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
         } else if (KIND == 13) {  // v_cvt_f32_f16 (what a plain conversion of a staged half would cost)
             REP16(asm volatile("v_cvt_f32_f16 %0, %8\n v_cvt_f32_f16 %1, %9\n v_cvt_f32_f16 %2, %8\n v_cvt_f32_f16 %3, %9\n"
                                "v_cvt_f32_f16 %4, %8\n v_cvt_f32_f16 %5, %9\n v_cvt_f32_f16 %6, %8\n v_cvt_f32_f16 %7, %9\n"
@@ -109,7 +133,16 @@ void run(const char* name, int per_iter) {
     }
 }
 
-int main() {
+int main(int argc, char**) {
+    if (argc > 1) {            // any argument: only the kinds added last
+        run<14>("v_fmaak_f32 (32-bit literal)", 128);
+        run<15>("v_alignbit_b32 v, v, v, 31", 128);
+        run<16>("v_alignbit_b32 v, v, v, v", 128);
+        run<17>("v_lshl_or_b32 v, v, 1, v", 128);
+        run<18>("v_lshl_or_b32 v, v, v, v", 128);
+        run<19>("v_max 0 / v_fma inline 1.0 mix", 128);
+        return 0;
+    }
     run<0>("v_fma_f32 (VOP3) independent", 128);
     run<1>("v_fmac_f32 (VOP2) independent", 128);
     run<6>("v_sub/v_max/v_mul (VOP2)", 128);
@@ -124,5 +157,11 @@ int main() {
     run<11>("v_fma_mix_f32 (2 fp16 srcs)", 128);
     run<12>("v_fma_mix_f32 (1 fp16 hi src)", 128);
     run<13>("v_cvt_f32_f16", 128);
+    run<14>("v_fmaak_f32 (32-bit literal)", 128);
+    run<15>("v_alignbit_b32 v, v, v, 31", 128);
+    run<16>("v_alignbit_b32 v, v, v, v", 128);
+    run<17>("v_lshl_or_b32 v, v, 1, v", 128);
+    run<18>("v_lshl_or_b32 v, v, v, v", 128);
+    run<19>("v_max 0 / v_fma inline 1.0 mix", 128);
     return 0;
 }
