@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage: scratch/mkvariant.sh NAME "-DFOO=1 -DBAR=2"   -> scratch/v/libsph_NAME.so
+# usage: profiles/scripts/mkvariant.sh NAME "-DFOO=1 -DBAR=2"   -> scratch/v/libsph_NAME.so
 set -e
 cd /root/repo
 N=$1; shift
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value -fno-slp-vectorize -Iinclude $*"
-T=/tmp/var_$N; mkdir -p $T
+T=/tmp/var_$N; mkdir -p $T scratch/v
 for f in sph_capi sph_sort sph_pairs sph_halo sph_slab sph_compat; do
   /opt/rocm/bin/hipcc $FL -x hip -c gpufluidsimulator_amd/csrc/$f.hip -o $T/$f.o &
 done

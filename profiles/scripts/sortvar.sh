@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for L in default "$@"; do
   if [ "$L" = default ]; then unset SPH_HIP_LIB; else export SPH_HIP_LIB=$PWD/scratch/v/libsph_$L.so; fi
   rm -rf gpurun_out/prof_sv
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_sv -o sv -- python scratch/fullsort_prof.py C3 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_sv -o sv -- python profiles/scripts/fullsort_prof.py C3 > /dev/null 2>&1
   echo "== $L"
   python - <<PY
 import csv
