@@ -639,6 +639,8 @@ def bench_main(args):
         cfg = ic.weak_scaling_config(world)
     sim = NativeSlabSimulation(comm, cfg["box"], cfg["grid"], device_index=local, transport=transport,
                                lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"])
+    mixed = getattr(args, "precision", "f32") == "mixed"        # BASELINE config 5's arithmetic
+    sim.engine.ctx.set_precision(mixed)
     dt = float(ic.DEFAULT_DT)
     runup = args.runup if getattr(args, "runup", None) is not None else 6000
     t0 = time.perf_counter()
@@ -674,7 +676,8 @@ def bench_main(args):
         out = {
             "metric": "particle-steps/sec", "value": total * args.steps / wall, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32 state + packed-f16 density pairs (config 5)" if mixed else "f32",
             "data": "synthetic",
             "config": {"workload": f"dam-break {'C4 (strong scaling)' if strong else 'C3 per GPU (weak scaling)'}: "
                                    f"{cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} = {total} particles "
