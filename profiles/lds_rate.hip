@@ -79,6 +79,16 @@ __global__ __launch_bounds__(256) void kmix(const int* __restrict__ entry, int s
             if (READS == 2)
                 asm volatile("ds_read_b64 %0, %2\n ds_read_b32 %1, %2 offset:8\n s_waitcnt lgkmcnt(0)\n"
                              : "=&v"(d0), "=&v"(a5) : "v"(a) : "memory");
+            if (READS == 22)       // two density candidates: b64 + b32 each
+                asm volatile("ds_read_b64 %0, %3\n ds_read_b32 %2, %3 offset:8\n ds_read_b64 %1, %3 offset:40\n ds_read_b32 %2, %3 offset:48\n s_waitcnt lgkmcnt(0)\n"
+                             : "=&v"(d0), "=&v"(d1), "=&v"(a5) : "v"(a) : "memory");
+            if (READS == 21) {     // two density candidates in one b128 ({x0,y0,x1,y1}) + one b64 ({z0,z1}); 16-byte aligned
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 q;
+                asm volatile("ds_read_b128 %0, %2\n ds_read_b64 %1, %2 offset:16\n s_waitcnt lgkmcnt(0)\n"
+                             : "=&v"(q), "=&v"(d1) : "v"(a & ~15u) : "memory");
+                d0 = *(double*)&q;
+            }
             a += sb;
             const float x0 = ((float*)&d0)[0], x1 = ((float*)&d0)[1], x2 = ((float*)&d1)[0], x3 = ((float*)&d1)[1];
 #pragma unroll
@@ -161,6 +171,11 @@ int main() {
     runmix<0, 12>("12 VALU, no LDS", rest);
     runmix<2, 0>("b64 + b32, no VALU", rest);
     runmix<2, 12>("b64 + b32 + 12 VALU (density-like)", rest);
+    runmix<22, 18>("2 x (b64 + b32) + 18 VALU (2 density cand.)", rest);
+    runmix<21, 18>("b128 + b64 + 18 VALU (2 density cand.)", rest);
+    runmix<21, 0>("b128 + b64, no VALU", rest);
+    runmix<22, 0>("2 x (b64 + b32), no VALU", rest);
+    return 0;
     const auto flow = cells({5, 9, 7, 10, 8, 9, 7, 9}, {7, 9, 7, 10, 8, 9, 7, 9});  // cells c, c+2 are 16 apart inside a 16-lane group
     const auto flow2 = cells({3, 9, 9, 9, 9, 9, 9, 7}, {9, 9, 9, 9, 9, 9, 9, 9});   // 9 per cell: no pair is 16 or 32 apart
     for (int stride : {10, 11}) {
