@@ -101,6 +101,40 @@ __global__ __launch_bounds__(256) void kmix(const int* __restrict__ entry, int s
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + (float)(d2 + d3);
 }
 
+// software-pipelined form of the force-like mix: the reads of candidate k+1 are in flight while candidate k's
+// arithmetic runs (two register sets, loop unrolled by two; s_waitcnt lgkmcnt(4) = "all but the newest four")
+__global__ __launch_bounds__(256) void kpipe(const int* __restrict__ entry, int stride, int iters, float* out) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < 4864; i += 256) lds[i] = 1.0f + (float)i * 1e-6f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned addr = (unsigned)((wave * 100 + entry[lane]) * stride * 4);
+    const unsigned sb = (unsigned)stride * 4u;
+    float a0 = 1.f + lane, a1 = 2.f, a2 = 3.f, a3 = 4.f, a4 = 5.f, a5 = 6.f;
+    double p0, p1, p2, p3, q0, q1, q2, q3;
+#define ISSUE(r0, r1, r2, r3, ad) asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:8\n ds_read_b64 %2, %4 offset:16\n ds_read_b64 %3, %4 offset:24\n" \
+                                               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(ad) : "memory")
+#define WORK(r0, r1) do { asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                                  \
+        const float x0 = ((float*)&r0)[0], x1 = ((float*)&r0)[1], x2 = ((float*)&r1)[0], x3 = ((float*)&r1)[1];          \
+        _Pragma("unroll") for (int v = 0; v < 4; v++)                                                                          \
+            asm volatile("v_fmac_f32 %0, %6, %7\n v_fmac_f32 %1, %7, %8\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %9, %6\n v_fmac_f32 %4, %6, %8\n v_fmac_f32 %5, %7, %9\n" \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "v"(x0), "v"(x1), "v"(x2), "v"(x3)); } while (0)
+    for (int it = 0; it < iters; it++) {
+        unsigned a = addr;
+        ISSUE(p0, p1, p2, p3, a); a += sb;
+        for (int k = 0; k < 16; k += 2) {
+            ISSUE(q0, q1, q2, q3, a); a += sb;
+            WORK(p0, p1);
+            ISSUE(p0, p1, p2, p3, a); a += sb;      // (one candidate past the end on the last round: still inside the slice)
+            WORK(q0, q1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#undef ISSUE
+#undef WORK
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + (float)(p2 + p3 + q2 + q3);
+}
+
 template <int READS, int VALU>
 void runmix(const char* name, const std::vector<int>& entry) {
     int* d_entry; float* out;
@@ -171,6 +205,26 @@ int main() {
     runmix<0, 12>("12 VALU, no LDS", rest);
     runmix<2, 0>("b64 + b32, no VALU", rest);
     runmix<2, 12>("b64 + b32 + 12 VALU (density-like)", rest);
+    {
+        int* d_entry; float* out;
+        hipMalloc(&d_entry, 64 * sizeof(int));
+        hipMemcpy(d_entry, rest.data(), 64 * sizeof(int), hipMemcpyHostToDevice);
+        for (int w : {3, 5, 8}) {
+            const int blocks = 256 * w, iters = 300;
+            hipMalloc(&out, blocks * 256 * sizeof(float));
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipLaunchKernelGGL(kpipe, dim3(blocks), dim3(256), 19456, 0, d_entry, 10, 4, out);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kpipe, dim3(blocks), dim3(256), 19456, 0, d_entry, 10, iters, out);
+            hipEventRecord(e1);
+            hipDeviceSynchronize();
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-44s : %6.2f ns per candidate per SIMD at %d waves per SIMD\n", "4 ds_read_b64 + 24 VALU, software-pipelined", ms * 1e6 / ((double)iters * 16 * w), w);
+            hipFree(out);
+        }
+        hipFree(d_entry);
+    }
     runmix<22, 18>("2 x (b64 + b32) + 18 VALU (2 density cand.)", rest);
     runmix<21, 18>("b128 + b64 + 18 VALU (2 density cand.)", rest);
     runmix<21, 0>("b128 + b64, no VALU", rest);
