@@ -244,6 +244,8 @@ def main():
                          "the density pass): a separate dtype line, never the fp32 headline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="rehearsal of the multi-rank path on a one-GPU box: every rank uses device 0 (needs --transport host)")
     args = ap.parse_args()
     rank, world, local = _dist_env()
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ:

@@ -622,6 +622,10 @@ def bench_main(args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")     # only a direct single-rank run gets here without a launcher
     transport = getattr(args, "transport", "rccl")
+    if getattr(args, "one_gpu", False):               # rehearsal on a one-GPU box: every rank on device 0, host-staged
+        if transport != "host":
+            sys.exit("bench: --one-gpu needs --transport host (RCCL refuses two ranks on one device)")
+        local = 0
     torch.cuda.set_device(local)
     # torch.distributed is the launcher's plumbing: rendezvous, the RCCL id, barriers and the max over ranks.  The
     # data path (migrants, halos) is the library's own RCCL communicator on its comm stream -- or, with
