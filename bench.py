@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- particle-steps/sec of the SPH step on MI355X (see BASELINE.json / DESIGN.md section 5).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--runup R] [--workload C3|C2|C1] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--runup R] [--workload C3|C2|C1|C4|C5] [--no-cpu]
 
 N = 1: the whole-domain context runs BASELINE config 3 (dam-break, 16,777,216 particles, 512^3 grid, dt 5e-7)
 with the state resident in HBM.  The timed state is a FLOWING dam: the same initial lattice is first stepped R
@@ -10,7 +10,10 @@ steps), so that in the timed window every phase of the reference's step does wor
 density, force, collision, integrate (SPH/particleSystem.cpp:773-795).  Then W warm-up steps and K timed steps
 between two device syncs.  `value` is that figure; `value_at_rest` (fresh lattice) and `value_full_sort` (the same
 flowing state with the radix sort forced every step) are reported next to it.
-N > 1 (launched by torch.distributed.run, one rank per GPU): z-slabs, see gpufluidsimulator_amd/slab.py.
+N > 1 (launched by torch.distributed.run, one rank per GPU): z-slabs, see gpufluidsimulator_amd/slab.py.  The default is
+STRONG scaling of the same config 3 (BASELINE.json's metric: "dam-break 16M particles, 1/2/4/8 MI355X"); `--scaling weak`
+gives every GPU its own 16.7 M particles, `--workload C4` is BASELINE config 4.  `--gpus N --one-gpu --transport local`
+rehearses the N-rank step as N threads on one GPU.
 
 One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the fused force+collision+integrate
 traversal) by its ALGORITHMIC bytes over its mean device time measured with HIP events on the library's stream
@@ -46,7 +49,7 @@ BYTES_PER_PARTICLE = {
 }
 # useful flops: candidates x per-pair arithmetic of the reference formulas
 FLOP_PER_PARTICLE = {"dens": 216 * 11, "force_fused": 216 * 34}
-DEFAULT_RUNUP = {"C3": 6000, "C2": 6000, "C1": 4000, "C4": 6000}
+DEFAULT_RUNUP = {"C3": 6000, "C2": 6000, "C1": 4000, "C4": 6000, "C5": 6000}
 
 
 def _dist_env():
@@ -135,6 +138,9 @@ def cpu_baseline(budget_s=24.0):
         rate1, rates1 = _median_rate(ref_run(1, 1))
         legs["reference"]["one_thread"] = {"value": rate1, "runs": rates1, "steps_per_run": 1}
     kind = "reference" if "reference" in legs else "port"
+    out["reference_binary_present"] = "reference" in legs      # oracle/_ref/sph_ref travels in the snapshot (git-ignored)
+    if "reference" not in legs:
+        print("[bench] cpu_baseline: oracle/_ref/sph_ref is absent -- reporting the C restatement (kind 'port')", file=sys.stderr)
     out.update(value=legs[kind]["value"], cores=legs[kind]["cores"], kind=kind,
                one_thread=legs[kind]["one_thread"]["value"])
     out.update(legs)
@@ -177,18 +183,21 @@ def run_single(args):
     while left > 0:                                       # in pieces: a progress line per piece on stderr
         k = min(left - tail, 2000) if left > tail else left
         if left == tail:
-            q0 = ctx.sort_stats()
+            q0 = ctx.sort_stats()                         # (synchronises the stream)
+            t_tail = time.perf_counter()
         ctx.step(dt, k); ctx.sync()
         left -= k
         print(f"[bench] run-up {args.runup - left}/{args.runup} steps, {time.perf_counter() - t0:.1f} s", file=sys.stderr,
               flush=True)
     res["runup_s"] = time.perf_counter() - t0
     if args.runup:
+        tail_wall = time.perf_counter() - t_tail          # the last `tail` run-up steps, between two device syncs
         q1 = ctx.sort_stats()
         res["runup_tail"] = {"steps": tail, "movers_per_step": (q1["movers_total"] - q0["movers_total"]) / max(tail, 1),
-                             "skips": q1["skips"] - q0["skips"]}
+                             "skips": q1["skips"] - q0["skips"], "wall_s": tail_wall,
+                             "ms_per_step": tail_wall / max(tail, 1) * 1e3}
     else:
-        res["runup_tail"] = {"steps": 0, "movers_per_step": 0.0, "skips": 0}
+        res["runup_tail"] = {"steps": 0, "movers_per_step": 0.0, "skips": 0, "wall_s": 0.0, "ms_per_step": None}
 
     # ---- the headline: W warm-up + K timed steps of the flowing dam ------------------------------------------------
     ctx.step(dt, args.warmup)
@@ -233,22 +242,30 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--runup", type=int, default=None,
                     help="steps of state preparation before the warm-up (default: 6000 for C3 -- a flowing dam)")
-    ap.add_argument("--workload", default="C3", choices=sorted(ic.CONFIGS) + ["C4"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="--gpus N > 1: weak = 16.7 M particles per GPU; strong = BASELINE config 4 (67,108,864 in total)")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+    ap.add_argument("--workload", default="C3", choices=sorted(ic.CONFIGS))
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="--gpus N > 1: strong (default) = the SAME particles on every N -- BASELINE's metric is 'dam-break 16M "
+                         "particles, 1/2/4/8 MI355X', i.e. --workload C3 (--workload C4 = config 4, 67,108,864 particles); "
+                         "weak = 16.7 M particles PER GPU")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host", "local"],
                     help="--gpus N > 1: rccl = the library's own RCCL communicator (one rank per GPU); host = host-staged "
-                         "messages over gloo (rehearsal: several ranks on one GPU)")
+                         "messages (processes over gloo, or threads); local = device-to-device copies between the streams of "
+                         "one process (--one-gpu without a launcher)")
+    ap.add_argument("--lattice", default=None, help="slab path: nx,ny,nz instead of the workload's lattice (e.g. one rank's "
+                                                    "eighth of C3: --force-slab --lattice 256,256,32)")
+    ap.add_argument("--rebalance-every", type=int, default=500, help="slab path: re-balancing check every so many run-up steps")
     ap.add_argument("--precision", default="f32", choices=["f32", "mixed"],
                     help="mixed = BASELINE config 5's arithmetic (fp32 state, packed-fp16 pair arithmetic and per-row sums in "
                          "the density pass): a separate dtype line, never the fp32 headline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
     ap.add_argument("--one-gpu", action="store_true",
-                    help="rehearsal of the multi-rank path on a one-GPU box: every rank uses device 0 (needs --transport host)")
+                    help="rehearsal of the multi-rank path on a one-GPU box: every rank uses device 0.  Without a launcher the "
+                         "N ranks are N THREADS of this process (--transport local or host; a GPU box admits at most 6 "
+                         "processes on its card); under torch.distributed.run they are processes (--transport host)")
     args = ap.parse_args()
     rank, world, local = _dist_env()
-    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ and not args.one_gpu:
         # called without a launcher: start one rank per GPU as child processes (nothing has touched the GPU yet)
         import subprocess
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -267,13 +284,20 @@ def main():
     value = n * args.steps / r["wall"]
     t_force, t_dens, t_sort = phases_ms["force"] * 1e-3, phases_ms["dens"] * 1e-3, phases_ms["sort"] * 1e-3
     achieved = BYTES_PER_PARTICLE["force_fused"] * n / t_force / 1e9
-    traffic = None
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the one
+    # profiles/collect_pmc.sh measured for the same workload and state (separate rocprofv3 --pmc passes), and
+    # `traffic_source` says so -- it is NOT a measurement of this run
+    traffic, traffic_source = None, None
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
             pj = json.load(open(prof))
             if pj.get("workload") == args.workload and pj.get("state") == "flow":
                 traffic = pj.get("force_fused_hbm_bytes_per_launch")
+                traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  f"profiles/collect_pmc.sh ({pj.get('collected', 'date not recorded')}), FETCH_SIZE x 2 + "
+                                  "WRITE_SIZE per the gfx950 correction; a constant of an earlier run of this command, not "
+                                  "of this process")
         except Exception:
             traffic = None
     # a flowing state: no sort of the timed window was skipped, particles changed cell in it, and over the last 1000
@@ -284,7 +308,8 @@ def main():
     out = {
         "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["wall"] / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # the N = 1 point of the strong-scaling series BASELINE's metric names (the same 16.7 M particles on 1/2/4/8 GPUs)
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32" if args.precision == "f32" else "f32 state + packed-f16 density pairs (config 5)", "data": "synthetic",
         "config": {"workload": f"dam-break {args.workload}: {cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} "
                                f"= {n} particles, grid {cfg['grid'][0]}^3, box {cfg['box'][0]}, dt 5e-7, jittered lattice"
@@ -295,6 +320,7 @@ def main():
                    "runup_last_1000_steps": r["runup_tail"]},
         "roofline": {"bound": "hbm", "kernel": "k_force<force+collision+integrate>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_source,
                      "algorithmic_bytes_per_particle": BYTES_PER_PARTICLE["force_fused"],
                      "avg_launch_ms": phases_ms["force"],
                      "valu": {"flop_per_particle": FLOP_PER_PARTICLE["force_fused"],
@@ -308,6 +334,10 @@ def main():
                      "sort_phase": {"achieved": BYTES_PER_PARTICLE["sort_merge"] * n / max(t_sort, 1e-9) / 1e9,
                                     "unit": "GB/s", "avg_ms": phases_ms["sort"],
                                     "frac": BYTES_PER_PARTICLE["sort_merge"] * n / max(t_sort, 1e-9) / 1e9 / HBM_PEAK_GBS}},
+        # the sustained figure of the regime: the last 1000 run-up steps between two device syncs (cell changes come
+        # in bursts -- whole lattice layers cross a face together -- and a 100-step window can sit in a lull)
+        "value_sustained": (n * r["runup_tail"]["steps"] / r["runup_tail"]["wall_s"]) if r["runup_tail"]["wall_s"] else None,
+        "ms_per_step_sustained": r["runup_tail"]["ms_per_step"],
         "phases_ms": phases_ms, "sort": r["sort"], "flowing": flow_ok, "finite": r["finite"], "vmax": r["vmax"],
         "value_full_sort": n * args.steps / r["wall_full_sort"],
         "ms_per_step_full_sort": r["wall_full_sort"] / args.steps * 1e3, "phases_ms_full_sort": r["phases_ms_full_sort"],

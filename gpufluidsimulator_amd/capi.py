@@ -117,6 +117,13 @@ SIGNATURES = {
     "sph_slab_step": (C.c_int, [_P, C.c_float, _U32]),
     "sph_slab_sync": (C.c_int, [_P]),
     "sph_slab_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "sph_slab_counters": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "sph_slab_set_wait_timeout": (C.c_int, [_P, C.c_double]),
+    "sph_local_hub_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
+    "sph_local_hub_destroy": (None, [_P]),
+    "sph_local_hub_set_timeout": (C.c_int, [_P, C.c_double]),
+    "sph_local_transport_create": (C.c_int, [C.POINTER(C.POINTER(Transport)), _P, C.c_int]),
+    "sph_local_transport_destroy": (None, [C.POINTER(Transport)]),
     # include/particleSystem.h: host-only twins of ic.py (used by the C++ class's reset())
     "sph_ic_dam_break": (None, [C.POINTER(_U32), C.POINTER(C.c_float), C.c_int, C.c_uint64, C.c_uint64, _P, _P]),
     "sph_ic_random_box": (None, [C.c_uint64, C.POINTER(C.c_float), C.c_float, _U32, C.c_float, _P, _P]),
@@ -168,6 +175,27 @@ def device_count():
     flag = C.c_int(0)
     n = load().sph_device_count(C.byref(flag))
     return n, bool(flag.value)
+
+
+class LocalHub:
+    """`sph_local_hub`: the rendezvous of the device-to-device transport between slabs of one process (one GPU)."""
+
+    def __init__(self, world, device=0, timeout_s=None):
+        h = _P()
+        _check(load().sph_local_hub_create(C.byref(h), int(world), int(device)))
+        self.h = h
+        if timeout_s:
+            _check(load().sph_local_hub_set_timeout(self.h, float(timeout_s)))
+
+    def transport(self, rank):
+        t = C.POINTER(Transport)()
+        _check(load().sph_local_transport_create(C.byref(t), self.h, int(rank)))
+        return t
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().sph_local_hub_destroy(self.h)
+            self.h = None
 
 
 def _f32(a, cols):

@@ -102,7 +102,7 @@ static int dev_alloc(T** p, size_t count) {
 static void free_all(sph_ctx* c) {
     hipFree(c->posi); hipFree(c->velr); hipFree(c->posi2); hipFree(c->velr2); hipFree(c->keyS); hipFree(c->dp);
     hipFree(c->fpress); hipFree(c->fvisc); hipFree(c->dvel); hipFree(c->pos_out); hipFree(c->cells_base);
-    hipFree(c->k0); hipFree(c->v0); hipFree(c->k1); hipFree(c->v1); hipFree(c->os_hist); hipFree(c->os_base); hipFree(c->os_tickets); hipFree(c->os_tot); hipFree(c->os_status); hipFree(c->os_status32); hipFree(c->keyS2); hipFree(c->mm_tileL);
+    hipFree(c->k0); hipFree(c->v0); hipFree(c->k1); hipFree(c->v1); hipFree(c->os_hist); hipFree(c->os_base); hipFree(c->os_tickets); hipFree(c->os_tot); hipFree(c->os_status); hipFree(c->os_status32); hipFree(c->keyS2); hipFree(c->mm_tileL); hipFree(c->mm_tileA);
     if (c->os_err_host) hipHostFree(c->os_err_host);
     hipFree(c->d_scratch);
     hipFree(c->mm_mask); hipFree(c->mm_M64); hipFree(c->mm_tile_cnt); hipFree(c->mm_tile_off);
@@ -171,6 +171,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (!rc) rc = dev_alloc(&c->os_status, (size_t)512 * c->sort_blocks_cap);
     if (!rc) rc = dev_alloc(&c->os_status32, (size_t)512 * c->sort_blocks_cap);
     if (!rc) rc = dev_alloc(&c->mm_tileL, (size_t)c->sort_blocks_cap + 2);
+    if (!rc) rc = dev_alloc(&c->mm_tileA, (size_t)c->sort_blocks_cap + 2);
     if (!rc && (hipHostMalloc((void**)&c->os_err_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
                 hipHostGetDevicePointer((void**)&c->os_err_dev, c->os_err_host, 0) != hipSuccess)) {
         set_error("hipHostMalloc(mapped) failed");

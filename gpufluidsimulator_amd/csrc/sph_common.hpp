@@ -129,6 +129,7 @@ struct sph_ctx {
     bool mm_marked = false;
     bool mm_scanned = false;        // ... and the scan that counts them is already queued (mm_scan_marks)
     uint32_t* mm_tileL = nullptr;   // coarse mover ranks per 4096 slots (k_mm_tile_rank)
+    uint32_t* mm_tileA = nullptr;   // first key of every 4096-slot tile of the old order (k_mm_tile_rank)
     uint32_t mm_marked_off = 0, mm_marked_n = 0;
     uint32_t* d_scratch = nullptr;  // small device scratch (counts)
     uint32_t* h_scratch = nullptr;  // pinned host mirror
@@ -174,11 +175,17 @@ int launch_merge_arrivals(sph_ctx* c, uint32_t n_in);   // particles appended be
 int launch_cells_clear(sph_ctx* c);
 int launch_cells_clear_range(sph_ctx* c, uint32_t lo, uint32_t hi);
 int launch_cells_build_range(sph_ctx* c, uint32_t lo, uint32_t hi);
+int launch_cells_clear_2ranges(sph_ctx* c, uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1);
+int launch_cells_build_2ranges(sph_ctx* c, uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1);
 int launch_cells_build(sph_ctx* c);
 int launch_density(sph_ctx* c);
 int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt);
 // sub-range forms for the slab driver (interior first, boundary layers once the ghosts are in)
 int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi);
+int launch_density_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi);   // [lo, hi) minus the hole
+int launch_density_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count);            // range in device memory
+int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi, bool force, bool collide,
+                      bool integrate, float dt, bool mark);
 bool force_begin(sph_ctx* c, bool integrate);
 int launch_force_range(sph_ctx* c, uint32_t lo, uint32_t hi, bool force, bool collide, bool integrate, float dt, bool mark);
 void force_finish(sph_ctx* c, bool integrate, bool mark);

@@ -51,6 +51,48 @@ __global__ __launch_bounds__(256) void k_cells_build(const uint32_t* __restrict_
     if (s + 1 == hi || key[s + 1] != k) cells[k].y = s + 1;
 }
 
+// the same two kernels over TWO slot ranges in one launch (a slab's two ghost ranges, the leavers at both ends)
+__global__ __launch_bounds__(256) void k_cells_clear2(const uint32_t* __restrict__ key, uint32_t lo0, uint32_t hi0,
+                                                      uint32_t lo1, uint32_t hi1, uint2* __restrict__ cells) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, n0 = hi0 - lo0;
+    const uint32_t lo = t < n0 ? lo0 : lo1, hi = t < n0 ? hi0 : hi1;
+    const uint32_t s = t < n0 ? lo0 + t : lo1 + (t - n0);
+    if (s >= hi) return;
+    const uint32_t k = key[s];
+    if (s == lo || key[s - 1] != k) cells[k] = make_uint2(0u, 0u);
+}
+
+__global__ __launch_bounds__(256) void k_cells_build2(const uint32_t* __restrict__ key, uint32_t lo0, uint32_t hi0,
+                                                      uint32_t lo1, uint32_t hi1, uint2* __restrict__ cells) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, n0 = hi0 - lo0;
+    const uint32_t lo = t < n0 ? lo0 : lo1, hi = t < n0 ? hi0 : hi1;
+    const uint32_t s = t < n0 ? lo0 + t : lo1 + (t - n0);
+    if (s >= hi) return;
+    const uint32_t k = key[s];
+    if (s == lo || key[s - 1] != k) cells[k].x = s;
+    if (s + 1 == hi || key[s + 1] != k) cells[k].y = s + 1;
+}
+
+int launch_cells_clear_2ranges(sph_ctx* c, uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1) {
+    if (hi0 < lo0) hi0 = lo0;
+    if (hi1 < lo1) hi1 = lo1;
+    const uint32_t tot = (hi0 - lo0) + (hi1 - lo1);
+    if (!tot) return SPH_OK;
+    hipLaunchKernelGGL(k_cells_clear2, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, c->keyS, lo0, hi0, lo1, hi1, c->cells);
+    SPH_HIP(hipGetLastError());
+    return SPH_OK;
+}
+
+int launch_cells_build_2ranges(sph_ctx* c, uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1) {
+    if (hi0 < lo0) hi0 = lo0;
+    if (hi1 < lo1) hi1 = lo1;
+    const uint32_t tot = (hi0 - lo0) + (hi1 - lo1);
+    if (!tot) return SPH_OK;
+    hipLaunchKernelGGL(k_cells_build2, dim3(ceil_div(tot, 256)), dim3(256), 0, c->stream, c->keyS, lo0, hi0, lo1, hi1, c->cells);
+    SPH_HIP(hipGetLastError());
+    return SPH_OK;
+}
+
 int launch_cells_clear(sph_ctx* c) {
     if (!c->cells_valid || c->cells_hi <= c->cells_lo) { c->cells_valid = false; return SPH_OK; }
     hipLaunchKernelGGL(k_cells_clear, dim3(ceil_div(c->cells_hi - c->cells_lo, 256)), dim3(256), 0, c->stream, c->keyS,
@@ -81,8 +123,7 @@ int launch_cells_build(sph_ctx* c) {
     if (c->cells_valid && c->cells_lo == c->own_off && c->cells_hi == c->own_off + c->n) {
         // the sort's reorder pass built the owned cells; ghost layers hold no owned particle, so their
         // cells are disjoint from those: add them from the two ghost ranges only
-        rc = launch_cells_build_range(c, lo, c->own_off);
-        if (!rc) rc = launch_cells_build_range(c, c->own_off + c->n, hi);
+        rc = launch_cells_build_2ranges(c, lo, c->own_off, c->own_off + c->n, hi);
     } else {
         rc = launch_cells_clear(c);      // a table over another slot set, if any
         if (!rc) rc = launch_cells_build_range(c, lo, hi);
@@ -234,14 +275,36 @@ __device__ __forceinline__ void traverse(const Hulls& H, Load&& load, Store&& st
     }
 }
 
+// Which slots a launch of a pair kernel works on: [lo, hi) minus the hole [gap_lo, gap_lo + gap_len) -- thread t takes
+// slot lo + t, shifted up by gap_len from gap_lo on, so ONE launch covers a slab's two boundary layers (the hole is
+// its interior) or its interior around the part that was computed earlier.  gap_lo - lo is a multiple of 64: a wave
+// never straddles the hole (its lanes stay 64 consecutive slots).  dev != null: {lo, hi} come from device memory
+// (the slab step queues the density of its deep interior BEFORE the host knows the layer bounds, csrc/sph_slab.hip);
+// the grid is then an upper bound and waves beyond hi leave at once.
+struct Targets {
+    uint32_t lo, hi, gap_lo, gap_len;
+    const uint32_t* dev;
+};
+
+__device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, uint32_t lane, uint32_t& i, uint32_t& hi,
+                                             uint32_t& first) {
+    uint32_t lo = T.lo;
+    hi = T.hi;
+    if (T.dev) { lo = T.dev[0]; hi = T.dev[1]; }          // wave-uniform (scalar loads)
+    first = lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE;
+    if (first >= T.gap_lo) first += T.gap_len;
+    i = first + lane;
+    return first < hi;
+}
+
 // ---- density + pressure (kernelComputeDensities, particleSystem.cu:132-187) ---------------------------
 // rho_i = sum_{j in 27 cells, r2 < h2} m * POLY6 * (h2 - r2)^3   (self included)   (.cu:28-37)
 // p_i   = max(0, k * (rho_i - rho0))                                              (.cu:15-17)
 __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const float4* __restrict__ posi,
                                                                         const uint32_t* __restrict__ keyS,
                                                                         const uint2* __restrict__ cells,
-                                                                        float2* __restrict__ dp, uint32_t tgt_lo,
-                                                                        uint32_t tgt_hi, GridDesc g, Phys ph) {
+                                                                        float2* __restrict__ dp, Targets tg,
+                                                                        GridDesc g, Phys ph) {
     __shared__ float2 s_xy[LDS_ENT];
     __shared__ float s_z[LDS_ENT];
     for (uint32_t k = threadIdx.x; k < LDS_ENT; k += PAIR_THREADS) {   // see LDS_ENT: keep over-reads finite
@@ -251,7 +314,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slice = wave * PIECE;
-    const uint32_t i = tgt_lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE + lane;
+    uint32_t i, tgt_hi, wave_first;
+    if (!wave_targets(tg, wave, lane, i, tgt_hi, wave_first)) return;      // wave-uniform; no barrier below
     const bool active = i < tgt_hi;
     const uint32_t ii = active ? i : tgt_hi - 1;
     const float4 pi = posi[ii];
@@ -356,8 +420,8 @@ __device__ __forceinline__ PairWalk pair_walk(uint32_t slice_pairs, uint32_t l0,
 __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const float4* __restrict__ posi,
                                                                           const uint32_t* __restrict__ keyS,
                                                                           const uint2* __restrict__ cells,
-                                                                          float2* __restrict__ dp, uint32_t tgt_lo,
-                                                                          uint32_t tgt_hi, GridDesc g, Phys ph) {
+                                                                          float2* __restrict__ dp, Targets tg,
+                                                                          GridDesc g, Phys ph) {
     struct XY { h2 x, y; };                                   // 8 bytes: one ds_read_b64 per pair
     __shared__ XY s_xy[2 * LDS_PAIRS];
     __shared__ h2 s_z[2 * LDS_PAIRS];
@@ -368,7 +432,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slice = wave * HPAIRS;
-    const uint32_t i = tgt_lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE + lane;
+    uint32_t i, tgt_hi, wave_first;
+    if (!wave_targets(tg, wave, lane, i, tgt_hi, wave_first)) return;      // wave-uniform; no barrier below
     const bool active = i < tgt_hi;
     const uint32_t ii = active ? i : tgt_hi - 1;
     const float4 pi = posi[ii];
@@ -495,7 +560,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     const uint32_t* __restrict__ keyS, const uint2* __restrict__ cells, float4* __restrict__ fpress,
     float4* __restrict__ fvisc, float4* __restrict__ dvel, float4* __restrict__ posi_out,
     float4* __restrict__ velr_out, float4* __restrict__ pos_by_index, uint32_t* __restrict__ keys_out,
-    uint64_t* __restrict__ mm_mask, uint32_t* __restrict__ mm_tile_cnt, uint32_t tgt_lo, uint32_t tgt_hi,
+    uint64_t* __restrict__ mm_mask, uint32_t* __restrict__ mm_tile_cnt, Targets tg,
     uint32_t slot0, float dt, GridDesc g, Phys ph) {
     // One candidate = 4 float2 {x,y} {z,vx} {vy,vz} {cp,w} at a 40-byte stride (5 float2, the fifth is
     // padding): one address register serves all four ds_read_b64 through immediate offsets, and the
@@ -507,7 +572,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slice = wave * PIECE;
-    const uint32_t i = tgt_lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE + lane;
+    uint32_t i, tgt_hi, wave_first;
+    if (!wave_targets(tg, wave, lane, i, tgt_hi, wave_first)) return;      // wave-uniform; no barrier below
     const bool active = i < tgt_hi;
     const uint32_t ii = active ? i : tgt_hi - 1;
     float4 pi = posi[ii];
@@ -684,27 +750,47 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     }
     if (INTEG && mm_mask) {
         // movers of the next sort (sph_sort.hip: the merge path), one bit per slot: this wave IS one 64-slot chunk
-        // (a sub-range launch starts on a chunk boundary: tgt_lo - slot0 is a multiple of 64)
+        // (a sub-range launch starts on a chunk boundary: lo - slot0, gap_lo - lo and gap_len are multiples of 64)
         const uint64_t m = __ballot(moved);
-        const uint32_t wave_first = tgt_lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE;
         const uint32_t chunk = (wave_first - slot0) >> 6;
-        if (lane == 0 && wave_first < tgt_hi) {
+        if (lane == 0) {
             mm_mask[chunk] = m;
             if (m) atomicAdd(&mm_tile_cnt[chunk / MM_TILE_CHUNKS], (uint32_t)__popcll(m));
         }
     }
 }
 
-// One launch of the pair kernel over the owned slots [lo, hi) (lo - own_off a multiple of 64).  The fused form
+// [lo, hi) minus the hole [hole_lo, hole_hi): the hole's start is rounded UP to a whole wave from lo (see Targets),
+// what is cut off the hole that way is simply computed by this launch as well.
+static Targets targets_with_hole(uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi, uint32_t& threads) {
+    Targets t{lo, hi, hi, 0u, nullptr};
+    threads = hi - lo;
+    if (hole_lo < lo) hole_lo = lo;
+    if (hole_hi > hi) hole_hi = hi;
+    if (hole_lo < hole_hi) {
+        const uint32_t g0 = lo + ((hole_lo - lo + 63u) & ~63u);
+        if (g0 < hole_hi) { t.gap_lo = g0; t.gap_len = hole_hi - g0; threads -= t.gap_len; }
+    }
+    return t;
+}
+
+// One launch of the pair kernel over the owned slots [lo, hi) minus the hole [hole_lo, hole_hi) (lo - own_off,
+// hole_lo - lo and the hole's length multiples of 64: a wave is one chunk of the mover marks).  The fused form
 // (integrate) writes the ping-pong arrays; force_finish() swaps them once every sub-range has been launched.
-int launch_force_range(sph_ctx* c, uint32_t lo, uint32_t hi, bool force, bool collide, bool integrate, float dt, bool mark) {
+int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi, bool force, bool collide,
+                      bool integrate, float dt, bool mark) {
     if (hi <= lo) return SPH_OK;
     SPH_REQUIRE(((lo - c->own_off) & 63u) == 0u, SPH_E_INVALID, "force sub-range does not start on a 64-slot chunk");
-    dim3 grid(ceil_div(hi - lo, PAIR_THREADS)), block(PAIR_THREADS);
+    uint32_t threads;
+    const Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
+    SPH_REQUIRE(tg.gap_len == 0u || (((tg.gap_lo - lo) | tg.gap_len) & 63u) == 0u || tg.gap_lo + tg.gap_len == hi, SPH_E_INVALID,
+                "force hole is not made of whole 64-slot chunks");
+    if (threads == 0) return SPH_OK;
+    dim3 grid(ceil_div(threads, PAIR_THREADS)), block(PAIR_THREADS);
 #define SPH_LAUNCH_FORCE(F, C, I)                                                                              \
     hipLaunchKernelGGL((k_force<F, C, I>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->keyS, c->cells, \
                        c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, c->k0,              \
-                       mark ? c->mm_mask : nullptr, c->mm_tile_cnt, lo, hi, c->own_off, dt, c->grid, c->phys)
+                       mark ? c->mm_mask : nullptr, c->mm_tile_cnt, tg, c->own_off, dt, c->grid, c->phys)
     if (force && collide && integrate) SPH_LAUNCH_FORCE(true, true, true);
     else if (force && !collide && !integrate) SPH_LAUNCH_FORCE(true, false, false);
     else if (!force && collide && !integrate) SPH_LAUNCH_FORCE(false, true, false);
@@ -715,6 +801,10 @@ int launch_force_range(sph_ctx* c, uint32_t lo, uint32_t hi, bool force, bool co
 #undef SPH_LAUNCH_FORCE
     SPH_HIP(hipGetLastError());
     return SPH_OK;
+}
+
+int launch_force_range(sph_ctx* c, uint32_t lo, uint32_t hi, bool force, bool collide, bool integrate, float dt, bool mark) {
+    return launch_force_hole(c, lo, hi, hi, hi, force, collide, integrate, dt, mark);
 }
 
 // the integrate epilogue marks the movers of the next sort; marks of an earlier launch that no sort
@@ -745,17 +835,33 @@ int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt)
     return SPH_OK;
 }
 
-// density over the owned slots [lo, hi)
-int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi) {
-    if (hi <= lo) return SPH_OK;
+static int launch_density_targets(sph_ctx* c, const Targets& tg, uint32_t threads) {
+    if (threads == 0) return SPH_OK;
     if (c->precision == SPH_PRECISION_MIXED_F16)
-        hipLaunchKernelGGL(k_density_h, dim3(ceil_div(hi - lo, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
-                           c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
+        hipLaunchKernelGGL(k_density_h, dim3(ceil_div(threads, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
+                           c->keyS, c->cells, c->dp, tg, c->grid, c->phys);
     else
-        hipLaunchKernelGGL(k_density, dim3(ceil_div(hi - lo, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
-                           c->keyS, c->cells, c->dp, lo, hi, c->grid, c->phys);
+        hipLaunchKernelGGL(k_density, dim3(ceil_div(threads, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
+                           c->keyS, c->cells, c->dp, tg, c->grid, c->phys);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
+}
+
+// density over the owned slots [lo, hi) minus the hole [hole_lo, hole_hi)
+int launch_density_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi) {
+    if (hi <= lo) return SPH_OK;
+    uint32_t threads;
+    const Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
+    return launch_density_targets(c, tg, threads);
+}
+
+int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi) { return launch_density_hole(c, lo, hi, hi, hi); }
+
+// density over the slots [range_dev[0], range_dev[1]) -- two words of DEVICE memory written by an earlier kernel of
+// the stream; at most max_count slots (sizes the grid; waves beyond the range leave at once)
+int launch_density_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count) {
+    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev};
+    return launch_density_targets(c, tg, max_count);
 }
 
 // ---- stand-alone integrate for the phase API --------------------------------------------------------------

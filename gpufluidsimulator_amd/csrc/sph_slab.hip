@@ -1,17 +1,23 @@
 // sph_slab.hip -- one time step of a z-slab with its two neighbours, under the C ABI (sph_slab_step).
 //
-// No counterpart in the reference (single GPU).  Round 1 drove this protocol from Python over
-// torch.distributed with three host round trips per step; here the whole step is queued by C++ on two HIP
-// streams with ONE host wait:
+// No counterpart in the reference (single GPU).  The whole step is queued by C++ on two HIP streams with ONE host
+// wait, and that wait is covered by device work:
 //
 //   main stream                                   comm stream (high priority)
 //   -----------                                   -----------
 //   hash + sort owned particles
-//   layer bounds (device), pack leavers+header -> exchange MIGRANTS (fixed size, counts in-band)
-//   ............ host waits here for {own bounds, neighbours' headers}: the only wait of the step ..........
-//   [arrivals: appended behind the sorted range and merged in as movers]
+//   k_slab_bounds_pack: layer bounds, leavers
+//     + header {#leavers, #boundary, #far}     -> exchange MIGRANTS (header + 255 inline records: 8 KB)
+//   density of the DEEP interior (layers >= 3        k_slab_post_headers: own bounds + the neighbours' headers
+//     from either cut; its slot range is read        into mapped host memory, then a sequence word
+//     from DEVICE memory: the host does not
+//     know the bounds yet)
+//   ............ host polls the sequence word (bounded): the only wait of the step, hidden behind the deep density ...
+//   [more than 255 leavers on a side: the rest of them in a second, exact-size message]
+//   [arrivals: merged into their boundary layer in place; a particle that crossed more than one layer ("far") sends
+//    the step through the pass over all particles instead]
 //   pack boundary layers                       -> exchange HALO A (positions, velocities; exact size)
-//   density of the INTERIOR layers                unpack ghosts, cell table of the ghost layers
+//   density of the rest of the interior           unpack ghosts + cell table of the ghost layers (one kernel)
 //   density of the two boundary layers  <-(event)
 //   pack (rho, p) of the boundary layers       -> exchange HALO B
 //   force+collision+integrate, interior           unpack ghost (rho, p)
@@ -20,18 +26,43 @@
 // The interior layers (all but the first and last owned layer) never look at a ghost, so their passes run while
 // the halos travel.  Messages go point to point to the two z-neighbours only: RCCL ncclSend/ncclRecv in one group
 // on the comm stream (sph_rccl_transport_create; over the direct xGMI link), or through a caller-supplied
-// transport (tests: host-staged, several slabs of one GPU or several processes over gloo).
+// transport (tests: host-staged -- several processes over gloo -- or device-to-device between the streams of one
+// process, sph_local_transport_create).
 #include "sph_device.hpp"
 #include <vector>
 
 #include <dlfcn.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstring>
 #include <new>
 
 namespace sph {
 
-// slot of the first key >= target, for 4 targets (one thread each): the layer bounds of the owned range
+// words of the pinned, mapped host block the step's one wait reads (sph_slab::h_lb)
+enum {
+    HL_LB = 0,        // [0..3] own layer bounds: first slot (relative to the owned range) with a key >= layer, 2*layer,
+                      //        (zl-2)*layer, (zl-1)*layer
+    HL_DEEP = 4,      // [4..5] the deep interior [first key >= 3*layer, first key >= (zl-3)*layer), ABSOLUTE slots
+    HL_FAR = 6,       // [6..7] my leavers (down, up) that are NOT in the neighbour's adjacent layer (crossed > 1 layer)
+    HL_HDR_LO = 8,    // [8..11]  header received from the lower neighbour {#arrivals, #its boundary layer, #far, 0}
+    HL_HDR_HI = 12,   // [12..15] ... from the upper neighbour
+    HL_SEQ = 16,      // written last: the step number
+    HL_ERR = 17,      // [17..18] sticky error words set by device-side checks (plain stores of 1): SLAB_ERR_*
+    HL_WORDS = 32
+};
+enum { SLAB_ERR_INSERT_LAYER = 0, SLAB_ERR_ARRIVAL_OUTSIDE = 1 };
+// device words (sph_slab::d_lb): [0..3] bounds, [4..5] deep range (absolute), [6..7] far counts, [8..10] the
+// fused kernel's block counters {far down, far up, blocks done}
+enum { DL_DEEP = 4, DL_FAR = 6, DL_CTR = 8, DL_WORDS = 16 };
+
+constexpr uint32_t MIG_INLINE = 255;   // leavers per side that ride in the first (fixed-size, 8 KB) migrant message
+
+// slot of the first key >= target, for 4 targets (one thread each): the layer bounds of the owned range (used
+// after the rare pass over all particles that takes in far arrivals)
 __global__ void k_slab_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t layer, uint32_t zl,
                               uint32_t* __restrict__ out, volatile uint32_t* __restrict__ out_host) {
     const uint32_t t = threadIdx.x;
@@ -46,49 +77,160 @@ __global__ void k_slab_bounds(const uint32_t* __restrict__ keys, uint32_t n, uin
     out_host[t] = lo;
 }
 
-// Leavers sit at the two ends of the sorted owned range: [0, lb0) go down, [lb3, n) go up.  Record 0 of a
-// message is the header {#leavers, #particles that stay in the boundary layer on that side}.
-__global__ __launch_bounds__(256) void k_slab_pack_migrants(const float4* __restrict__ posi, const float4* __restrict__ velr,
-                                                            uint32_t n, const uint32_t* __restrict__ lb, uint32_t cap,
-                                                            float4* __restrict__ out_lo, float4* __restrict__ out_hi) {
-    const uint32_t m_lo = lb[0], m_hi = n - lb[3];
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k == 0) {
-        out_lo[0] = make_float4(__uint_as_float(m_lo), __uint_as_float(lb[1] - lb[0]), 0.f, 0.f);
-        out_lo[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        out_hi[0] = make_float4(__uint_as_float(m_hi), __uint_as_float(lb[3] - lb[2]), 0.f, 0.f);
-        out_hi[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+// ONE kernel after the sort: every block finds the six layer bounds of the sorted owned keys (six threads, binary
+// searches over L2-resident lines: cheaper than a kernel boundary), then the blocks pack the leavers -- they sit at
+// the two ends of the sorted owned range, [0, lb0) go down, [lb3, n) go up -- and count the FAR ones: a leaver whose
+// true cell layer is not the neighbour's adjacent layer (it crossed more than one layer in a step; its key is clamped
+// into my ghost layer, so only its position can tell).  The block that finishes last writes record 0 of both
+// messages, the header {#leavers, #particles that stay in my boundary layer on that side, #far leavers, 0}, and the
+// device words the deep-interior density launch reads its slot range from.
+__global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __restrict__ keys, const float4* __restrict__ posi,
+                                                          const float4* __restrict__ velr, uint32_t n, uint32_t own_off,
+                                                          uint32_t layer, uint32_t cap, GridDesc g,
+                                                          uint32_t* __restrict__ dl, float4* __restrict__ out_lo,
+                                                          float4* __restrict__ out_hi) {
+    __shared__ uint32_t s_lb[6];
+    __shared__ uint32_t s_last;
+    const uint32_t zl = g.zl;
+    if (threadIdx.x < 6) {
+        // deep interior = local layers [3, zl-3); empty for slabs of fewer than 5 owned layers
+        const uint32_t d0 = min(3u, zl - 1u), d1 = zl >= 6u ? zl - 3u : d0;
+        const uint32_t targets[6] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer, d0 * layer, max(d1, d0) * layer};
+        const uint32_t v = targets[threadIdx.x];
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (keys[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        s_lb[threadIdx.x] = lo;
     }
-    if (k < m_lo && k < cap) { out_lo[2 + 2 * k] = posi[k]; out_lo[3 + 2 * k] = velr[k]; }
-    if (k < m_hi && k < cap) { out_hi[2 + 2 * k] = posi[lb[3] + k]; out_hi[3 + 2 * k] = velr[lb[3] + k]; }
+    __syncthreads();
+    const uint32_t lb0 = s_lb[0], lb3 = s_lb[3];
+    const uint32_t m_lo = lb0, m_hi = n - lb3;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    bool far_l = false, far_h = false;
+    if (k < m_lo && k < cap) {
+        const float4 p = posi[k];
+        out_lo[2 + 2 * k] = p; out_lo[3 + 2 * k] = velr[k];
+        far_l = (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]) != g.z_off;              // global layer z_lo - 1
+    }
+    if (k < m_hi && k < cap) {
+        const float4 p = posi[lb3 + k];
+        out_hi[2 + 2 * k] = p; out_hi[3 + 2 * k] = velr[lb3 + k];
+        far_h = (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]) != g.z_off + (int)zl - 1;   // global layer z_hi
+    }
+    const uint64_t bl = __ballot(far_l), bh = __ballot(far_h);
+    if ((threadIdx.x & 63u) == 0) {
+        if (bl) atomicAdd(&dl[DL_CTR + 0], (uint32_t)__popcll(bl));
+        if (bh) atomicAdd(&dl[DL_CTR + 1], (uint32_t)__popcll(bh));
+    }
+    __threadfence();                       // the counts and the records before the ticket
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&dl[DL_CTR + 2], 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    const uint32_t far_lo = atomicExch(&dl[DL_CTR + 0], 0u), far_hi = atomicExch(&dl[DL_CTR + 1], 0u);
+    atomicExch(&dl[DL_CTR + 2], 0u);                                                   // re-armed for the next step
+    out_lo[0] = make_float4(__uint_as_float(m_lo), __uint_as_float(s_lb[1] - lb0), __uint_as_float(far_lo), 0.f);
+    out_lo[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    out_hi[0] = make_float4(__uint_as_float(m_hi), __uint_as_float(lb3 - s_lb[2]), __uint_as_float(far_hi), 0.f);
+    out_hi[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < 4; t++) dl[t] = s_lb[t];
+    dl[DL_DEEP] = own_off + s_lb[4];
+    dl[DL_DEEP + 1] = own_off + max(s_lb[5], s_lb[4]);
+    dl[DL_FAR] = far_lo; dl[DL_FAR + 1] = far_hi;
 }
 
-__global__ __launch_bounds__(256) void k_slab_pack(const float4* __restrict__ posi, const float4* __restrict__ velr,
-                                                   uint32_t n, float4* __restrict__ rec) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+// comm stream, right behind the migrant exchange: everything the host's one wait needs, in one mapped block, the
+// sequence word last (a system-scope fence in between: the host polls that word and then reads the rest)
+__global__ void k_slab_post_headers(const uint32_t* __restrict__ dl, const float4* __restrict__ hdr_lo,
+                                    const float4* __restrict__ hdr_hi, volatile uint32_t* __restrict__ host, uint32_t seq) {
+    if (threadIdx.x != 0) return;
+    for (int t = 0; t < 8; t++) host[t] = dl[t];
+    for (int side = 0; side < 2; side++) {
+        const float4* h = side == 0 ? hdr_lo : hdr_hi;
+        const float4 v = h ? h[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        volatile uint32_t* o = host + (side == 0 ? HL_HDR_LO : HL_HDR_HI);
+        o[0] = __float_as_uint(v.x); o[1] = __float_as_uint(v.y); o[2] = __float_as_uint(v.z); o[3] = 0u;
+    }
+    __threadfence_system();
+    host[HL_SEQ] = seq;
+}
+
+// both boundary layers -> their halo messages, one launch
+__global__ __launch_bounds__(256) void k_slab_pack2(const float4* __restrict__ posi, const float4* __restrict__ velr,
+                                                    uint32_t first_lo, uint32_t n_lo, uint32_t first_hi, uint32_t n_hi,
+                                                    float4* __restrict__ rec_lo, float4* __restrict__ rec_hi) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n_lo) { rec_lo[2 * t] = posi[first_lo + t]; rec_lo[2 * t + 1] = velr[first_lo + t]; }
+    else if (t - n_lo < n_hi) {
+        const uint32_t i = t - n_lo;
+        rec_hi[2 * i] = posi[first_hi + i]; rec_hi[2 * i + 1] = velr[first_hi + i];
+    }
+}
+
+// (density, pressure) of both boundary layers -> messages, and of both ghost layers <- messages: one launch each
+__global__ __launch_bounds__(256) void k_slab_copy_dp2(const float2* __restrict__ src_lo, float2* __restrict__ dst_lo,
+                                                       uint32_t n_lo, const float2* __restrict__ src_hi,
+                                                       float2* __restrict__ dst_hi, uint32_t n_hi) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n_lo) dst_lo[t] = src_lo[t];
+    else if (t - n_lo < n_hi) dst_hi[t - n_lo] = src_hi[t - n_lo];
+}
+
+// Ghost records of both sides -> the slots in front of / behind the owned range, with their cell keys, AND the cell
+// table entries of the two ghost layers, in one launch: a thread recomputes the keys of its two neighbours from
+// their records instead of reading them back (boundary flags as in k_cells_build; the records are in key order).
+__global__ __launch_bounds__(256) void k_slab_unpack_ghosts(const float4* __restrict__ rec_lo, uint32_t n_lo, uint32_t slot_lo,
+                                                            const float4* __restrict__ rec_hi, uint32_t n_hi, uint32_t slot_hi,
+                                                            float4* __restrict__ posi, float4* __restrict__ velr,
+                                                            uint32_t* __restrict__ key, uint2* __restrict__ cells, GridDesc g) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const bool low = t < n_lo;
+    const uint32_t i = low ? t : t - n_lo, n = low ? n_lo : n_hi;
     if (i >= n) return;
-    rec[2 * i] = posi[i];
-    rec[2 * i + 1] = velr[i];
+    const float4* rec = low ? rec_lo : rec_hi;
+    const uint32_t s = (low ? slot_lo : slot_hi) + i;
+    const float4 p = rec[2 * i];
+    const uint32_t k = cell_key(g, p.x, p.y, p.z);
+    posi[s] = p;
+    velr[s] = rec[2 * i + 1];
+    key[s] = k;
+    bool first = i == 0, last = i + 1 == n;
+    if (!first) { const float4 q = rec[2 * (i - 1)]; first = cell_key(g, q.x, q.y, q.z) != k; }
+    if (!last) { const float4 q = rec[2 * (i + 1)]; last = cell_key(g, q.x, q.y, q.z) != k; }
+    if (first) cells[k].x = s;
+    if (last) cells[k].y = s + 1;
 }
 
+// arrivals appended behind the owned range for the pass over all particles (launch_merge_arrivals): any owned layer
+// is fine there, but a particle that is not inside this slab at all cannot be represented (its key is clamped into a
+// ghost layer): flagged, the step reports SPH_E_STATE
 __global__ __launch_bounds__(256) void k_slab_unpack(const float4* __restrict__ rec, uint32_t n, float4* __restrict__ posi,
-                                                     float4* __restrict__ velr, uint32_t* __restrict__ key, GridDesc g) {
+                                                     float4* __restrict__ velr, uint32_t* __restrict__ key, GridDesc g,
+                                                     volatile uint32_t* __restrict__ err_host) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float4 p = rec[2 * i];
     posi[i] = p;
     velr[i] = rec[2 * i + 1];
-    if (key) key[i] = cell_key(g, p.x, p.y, p.z);
+    const uint32_t k = cell_key(g, p.x, p.y, p.z);
+    if (key) key[i] = k;
+    const uint32_t lz = k / (g.g[0] * g.g[1]);
+    if (lz == 0u || lz + 1u >= g.zl) err_host[SLAB_ERR_ARRIVAL_OUTSIDE] = 1u;
 }
 
 // Arrivals join a BOUNDARY LAYER in place.  A particle a neighbour sent lies in the cell layer next to the cut it
-// crossed, i.e. in the first or the last layer of the sorted owned range; the space in front of / behind the owned
-// range is free (the ghosts of the last step are gone, those of this step have not come yet).  So only that layer is
-// re-merged: the layer's nl particles and the k arrivals go, in key order (equal keys: residents first, arrivals in
-// arrival order -- the order the full stable sort of [owned, arrivals] would produce), to the slots [d0, d0 + nl + k)
-// of the scratch arrays, d0 = l0 - k on the low side and l0 on the high side, and are copied back; every other slot of
-// the 16.7 M stays where it is.  One thread per resident (counts the arrivals with a smaller key from LDS) and per
-// arrival (ranks itself among the arrivals, binary search among the residents).
+// crossed (the sender counted the exceptions -- "far" leavers -- into its header, and a step with any of those does
+// not come here), i.e. in the first or the last layer of the sorted owned range; the space in front of / behind the
+// owned range is free (the ghosts of the last step are gone, those of this step have not come yet).  So only that
+// layer is re-merged: the layer's nl particles and the k arrivals go, in key order (equal keys: residents first,
+// arrivals in arrival order -- the order the full stable sort of [owned, arrivals] would produce), to the slots
+// [d0, d0 + nl + k) of the scratch arrays, d0 = l0 - k on the low side and l0 on the high side, and are copied back;
+// every other slot stays where it is.  One thread per resident (counts the arrivals with a smaller key from LDS)
+// and per arrival (ranks itself among the arrivals, binary search among the residents).  An arrival whose key is
+// NOT in the expected layer would break the order: it is flagged (the step then fails with SPH_E_STATE).
 #ifndef SPH_SLAB_INSERT
 #define SPH_SLAB_INSERT 1            // 0: arrivals always take the pass over all particles (launch_merge_arrivals)
 #endif
@@ -97,11 +239,15 @@ __global__ __launch_bounds__(256) void k_slab_insert(const float4* __restrict__ 
                                                      const uint32_t* __restrict__ keyS, uint32_t l0, uint32_t nl,
                                                      const float4* __restrict__ rec, uint32_t k, GridDesc g,
                                                      float4* __restrict__ posi_o, float4* __restrict__ velr_o,
-                                                     uint32_t* __restrict__ key_o, uint32_t d0) {
+                                                     uint32_t* __restrict__ key_o, uint32_t d0, uint32_t want_layer,
+                                                     volatile uint32_t* __restrict__ err_host) {
     __shared__ uint32_t s_ak[SLAB_INSERT_MAX];
+    const uint32_t layer = g.g[0] * g.g[1];
     for (uint32_t r = threadIdx.x; r < k; r += 256u) {
         const float4 p = rec[2 * r];
-        s_ak[r] = cell_key(g, p.x, p.y, p.z);
+        const uint32_t key = cell_key(g, p.x, p.y, p.z);
+        s_ak[r] = key;
+        if (blockIdx.x == 0 && key / layer != want_layer) err_host[SLAB_ERR_INSERT_LAYER] = 1u;
     }
     __syncthreads();
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -127,6 +273,18 @@ __global__ __launch_bounds__(256) void k_slab_insert(const float4* __restrict__ 
         velr_o[dst] = rec[2 * r + 1];
         key_o[dst] = key;
     }
+}
+
+// the merged boundary layer back from the scratch arrays (one launch instead of three copies)
+__global__ __launch_bounds__(256) void k_slab_copy_back(const float4* __restrict__ p_src, const float4* __restrict__ v_src,
+                                                        const uint32_t* __restrict__ k_src, float4* __restrict__ p_dst,
+                                                        float4* __restrict__ v_dst, uint32_t* __restrict__ k_dst, uint32_t first,
+                                                        uint32_t count) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= count) return;
+    p_dst[first + t] = p_src[first + t];
+    v_dst[first + t] = v_src[first + t];
+    k_dst[first + t] = k_src[first + t];
 }
 
 }  // namespace sph
@@ -205,6 +363,101 @@ int rccl_exchange(void* self, int, const void* send_lo, size_t send_lo_bytes, vo
     return SPH_OK;
 }
 
+// ---- device-to-device transport between the slabs of ONE process (several ranks sharing one GPU, one thread each) ----
+// What RCCL does between GPUs, restated for ranks that share a device: the buffers are DEVICE pointers, the transfers
+// are queued on the caller's comm stream and nothing waits for them on the host -- so the step's stream/event edges
+// (after_main / after_comm, the ghost unpack on the comm stream, the (rho, p) copies) are exercised exactly as with
+// the product transport, which a host-staged test transport (it drains the comm stream inside every exchange) cannot
+// do.  Per directed link: the sender records an event behind the kernels that filled its buffer and posts {pointer,
+// size, tag}; the receiver makes its stream wait for that event, queues the copy, records a `done` event and marks the
+// post consumed; the sender then makes its own stream wait for `done` (its buffer is free again once the copy ran).
+// The host threads only rendezvous (mutex + condition variable, bounded waits); sizes and tags of both ends are
+// compared, so a disagreement is an error message instead of a hang.
+struct LocalLink {
+    uint64_t posted = 0, consumed = 0;
+    const void* ptr = nullptr;
+    size_t bytes = 0;
+    int tag = 0;
+    hipEvent_t ready = nullptr, done = nullptr;
+};
+
+}  // namespace
+
+struct sph_local_hub {
+    int world = 0;
+    double timeout_s = 120.0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<LocalLink> links;        // [2 r] = r -> r + 1, [2 r + 1] = r -> r - 1
+};
+
+namespace {
+
+struct LocalEnd { sph_local_hub* hub; int rank; };
+
+int local_exchange(void* self, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
+                   const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes, void* stream) {
+    LocalEnd* E = (LocalEnd*)self;
+    sph_local_hub* H = E->hub;
+    hipStream_t st = (hipStream_t)stream;
+    const int r = E->rank;
+    const bool lo = r > 0, hi = r + 1 < H->world;
+    LocalLink* out[2] = {lo ? &H->links[2 * r + 1] : nullptr, hi ? &H->links[2 * r] : nullptr};             // r -> r-1, r -> r+1
+    LocalLink* in[2] = {lo ? &H->links[2 * (r - 1)] : nullptr, hi ? &H->links[2 * (r + 1) + 1] : nullptr};   // r-1 -> r, r+1 -> r
+    const void* sp[2] = {send_lo, send_hi};
+    const size_t sb[2] = {lo ? send_lo_bytes : 0, hi ? send_hi_bytes : 0};
+    void* rp[2] = {recv_lo, recv_hi};
+    const size_t rb[2] = {lo ? recv_lo_bytes : 0, hi ? recv_hi_bytes : 0};
+    const auto limit = std::chrono::duration<double>(H->timeout_s);
+    for (int k = 0; k < 2; k++) {                       // post what I send
+        if (!sb[k]) continue;
+        SPH_HIP(hipEventRecord(out[k]->ready, st));
+        std::lock_guard<std::mutex> g(H->mu);
+        out[k]->ptr = sp[k]; out[k]->bytes = sb[k]; out[k]->tag = tag;
+        out[k]->posted++;
+        H->cv.notify_all();
+    }
+    for (int k = 0; k < 2; k++) {                       // take what the neighbours posted
+        if (!rb[k]) continue;
+        LocalLink* L = in[k];
+        const void* src; size_t bytes; int ptag;
+        {
+            std::unique_lock<std::mutex> g(H->mu);
+            if (!H->cv.wait_for(g, limit, [&] { return L->posted > L->consumed; })) {
+                set_error("local transport: rank %d waited %.0f s for a %zu-byte message (tag %d) its neighbour never sent", r,
+                          H->timeout_s, rb[k], tag);
+                return SPH_E_DEVICE;
+            }
+            src = L->ptr; bytes = L->bytes; ptag = L->tag;
+        }
+        if (bytes != rb[k] || ptag != tag) {
+            set_error("local transport: rank %d expects %zu bytes (tag %d) from its %s neighbour, which sent %zu (tag %d): the two "
+                      "ends of a link disagree on a message size", r, rb[k], tag, k == 0 ? "lower" : "upper", bytes, ptag);
+            return SPH_E_STATE;
+        }
+        SPH_HIP(hipStreamWaitEvent(st, L->ready, 0));
+        SPH_HIP(hipMemcpyAsync(rp[k], src, bytes, hipMemcpyDeviceToDevice, st));
+        SPH_HIP(hipEventRecord(L->done, st));
+        std::lock_guard<std::mutex> g(H->mu);
+        L->consumed++;
+        H->cv.notify_all();
+    }
+    for (int k = 0; k < 2; k++) {                       // my buffers are free once the neighbours' copies ran
+        if (!sb[k]) continue;
+        LocalLink* L = out[k];
+        {
+            std::unique_lock<std::mutex> g(H->mu);
+            if (!H->cv.wait_for(g, limit, [&] { return L->consumed == L->posted; })) {
+                set_error("local transport: rank %d waited %.0f s for its neighbour to take a %zu-byte message (tag %d)", r,
+                          H->timeout_s, sb[k], tag);
+                return SPH_E_DEVICE;
+            }
+        }
+        SPH_HIP(hipStreamWaitEvent(st, L->done, 0));
+    }
+    return SPH_OK;
+}
+
 }  // namespace
 
 struct sph_slab {
@@ -214,11 +467,14 @@ struct sph_slab {
     sph_transport tr{};
     bool host_staged = false;            // the transport wants host buffers (tests); else device pointers on the comm stream
     hipStream_t comm = nullptr;
-    hipEvent_t ev_main = nullptr, ev_comm = nullptr, ev_sync = nullptr;
+    hipEvent_t ev_main = nullptr, ev_comm = nullptr;
     uint32_t gcap = 0, mcap = 0;         // halo / migrant capacity per side, in records
-    uint32_t* d_lb = nullptr;            // 4 layer bounds of the owned range (device)
-    uint32_t* h_lb = nullptr;            // pinned: the same 4 + 2 x 4 header words received
+    uint32_t* d_lb = nullptr;            // DL_* words: layer bounds, deep-interior range, far counts, block counters (device)
+    volatile uint32_t* h_lb = nullptr;   // HL_* words (pinned, mapped): what the step's one wait reads
     uint32_t* h_lb_dev = nullptr;        // its device view
+    uint32_t seq = 0;                    // step number the device echoes into h_lb[HL_SEQ]
+    double wait_timeout_s = 120.0;       // bound of the poll (sph_slab_set_wait_timeout; SPH_SLAB_TIMEOUT_S)
+    int device = 0;                      // copied from the context: destroy does not touch it
     float4* mig_send[2] = {nullptr, nullptr};   // (1 + mcap) records of 2 float4
     float4* mig_recv[2] = {nullptr, nullptr};
     float4* halo_send[2] = {nullptr, nullptr};  // gcap records
@@ -228,7 +484,7 @@ struct sph_slab {
     char* stage_send[2] = {nullptr, nullptr};   // pinned staging for host-staged transports
     char* stage_recv[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
-    uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0, inserts = 0;
+    uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0, inserts = 0, far_steps = 0, rest_msgs = 0;
 };
 
 namespace {
@@ -242,10 +498,9 @@ void slab_free(sph_slab* s) {
         if (s->stage_recv[k]) hipHostFree(s->stage_recv[k]);
     }
     hipFree(s->d_lb);
-    if (s->h_lb) hipHostFree(s->h_lb);
+    if (s->h_lb) hipHostFree((void*)s->h_lb);
     if (s->ev_main) hipEventDestroy(s->ev_main);
     if (s->ev_comm) hipEventDestroy(s->ev_comm);
-    if (s->ev_sync) hipEventDestroy(s->ev_sync);
     if (s->comm) hipStreamDestroy(s->comm);
     delete s;
 }
@@ -287,53 +542,103 @@ int after_comm(sph_slab* s) {
     return SPH_OK;
 }
 
+// the step's one wait: poll the sequence word the comm stream writes behind the migrant exchange.  Polled, not slept
+// on (hipEventSynchronize hands the thread to the kernel and comes back tens of microseconds late); BOUNDED: a
+// neighbour that left its step with an error never sends, and this rank must report that instead of spinning forever.
+int slab_wait_headers(sph_slab* s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (s->h_lb[HL_SEQ] != s->seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0x3FFFu) == 0u) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > s->wait_timeout_s) {
+                set_error("rank %d: no migrant header after %.1f s (step %llu): a neighbour stopped, or the transport is stuck",
+                          s->rank, dt, (unsigned long long)s->steps);
+                return SPH_E_DEVICE;
+            }
+            hipError_t q = hipStreamQuery(s->comm);            // a device fault shows up here, not in the mapped word
+            if (q != hipSuccess && q != hipErrorNotReady) SPH_HIP(q);
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    s->host_waits++;
+    return SPH_OK;
+}
+
+int slab_check_device_flags(sph_slab* s) {
+    SPH_REQUIRE(s->h_lb[HL_ERR + SLAB_ERR_INSERT_LAYER] == 0u, SPH_E_STATE,
+                "rank %d: an arriving particle was not in the boundary layer next to the cut it crossed (the sorted order of "
+                "that layer is invalid)", s->rank);
+    SPH_REQUIRE(s->h_lb[HL_ERR + SLAB_ERR_ARRIVAL_OUTSIDE] == 0u, SPH_E_STATE,
+                "rank %d: an arriving particle lies outside this slab altogether (it crossed a whole slab in one step)", s->rank);
+    return SPH_OK;
+}
+
 int slab_step_once(sph_slab* s, float dt) {
     sph_ctx* c = s->c;
     int rc;
+    rc = slab_check_device_flags(s); if (rc) return rc;
     // ---- hash + sort the owned particles (leavers end up at the two ends of the owned range) -----------------------
     rc = step_hash(c); if (rc) return rc;
     rc = step_sort(c); if (rc) return rc;
     const uint32_t layer = c->grid.g[0] * c->grid.g[1];
-    const uint32_t n0 = c->n;
-    // ---- layer bounds on the device; leavers + header into the fixed-size migrant messages -----------------------
-    hipLaunchKernelGGL(k_slab_bounds, dim3(1), dim3(64), 0, c->stream, c->keyS + c->own_off, n0, layer, c->grid.zl, s->d_lb,
-                       s->h_lb_dev);
-    hipLaunchKernelGGL(k_slab_pack_migrants, dim3(ceil_div(s->mcap, 256u)), dim3(256), 0, c->stream, c->posi + c->own_off,
-                       c->velr + c->own_off, n0, s->d_lb, s->mcap, s->mig_send[0], s->mig_send[1]);
+    const uint32_t n0 = c->n, off0 = c->own_off;
+    const size_t rec = 2 * sizeof(float4);
+    // ---- layer bounds, leavers and headers in ONE kernel; the comm stream ships the fixed-size part ------------------
+    s->seq++;
+    hipLaunchKernelGGL(k_slab_bounds_pack, dim3(ceil_div(s->mcap, 256u)), dim3(256), 0, c->stream, c->keyS + off0, c->posi + off0,
+                       c->velr + off0, n0, off0, layer, s->mcap, c->grid, s->d_lb, s->mig_send[0], s->mig_send[1]);
     SPH_HIP(hipGetLastError());
     rc = after_main(s); if (rc) return rc;
-    const size_t mig_bytes = (size_t)(1 + s->mcap) * 2 * sizeof(float4);
+    // ---- the density of the deep interior goes into the main stream's queue BEFORE the host waits: its slot range
+    //      comes from device memory (k_slab_bounds_pack wrote it).  Layers >= 3 from either cut see neither ghosts nor
+    //      arrivals (those land in the boundary layers), and no slot of them moves before the force pass.
+    bool deep_valid = c->grid.zl >= 7u;
+    if (deep_valid) {
+        PhaseTimer t(c, SPH_PH_DENS);
+        rc = launch_density_dev_range(c, s->d_lb + DL_DEEP, n0);
+        if (rc) return rc;
+    }
+    const uint32_t inl = min(MIG_INLINE, s->mcap);
+    const size_t mig_bytes = (size_t)(1 + inl) * rec;
     rc = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
                        s->mig_recv[1], mig_bytes);
     if (rc) return rc;
-    if (s->has_lo) SPH_HIP(hipMemcpyAsync(s->h_lb + 4, s->mig_recv[0], 16, hipMemcpyDeviceToHost, s->comm));
-    if (s->has_hi) SPH_HIP(hipMemcpyAsync(s->h_lb + 8, s->mig_recv[1], 16, hipMemcpyDeviceToHost, s->comm));
-    SPH_HIP(hipEventRecord(s->ev_sync, s->comm));
-    // ---- the one host wait of the step: own bounds (written by k_slab_bounds before the comm stream started) and
-    //      the neighbours' headers -------------------------------------------------------------------------------
-    //      Polled, not slept on: hipEventSynchronize hands the thread to the kernel and comes back tens of
-    //      microseconds after the event -- with an empty queue behind it, that is device idle time.
-    {
-        hipError_t q;
-        while ((q = hipEventQuery(s->ev_sync)) == hipErrorNotReady) __builtin_ia32_pause();
-        SPH_HIP(q);
-    }
-    s->host_waits++;
-    const uint32_t lb0 = s->h_lb[0], lb1 = s->h_lb[1], lb2 = s->h_lb[2], lb3 = s->h_lb[3];
+    hipLaunchKernelGGL(k_slab_post_headers, dim3(1), dim3(64), 0, s->comm, s->d_lb, s->has_lo ? s->mig_recv[0] : (float4*)nullptr,
+                       s->has_hi ? s->mig_recv[1] : (float4*)nullptr, s->h_lb_dev, s->seq);
+    SPH_HIP(hipGetLastError());
+    // ---- the one host wait of the step ---------------------------------------------------------------------------
+    rc = slab_wait_headers(s); if (rc) return rc;
+    const uint32_t lb0 = s->h_lb[HL_LB], lb1 = s->h_lb[HL_LB + 1], lb2 = s->h_lb[HL_LB + 2], lb3 = s->h_lb[HL_LB + 3];
+    const uint32_t deep_lo = s->h_lb[HL_DEEP], deep_hi = s->h_lb[HL_DEEP + 1];
+    const uint32_t far_lo = s->has_lo ? s->h_lb[HL_FAR] : 0u, far_hi = s->has_hi ? s->h_lb[HL_FAR + 1] : 0u;
     const uint32_t m_lo = lb0, m_hi = n0 - lb3;
     uint32_t own_lo = lb1 - lb0, own_hi = lb3 - lb2;
-    const uint32_t in_lo = s->has_lo ? s->h_lb[4] : 0u, peer_own_lo = s->has_lo ? s->h_lb[5] : 0u;
-    const uint32_t in_hi = s->has_hi ? s->h_lb[8] : 0u, peer_own_hi = s->has_hi ? s->h_lb[9] : 0u;
+    const uint32_t in_lo = s->has_lo ? s->h_lb[HL_HDR_LO] : 0u, peer_own_lo = s->has_lo ? s->h_lb[HL_HDR_LO + 1] : 0u;
+    const uint32_t in_hi = s->has_hi ? s->h_lb[HL_HDR_HI] : 0u, peer_own_hi = s->has_hi ? s->h_lb[HL_HDR_HI + 1] : 0u;
+    const uint32_t far_in_lo = s->has_lo ? s->h_lb[HL_HDR_LO + 2] : 0u, far_in_hi = s->has_hi ? s->h_lb[HL_HDR_HI + 2] : 0u;
     SPH_REQUIRE(s->has_lo || m_lo == 0, SPH_E_STATE, "rank %d: %u particles below the lowest slab", s->rank, m_lo);
     SPH_REQUIRE(s->has_hi || m_hi == 0, SPH_E_STATE, "rank %d: %u particles above the highest slab", s->rank, m_hi);
+    // both ends of a link see the same numbers (mine in my header, the neighbour's in its header): they fail together
     SPH_REQUIRE(m_lo <= s->mcap && m_hi <= s->mcap && in_lo <= s->mcap && in_hi <= s->mcap, SPH_E_CAPACITY,
                 "rank %d: a burst of %u/%u leaving, %u/%u arriving particles exceeds the migrant capacity %u", s->rank, m_lo, m_hi,
                 in_lo, in_hi, s->mcap);
+    SPH_REQUIRE(far_in_lo <= in_lo && far_in_hi <= in_hi && far_lo <= m_lo && far_hi <= m_hi, SPH_E_STATE,
+                "rank %d: inconsistent migrant headers", s->rank);
+    // ---- more leavers than ride in the fixed-size message: the rest, exact size (both ends know both counts) ----------
+    if (m_lo > inl || m_hi > inl || in_lo > inl || in_hi > inl) {
+        const size_t s_lo = m_lo > inl ? (size_t)(m_lo - inl) * rec : 0, s_hi = m_hi > inl ? (size_t)(m_hi - inl) * rec : 0;
+        const size_t r_lo = in_lo > inl ? (size_t)(in_lo - inl) * rec : 0, r_hi = in_hi > inl ? (size_t)(in_hi - inl) * rec : 0;
+        rc = slab_exchange(s, SPH_TAG_MIGRANTS_REST, s->mig_send[0] + 2 * (1 + inl), s_lo, s->mig_recv[0] + 2 * (1 + inl), r_lo,
+                           s->mig_send[1] + 2 * (1 + inl), s_hi, s->mig_recv[1] + 2 * (1 + inl), r_hi);
+        if (rc) return rc;
+        s->rest_msgs++;
+    }
     // ---- drop the leavers (their cells hold nothing else until the ghosts arrive) ------------------------------------
     if (m_lo || m_hi) {
         if (c->cells_valid && c->cells_lo == c->own_off && c->cells_hi == c->own_off + c->n) {
-            rc = launch_cells_clear_range(c, c->own_off, c->own_off + m_lo);
-            if (!rc) rc = launch_cells_clear_range(c, c->own_off + c->n - m_hi, c->own_off + c->n);
+            rc = launch_cells_clear_2ranges(c, c->own_off, c->own_off + m_lo, c->own_off + c->n - m_hi, c->own_off + c->n);
             if (rc) return rc;
             c->cells_lo += m_lo;
             c->cells_hi -= m_hi;
@@ -342,18 +647,16 @@ int slab_step_once(sph_slab* s, float dt) {
         c->n -= m_lo + m_hi;
         s->migrants += m_lo + m_hi;
     }
-    // ---- arrivals become owned particles: appended behind the owned range and merged by a second sort.  They land in
-    //      the boundary layer next to the cut they crossed, so the boundary counts are known without counting again ------
+    // ---- arrivals become owned particles.  They land in the boundary layer next to the cut they crossed -- except the
+    //      `far` ones the sender counted, which land deeper -- so the boundary counts are known without counting again ---
     if (in_lo || in_hi) {
         SPH_REQUIRE(c->n + in_lo + in_hi <= c->cap && c->own_off + c->n + in_lo + in_hi <= c->tot, SPH_E_CAPACITY,
                     "rank %d: %u + %u arriving particles exceed the capacity %u", s->rank, c->n, in_lo + in_hi, c->cap);
         rc = after_comm(s); if (rc) return rc;                  // the received records are in mig_recv
-        // behind the sorted owned range, with their cell keys: the merge path takes them in as movers without an old
-        // slot (one pass over the particles; a full radix sort when the merge path is switched off)
         const bool merge = c->sort_merge && c->order_valid && c->cells_valid && c->cells_lo == c->own_off &&
                            c->cells_hi == c->own_off + c->n;
-        const bool in_place = SPH_SLAB_INSERT && merge && in_lo <= SLAB_INSERT_MAX && in_hi <= SLAB_INSERT_MAX && in_lo <= c->own_off &&
-                              own_lo + own_hi <= c->n;
+        const bool in_place = SPH_SLAB_INSERT && merge && far_in_lo == 0 && far_in_hi == 0 && in_lo <= SLAB_INSERT_MAX &&
+                              in_hi <= SLAB_INSERT_MAX && in_lo <= c->own_off && own_lo + own_hi <= c->n;
         if (in_place) {
             // only the two boundary layers are touched (see k_slab_insert): their cells leave the table, the merged
             // layers come back from the scratch arrays, their cells are built again
@@ -365,11 +668,11 @@ int slab_step_once(sph_slab* s, float dt) {
                 const uint32_t d0 = side == 0 ? l0 - k : l0;
                 rc = launch_cells_clear_range(c, l0, l0 + nl); if (rc) return rc;
                 hipLaunchKernelGGL(k_slab_insert, dim3(ceil_div(nl + k, 256u)), dim3(256), 0, c->stream, c->posi, c->velr, c->keyS, l0,
-                                   nl, s->mig_recv[side] + 2, k, c->grid, c->posi2, c->velr2, c->keyS2, d0);
+                                   nl, s->mig_recv[side] + 2, k, c->grid, c->posi2, c->velr2, c->keyS2, d0,
+                                   side == 0 ? 1u : c->grid.zl - 2u, s->h_lb_dev + HL_ERR);
+                hipLaunchKernelGGL(k_slab_copy_back, dim3(ceil_div(nl + k, 256u)), dim3(256), 0, c->stream, c->posi2, c->velr2, c->keyS2,
+                                   c->posi, c->velr, c->keyS, d0, nl + k);
                 SPH_HIP(hipGetLastError());
-                SPH_HIP(hipMemcpyAsync(c->posi + d0, c->posi2 + d0, (size_t)(nl + k) * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-                SPH_HIP(hipMemcpyAsync(c->velr + d0, c->velr2 + d0, (size_t)(nl + k) * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-                SPH_HIP(hipMemcpyAsync(c->keyS + d0, c->keyS2 + d0, (size_t)(nl + k) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
                 if (side == 0) c->own_off = d0;
                 c->n += k;
                 c->cells_lo = c->own_off; c->cells_hi = c->own_off + c->n;
@@ -380,34 +683,56 @@ int slab_step_once(sph_slab* s, float dt) {
             s->inserts++;
             s->resorts++;
         } else {
-        uint32_t appended = 0;
-        for (int side = 0; side < 2; side++) {
-            const uint32_t cnt = side == 0 ? in_lo : in_hi;
-            if (!cnt) continue;
-            const uint32_t at = c->own_off + c->n + appended;
-            hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(cnt, 256u)), dim3(256), 0, c->stream, s->mig_recv[side] + 2, cnt,
-                               c->posi + at, c->velr + at, merge ? c->k0 + c->n + appended : (uint32_t*)nullptr, c->grid);
-            appended += cnt;
-        }
-        SPH_HIP(hipGetLastError());
-        if (merge) {
-            rc = launch_merge_arrivals(c, appended); if (rc) return rc;
-        } else {
-            c->n += appended;
-            c->keys_fresh = false;
-            c->order_valid = false;
-            c->stage = sph_ctx::ST_LOADED;
-            rc = step_hash(c); if (rc) return rc;
-            rc = step_sort(c); if (rc) return rc;
-        }
-        own_lo += in_lo;
-        own_hi += in_hi;
-        s->resorts++;
+            // behind the sorted owned range, with their cell keys: the merge path takes them in as movers without an old
+            // slot (one pass over the particles; a full radix sort when the merge path is switched off).  Every slot
+            // moves: the density of the deep interior is computed again with the rest.
+            deep_valid = false;
+            uint32_t appended = 0;
+            for (int side = 0; side < 2; side++) {
+                const uint32_t cnt = side == 0 ? in_lo : in_hi;
+                if (!cnt) continue;
+                const uint32_t at = c->own_off + c->n + appended;
+                hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(cnt, 256u)), dim3(256), 0, c->stream, s->mig_recv[side] + 2, cnt,
+                                   c->posi + at, c->velr + at, merge ? c->k0 + c->n + appended : (uint32_t*)nullptr, c->grid,
+                                   s->h_lb_dev + HL_ERR);
+                appended += cnt;
+            }
+            SPH_HIP(hipGetLastError());
+            if (merge) {
+                rc = launch_merge_arrivals(c, appended); if (rc) return rc;
+            } else {
+                c->n += appended;
+                c->keys_fresh = false;
+                c->order_valid = false;
+                c->stage = sph_ctx::ST_LOADED;
+                rc = step_hash(c); if (rc) return rc;
+                rc = step_sort(c); if (rc) return rc;
+            }
+            own_lo += in_lo - far_in_lo;          // the far ones went past the boundary layer
+            own_hi += in_hi - far_in_hi;
+            s->resorts++;
+            if (far_in_lo || far_in_hi) {
+                // rare (a particle crossed more than one cell layer in a step): count the layers again.  The neighbours
+                // size their ghost messages from the headers, so what the count must confirm is that every far arrival
+                // stayed clear of the OTHER boundary layer and of the ghost layers.
+                s->far_steps++;
+                hipLaunchKernelGGL(k_slab_bounds, dim3(1), dim3(64), 0, c->stream, c->keyS + c->own_off, c->n, layer, c->grid.zl,
+                                   s->d_lb, s->h_lb_dev);
+                SPH_HIP(hipGetLastError());
+                SPH_HIP(hipStreamSynchronize(c->stream));
+                s->host_waits++;
+                rc = slab_check_device_flags(s); if (rc) return rc;
+                const uint32_t r0 = s->h_lb[0], r1 = s->h_lb[1], r2 = s->h_lb[2], r3 = s->h_lb[3];
+                SPH_REQUIRE(r0 == 0u && r3 == c->n && r1 - r0 == own_lo && r3 - r2 == own_hi, SPH_E_STATE,
+                            "rank %d: a particle that crossed several cell layers in one step landed in a boundary or ghost "
+                            "layer (boundary layers %u/%u, expected %u/%u): the time step is too large for this slab width",
+                            s->rank, r1 - r0, r3 - r2, own_lo, own_hi);
+            }
         }
     }
     const uint32_t n = c->n;
-    const uint32_t g_lo = s->has_lo ? peer_own_lo + m_lo : 0u;   // ghosts I receive = what stayed in the neighbour's
-    const uint32_t g_hi = s->has_hi ? peer_own_hi + m_hi : 0u;   // boundary layer + what I just sent there
+    const uint32_t g_lo = s->has_lo ? peer_own_lo + m_lo - far_lo : 0u;   // ghosts I receive = what stayed in the neighbour's
+    const uint32_t g_hi = s->has_hi ? peer_own_hi + m_hi - far_hi : 0u;   // boundary layer + what I just sent INTO that layer
     const uint32_t h_lo = s->has_lo ? own_lo : 0u, h_hi = s->has_hi ? own_hi : 0u;
     SPH_REQUIRE(own_lo <= n && own_hi <= n, SPH_E_STATE, "rank %d: inconsistent boundary counts", s->rank);
     SPH_REQUIRE(h_lo <= s->gcap && h_hi <= s->gcap && g_lo <= s->gcap && g_hi <= s->gcap && g_lo <= c->own_off &&
@@ -415,54 +740,43 @@ int slab_step_once(sph_slab* s, float dt) {
                 "rank %d: a boundary layer of %u/%u (ghosts %u/%u) exceeds the ghost capacity %u", s->rank, h_lo, h_hi, g_lo, g_hi,
                 s->gcap);
     // ---- halo A: boundary layers -> neighbours' ghost layers; the interior density runs meanwhile ------------------
-    if (h_lo) hipLaunchKernelGGL(k_slab_pack, dim3(ceil_div(h_lo, 256u)), dim3(256), 0, c->stream, c->posi + c->own_off,
-                                 c->velr + c->own_off, h_lo, s->halo_send[0]);
-    if (h_hi) hipLaunchKernelGGL(k_slab_pack, dim3(ceil_div(h_hi, 256u)), dim3(256), 0, c->stream, c->posi + c->own_off + n - h_hi,
-                                 c->velr + c->own_off + n - h_hi, h_hi, s->halo_send[1]);
+    if (h_lo + h_hi)
+        hipLaunchKernelGGL(k_slab_pack2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, c->stream, c->posi, c->velr, c->own_off, h_lo,
+                           c->own_off + n - h_hi, h_hi, s->halo_send[0], s->halo_send[1]);
     SPH_HIP(hipGetLastError());
     rc = after_main(s); if (rc) return rc;                      // the comm stream may start once the slices are packed
     // interior = everything but the two boundary layers, in whole 64-slot chunks (the fused force pass marks the
     // movers of the next sort per chunk).  Queued BEFORE the transfers are handed to the transport: the main stream
-    // has the bulk of the step's work in its queue while the halo travels.
+    // has the bulk of the step's work in its queue while the halo travels.  What the deep launch already did is left out.
     uint32_t a = c->own_off + ((h_lo + 63u) & ~63u), b = c->own_off + ((n - h_hi) & ~63u);
     if (b < a || a > c->own_off + n) { a = c->own_off; b = c->own_off; }     // a thin slab: everything is "boundary"
-    { PhaseTimer t(c, SPH_PH_DENS); rc = launch_density_range(c, a, b); }
+    {
+        PhaseTimer t(c, SPH_PH_DENS);
+        rc = deep_valid ? launch_density_hole(c, a, b, deep_lo, deep_hi) : launch_density_range(c, a, b);
+    }
     if (rc) return rc;
-    const size_t rec = 2 * sizeof(float4);
     rc = slab_exchange(s, SPH_TAG_HALO_A, s->halo_send[0], h_lo * rec, s->halo_recv[0], g_lo * rec, s->halo_send[1], h_hi * rec,
                        s->halo_recv[1], g_hi * rec);
     if (rc) return rc;
     // ghosts go directly in front of / behind the owned range, already in key order; their cells join the table of
-    // the owned slots (comm stream: none of it is touched by the interior passes)
-    if (g_lo) hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(g_lo, 256u)), dim3(256), 0, s->comm, s->halo_recv[0], g_lo,
-                                 c->posi + c->own_off - g_lo, c->velr + c->own_off - g_lo, c->keyS + c->own_off - g_lo, c->grid);
-    if (g_hi) hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(g_hi, 256u)), dim3(256), 0, s->comm, s->halo_recv[1], g_hi,
-                                 c->posi + c->own_off + n, c->velr + c->own_off + n, c->keyS + c->own_off + n, c->grid);
+    // the owned slots (comm stream, one kernel: none of it is touched by the interior passes)
+    if (g_lo + g_hi)
+        hipLaunchKernelGGL(k_slab_unpack_ghosts, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->halo_recv[0], g_lo,
+                           c->own_off - g_lo, s->halo_recv[1], g_hi, c->own_off + n, c->posi, c->velr, c->keyS, c->cells, c->grid);
     SPH_HIP(hipGetLastError());
     c->n_glo = g_lo; c->n_ghi = g_hi;
     s->ghosts += g_lo + g_hi;
-    {
-        hipStream_t main = c->stream;
-        c->stream = s->comm;                                     // the ghost cells are built on the comm stream
-        rc = launch_cells_build_range(c, c->own_off - g_lo, c->own_off);
-        if (!rc) rc = launch_cells_build_range(c, c->own_off + n, c->own_off + n + g_hi);
-        c->stream = main;
-        if (rc) return rc;
-        c->cells_lo = c->own_off - g_lo; c->cells_hi = c->own_off + n + g_hi; c->cells_valid = true;
-        c->stage = sph_ctx::ST_CELLS;
-    }
+    c->cells_lo = c->own_off - g_lo; c->cells_hi = c->own_off + n + g_hi; c->cells_valid = true;
+    c->stage = sph_ctx::ST_CELLS;
     rc = after_comm(s); if (rc) return rc;
-    {
-        PhaseTimer t(c, SPH_PH_DENS);
-        rc = launch_density_range(c, c->own_off, a);
-        if (!rc) rc = launch_density_range(c, b, c->own_off + n);
-    }
+    { PhaseTimer t(c, SPH_PH_DENS); rc = launch_density_hole(c, c->own_off, c->own_off + n, a, b); }   // the two boundary layers
     if (rc) return rc;
     c->have_dens = true;
     // ---- halo B: (density, pressure) of the same boundary particles, same order; interior forces meanwhile ---------
-    if (h_lo) SPH_HIP(hipMemcpyAsync(s->dens_send[0], c->dp + c->own_off, h_lo * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
-    if (h_hi) SPH_HIP(hipMemcpyAsync(s->dens_send[1], c->dp + c->own_off + n - h_hi, h_hi * sizeof(float2), hipMemcpyDeviceToDevice,
-                                     c->stream));
+    if (h_lo + h_hi)
+        hipLaunchKernelGGL(k_slab_copy_dp2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, c->stream, c->dp + c->own_off, s->dens_send[0],
+                           h_lo, c->dp + c->own_off + n - h_hi, s->dens_send[1], h_hi);
+    SPH_HIP(hipGetLastError());
     rc = after_main(s); if (rc) return rc;
     const bool mark = force_begin(c, true);
     { PhaseTimer t(c, SPH_PH_FORCE); rc = launch_force_range(c, a, b, true, true, true, dt, mark); }   // interior: queued before the transfer
@@ -470,14 +784,12 @@ int slab_step_once(sph_slab* s, float dt) {
     rc = slab_exchange(s, SPH_TAG_HALO_B, s->dens_send[0], h_lo * sizeof(float2), s->dens_recv[0], g_lo * sizeof(float2),
                        s->dens_send[1], h_hi * sizeof(float2), s->dens_recv[1], g_hi * sizeof(float2));
     if (rc) return rc;
-    if (g_lo) SPH_HIP(hipMemcpyAsync(c->dp + c->own_off - g_lo, s->dens_recv[0], g_lo * sizeof(float2), hipMemcpyDeviceToDevice, s->comm));
-    if (g_hi) SPH_HIP(hipMemcpyAsync(c->dp + c->own_off + n, s->dens_recv[1], g_hi * sizeof(float2), hipMemcpyDeviceToDevice, s->comm));
+    if (g_lo + g_hi)
+        hipLaunchKernelGGL(k_slab_copy_dp2, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->dens_recv[0],
+                           c->dp + c->own_off - g_lo, g_lo, s->dens_recv[1], c->dp + c->own_off + n, g_hi);
+    SPH_HIP(hipGetLastError());
     rc = after_comm(s); if (rc) return rc;
-    {
-        PhaseTimer t(c, SPH_PH_FORCE);
-        rc = launch_force_range(c, c->own_off, a, true, true, true, dt, mark);
-        if (!rc) rc = launch_force_range(c, b, c->own_off + n, true, true, true, dt, mark);
-    }
+    { PhaseTimer t(c, SPH_PH_FORCE); rc = launch_force_hole(c, c->own_off, c->own_off + n, a, b, true, true, true, dt, mark); }
     if (rc) return rc;
     force_finish(c, true, mark);
     c->have_force = c->have_coll = false;
@@ -584,6 +896,58 @@ int sph_rccl_transport_selftest(sph_transport* t, size_t bytes) {
     return rc;
 }
 
+int sph_local_hub_create(sph_local_hub** out, int world, int device) {
+    SPH_REQUIRE(out && world >= 1, SPH_E_INVALID, "bad argument");
+    *out = nullptr;
+    if (device < 0) device = sph_selected_device();
+    SPH_HIP(hipSetDevice(device));
+    sph_local_hub* H = new (std::nothrow) sph_local_hub();
+    SPH_REQUIRE(H, SPH_E_NOMEM, "out of host memory");
+    H->world = world;
+    if (const char* e = getenv("SPH_SLAB_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) H->timeout_s = v; }
+    H->links.resize(2 * (size_t)world);
+    for (LocalLink& L : H->links)
+        if (hipEventCreateWithFlags(&L.ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L.done, hipEventDisableTiming) != hipSuccess) {
+            set_error("sph_local_hub_create: hipEventCreate failed");
+            sph_local_hub_destroy(H);
+            return SPH_E_DEVICE;
+        }
+    *out = H;
+    return SPH_OK;
+}
+
+void sph_local_hub_destroy(sph_local_hub* H) {
+    if (!H) return;
+    for (LocalLink& L : H->links) { if (L.ready) hipEventDestroy(L.ready); if (L.done) hipEventDestroy(L.done); }
+    delete H;
+}
+
+int sph_local_hub_set_timeout(sph_local_hub* H, double seconds) {
+    SPH_REQUIRE(H && seconds > 0.0, SPH_E_INVALID, "bad argument");
+    H->timeout_s = seconds;
+    return SPH_OK;
+}
+
+int sph_local_transport_create(sph_transport** out, sph_local_hub* hub, int rank) {
+    SPH_REQUIRE(out && hub && rank >= 0 && rank < hub->world, SPH_E_INVALID, "bad argument");
+    *out = nullptr;
+    LocalEnd* E = new (std::nothrow) LocalEnd{hub, rank};
+    sph_transport* t = new (std::nothrow) sph_transport();
+    if (!E || !t) { delete E; delete t; set_error("out of host memory"); return SPH_E_NOMEM; }
+    t->self = E;
+    t->exchange = local_exchange;
+    t->host_buffers = 0;
+    *out = t;
+    return SPH_OK;
+}
+
+void sph_local_transport_destroy(sph_transport* t) {
+    if (!t) return;
+    delete (LocalEnd*)t->self;
+    delete t;
+}
+
 int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph_transport* transport,
                     uint32_t migrant_capacity) {
     SPH_REQUIRE(out && ctx && transport && transport->exchange, SPH_E_INVALID, "null argument");
@@ -597,6 +961,8 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
     SPH_REQUIRE(s, SPH_E_NOMEM, "out of host memory");
     s->c = ctx; s->rank = rank; s->world = world;
     s->has_lo = rank > 0; s->has_hi = rank + 1 < world;
+    s->device = ctx->device;
+    if (const char* e = getenv("SPH_SLAB_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) s->wait_timeout_s = v; }
     s->tr = *transport;
     s->host_staged = transport->host_buffers != 0;
     s->gcap = ctx->gcap;
@@ -607,10 +973,10 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
     bool ok = hipStreamCreateWithPriority(&s->comm, hipStreamNonBlocking, hi_pri) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&s->ev_sync, hipEventDisableTiming) == hipSuccess &&
-              hipMalloc((void**)&s->d_lb, 16 * sizeof(uint32_t)) == hipSuccess &&
-              hipHostMalloc((void**)&s->h_lb, 16 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
-              hipHostGetDevicePointer((void**)&s->h_lb_dev, s->h_lb, 0) == hipSuccess;
+              hipMalloc((void**)&s->d_lb, DL_WORDS * sizeof(uint32_t)) == hipSuccess &&
+              hipMemset(s->d_lb, 0, DL_WORDS * sizeof(uint32_t)) == hipSuccess &&
+              hipHostMalloc((void**)&s->h_lb, HL_WORDS * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer((void**)&s->h_lb_dev, (void*)s->h_lb, 0) == hipSuccess;
     const size_t mig_bytes = (size_t)(1 + s->mcap) * 2 * sizeof(float4), halo_bytes = (size_t)(s->gcap + 1) * 2 * sizeof(float4);
     for (int k = 0; k < 2 && ok; k++)
         ok = hipMalloc((void**)&s->mig_send[k], mig_bytes) == hipSuccess && hipMalloc((void**)&s->mig_recv[k], mig_bytes) == hipSuccess &&
@@ -625,17 +991,24 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
                  hipHostMalloc((void**)&s->stage_recv[k], s->stage_bytes) == hipSuccess;
     }
     if (!ok) { set_error("sph_slab_create: allocation failed"); slab_free(s); return SPH_E_NOMEM; }
-    memset(s->h_lb, 0, 16 * sizeof(uint32_t));
+    for (int k = 0; k < HL_WORDS; k++) s->h_lb[k] = 0u;
     *out = s;
     return SPH_OK;
 }
 
+// must run BEFORE sph_destroy of its context (it drains the context's stream, on which its kernels run)
 void sph_slab_destroy(sph_slab* s) {
     if (!s) return;
-    hipSetDevice(s->c->device);
+    hipSetDevice(s->device);
     hipStreamSynchronize(s->comm);
     hipStreamSynchronize(s->c->stream);
     slab_free(s);
+}
+
+int sph_slab_set_wait_timeout(sph_slab* s, double seconds) {
+    SPH_REQUIRE(s && seconds > 0.0, SPH_E_INVALID, "bad argument");
+    s->wait_timeout_s = seconds;
+    return SPH_OK;
 }
 
 int sph_slab_step(sph_slab* s, float dt, uint32_t n_steps) {
@@ -652,10 +1025,19 @@ int sph_slab_sync(sph_slab* s) {
     SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
     SPH_HIP(hipSetDevice(s->c->device));
     SPH_HIP(hipStreamSynchronize(s->comm));
-    return sph_sync(s->c);
+    int rc = sph_sync(s->c);
+    if (rc) return rc;
+    return slab_check_device_flags(s);
 }
 
 uint64_t sph_slab_in_place_merges(const sph_slab* s) { return s ? s->inserts : 0; }
+
+int sph_slab_counters(const sph_slab* s, uint64_t out[8]) {
+    SPH_REQUIRE(s && out, SPH_E_INVALID, "null argument");
+    out[0] = s->steps; out[1] = s->migrants; out[2] = s->resorts; out[3] = s->ghosts; out[4] = s->host_waits;
+    out[5] = s->inserts; out[6] = s->far_steps; out[7] = s->rest_msgs;
+    return SPH_OK;
+}
 
 int sph_slab_stats(const sph_slab* s, uint64_t out[5]) {
     SPH_REQUIRE(s && out, SPH_E_INVALID, "null argument");

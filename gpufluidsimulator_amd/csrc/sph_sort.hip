@@ -783,13 +783,16 @@ __device__ __forceinline__ uint32_t mm_lower_bound(const uint32_t* __restrict__ 
 constexpr uint32_t MM_RANK_TILE = 4096;
 __global__ __launch_bounds__(256) void k_mm_tile_rank(const uint32_t* __restrict__ A, uint32_t n,
                                                       const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
-                                                      const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ tileL) {
+                                                      const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ tileL,
+                                                      uint32_t* __restrict__ tileA) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t ntiles = (n + MM_RANK_TILE - 1) / MM_RANK_TILE;
     if (t > ntiles) return;
     const uint32_t m = *m_dev;
     const uint32_t slot = t * MM_RANK_TILE;
-    tileL[t] = t == ntiles ? m : mm_lower_bound(mk, mi, 0u, m, A[slot], slot);
+    const uint32_t a = t == ntiles ? 0xFFFFFFFFu : A[slot];
+    tileA[t] = a;                      // first key of every tile: the coarse level of k_mm_place_movers' searches
+    tileL[t] = t == ntiles ? m : mm_lower_bound(mk, mi, 0u, m, a, slot);
 }
 
 // non-movers: one thread per slot, the particle goes straight to its final slot.  The bracket [L0, L1] of a
@@ -828,24 +831,46 @@ __global__ __launch_bounds__(256) void k_mm_scatter(const uint32_t* __restrict__
     if (perm_out) perm_out[dst] = i;
 }
 
+// movers: one thread each (grid-stride: the grid is generous, not exact).  A mover's slot follows from the run
+// [s, e) of its NEW cell in the old order.  Where the cell table of the old order is live and still holds that cell
+// (it was occupied, and no mover left it -- k_mm_compact cleared those), the run is ONE table read; else it is
+// searched: the first key of every 4096-slot tile (tileA, 16 KB at C3, written by k_mm_tile_rank) brackets it, one
+// binary search inside the tile finds s, and e is galloped to from s (a cell holds a handful of particles).  Two
+// full-array searches per mover -- 2 x 24 dependent loads at C3 -- made this kernel 167 us on burst steps.
 __global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restrict__ A, uint32_t n, uint32_t nchunks,
                                                          const uint64_t* __restrict__ mask,
                                                          const uint32_t* __restrict__ M64,
                                                          const uint32_t* __restrict__ mk,
                                                          const uint32_t* __restrict__ mi,
                                                          const uint32_t* __restrict__ m_dev,
+                                                         const uint32_t* __restrict__ tileA, const uint2* __restrict__ cells,
+                                                         uint32_t slot_base,
                                                          const float4* __restrict__ posi, const float4* __restrict__ velr,
                                                          float4* __restrict__ posi_out, float4* __restrict__ velr_out,
                                                          uint32_t* __restrict__ key_out, uint32_t* __restrict__ perm_out) {
     const uint32_t m = *m_dev;
+    const uint32_t ntiles = (n + MM_RANK_TILE - 1) / MM_RANK_TILE;
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < m; r += gridDim.x * 256u) {
         const uint32_t key = mk[r], slot = mi[r];
-        uint32_t lo = 0, hi = n;                       // s = first slot with A >= key
-        while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (A[mid] < key) lo = mid + 1; else hi = mid; }
-        const uint32_t s = lo;
-        hi = n;                                        // e = first slot with A > key
-        while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (A[mid] <= key) lo = mid + 1; else hi = mid; }
-        const uint32_t e = lo;
+        uint32_t s, e;
+        uint2 ce = make_uint2(0u, 0u);
+        if (cells) ce = cells[key];
+        if (ce.y > ce.x) {                              // the old order's run of this cell (absolute slots)
+            s = ce.x - slot_base; e = ce.y - slot_base;
+        } else {
+            // coarse: last tile whose first key is < key (s lies in it or at the start of the next one)
+            uint32_t lo = 0, hi = ntiles;               // first tile t with tileA[t] >= key
+            while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (tileA[mid] < key) lo = mid + 1; else hi = mid; }
+            uint32_t a = lo ? (lo - 1u) * MM_RANK_TILE : 0u, b = min(lo * MM_RANK_TILE, n);
+            while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (A[mid] < key) a = mid + 1; else b = mid; }
+            s = a;                                      // first slot with A >= key
+            uint32_t step = 1u, p = s;                  // gallop to the first slot with A > key
+            while (p < n && A[p] == key) { p = min(p + step, n); step <<= 1; }
+            uint32_t q = p > s ? max(s, p - (step >> 1)) : s;   // A[q .. ) still may equal key; A[p] != key or p == n
+            a = q; b = p;
+            while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (A[mid] <= key) a = mid + 1; else b = mid; }
+            e = a;
+        }
         const uint32_t j = min(max(slot, s), e);       // non-movers of cell `key` below `slot` end here
         uint32_t before = m;                           // movers among the slots [0, j)  (j <= n: the slots with an old key)
         if ((j >> 6) < nchunks) before = M64[j >> 6] + (uint32_t)__popcll(mask[j >> 6] & ((1ull << (j & 63u)) - 1ull));
@@ -857,9 +882,13 @@ __global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restr
     }
 }
 
+// Blocks for the movers' radix sort.  The count is only a hint (the previous report; whole lattice layers cross a
+// cell face together: x100 from one step to the next), and blocks without a tile leave at once, so the grid is
+// generous: never fewer than a full one-group grid (64 blocks: 262,144 movers at one tile each), twice the hint
+// beyond that.  A tight grid made ~20 blocks work through ~200 tiles of a burst with a chained look-back.
 static uint32_t merge_grid_for(uint32_t movers_hint, uint32_t n) {
-    const uint32_t want = ceil_div(2u * movers_hint + 1u, SORT_TILE) + 15u;    // head-room: the hint is stale
-    return min(want, ceil_div(n, SORT_TILE));
+    const uint32_t want = max(ceil_div(2u * movers_hint + 1u, SORT_TILE) + 15u, OS_ONE_GROUP_TILES);
+    return min(want, max(ceil_div(n, SORT_TILE), 1u));
 }
 
 // `counted`: the movers belong to a sort (they add to the running total), not to marks being dropped
@@ -933,13 +962,16 @@ static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_
     if (rc) return rc;
     const uint32_t rank_tiles = ceil_div(n, MM_RANK_TILE) + 1u;
     hipLaunchKernelGGL(k_mm_tile_rank, dim3(ceil_div(rank_tiles, 256u)), dim3(256), 0, c->stream, A, n, mk, mi, c->mm_count,
-                       c->mm_tileL);
+                       c->mm_tileL, c->mm_tileA);
     SPH_HIP(hipGetLastError());
     uint32_t* perm = c->keep_perm ? c->v1 : (uint32_t*)nullptr;
     const float4* ps = c->posi + c->own_off; const float4* vs = c->velr + c->own_off;
     float4* po = c->posi2 + c->gcap; float4* vo = c->velr2 + c->gcap; uint32_t* ko = c->keyS2 + c->gcap;
-    hipLaunchKernelGGL(k_mm_place_movers, dim3(min(ceil_div(2u * hint + 1u, 256u) + 15u, 65535u)), dim3(256), 0, c->stream,
-                       A, n, nchunks, c->mm_mask, c->mm_M64, mk, mi, c->mm_count, ps, vs, po, vo, ko, perm);
+    // generous grid (grid-stride loop over the device-side count): a burst is not left to a handful of blocks
+    const uint32_t place_blocks = min(max(ceil_div(2u * hint + 1u, 256u) + 15u, 512u), 65535u);
+    hipLaunchKernelGGL(k_mm_place_movers, dim3(place_blocks), dim3(256), 0, c->stream,
+                       A, n, nchunks, c->mm_mask, c->mm_M64, mk, mi, c->mm_count, c->mm_tileA,
+                       table_live ? c->cells : (const uint2*)nullptr, c->own_off, ps, vs, po, vo, ko, perm);
     SPH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_mm_scatter, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, A, n, c->mm_mask, c->mm_M64, mk, mi,
                        c->mm_tileL, ps, vs, po, vo, ko, perm);
@@ -1011,6 +1043,7 @@ int launch_sort(sph_ctx* c) {
             hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, c->keyS + c->own_off, c->k0, n,
                                c->mm_mask, c->mm_tile_cnt);
             mm_tilescan(c, n, true);
+            SPH_HIP(hipGetLastError());
         }
         uint32_t* kin = c->k0; uint32_t* vin = c->v0;
         uint32_t* kout = c->k1; uint32_t* vout = c->v1;

@@ -122,6 +122,9 @@ CONFIGS = {
     # BASELINE config 4: 67,108,864 particles in total, cut into z-slabs over 2 -> 4 -> 8 GPUs (strong scaling);
     # long axis = z, the slab axis
     "C4": dict(lattice=(256, 512, 512), box=(64.0, 64.0, 64.0), grid=(1024, 1024, 1024), steps=20),
+    # BASELINE config 5: 2^27 = 134,217,728 particles ("C5 n = 512, L = 64"); run with
+    # sph_set_precision(MIXED_F16) -- fp32 positions, fp16 neighbour accumulators.  ~32 GB of HBM: fits one MI355X.
+    "C5": dict(lattice=(512, 512, 512), box=(64.0, 64.0, 64.0), grid=(1024, 1024, 1024), steps=20),
 }
 
 

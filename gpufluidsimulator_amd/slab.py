@@ -249,6 +249,7 @@ class HipEngine:
         return self.ctx.download(index_base=0, count=total)
 
     def download_owned(self): return self.ctx.download_owned()
+    def layer_histogram(self): return self.ctx.layer_histogram()
 
     def to_device(self, arr):
         return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
@@ -413,20 +414,39 @@ class SlabSimulation:
                 self.rebalance()
 
     # -- re-cut the slabs ("cuts chosen so particle counts are equal ... re-cut every K steps") --
-    def rebalance(self, tolerance=0.02):
+    def _layer_histogram(self):
+        """Global per-layer particle histogram (collective).  The product engine counts on the device
+        (sph_layer_histogram: 4 bytes per layer cross the bus); the CPU test engine bins its host arrays."""
+        e, gz = self.engine, self.grid[2]
+        if hasattr(e, "layer_histogram"):
+            local = np.asarray(e.layer_histogram(), dtype=np.int64)
+        else:
+            pos, _, _ = e.download_owned()
+            layers = cell_layer_of(pos[:, 2], self.box[2], gz) if pos.shape[0] else np.zeros(0, np.int64)
+            local = np.bincount(layers, minlength=gz).astype(np.int64)
+        return self.comm.allreduce_sum(local).astype(np.int64)
+
+    def plan_rebalance(self, tolerance=0.02):
+        """The cuts a re-balancing would choose now, or None while the most loaded rank is within `tolerance` of the
+        mean (collective, cheap: one small all-reduce, nothing moves)."""
+        hist = self._layer_histogram()
+        counts = [int(hist[a:b].sum()) for a, b in zip(self.cuts, self.cuts[1:])]
+        if max(counts) <= (1.0 + tolerance) * self.total / self.world:
+            return None                                    # still balanced: keep the cuts
+        cuts = choose_cuts(hist, self.world)
+        return None if cuts == self.cuts else cuts
+
+    def rebalance(self, tolerance=0.02, cuts=None):
         """New count-balanced cuts from the current particle distribution; particles whose layer changed
         owner travel point to point.  Collective: every rank must call it.  Returns True if the cuts moved."""
         e, c = self.engine, self.comm
         gz = self.grid[2]
+        if cuts is None:
+            cuts = self.plan_rebalance(tolerance)
+        if cuts is None:
+            return False
         pos, vel, idx = e.download_owned()
         layers = cell_layer_of(pos[:, 2], self.box[2], gz) if pos.shape[0] else np.zeros(0, np.int64)
-        hist = c.allreduce_sum(np.bincount(layers, minlength=gz).astype(np.int64)).astype(np.int64)
-        counts = [int(hist[a:b].sum()) for a, b in zip(self.cuts, self.cuts[1:])]
-        if max(counts) <= (1.0 + tolerance) * self.total / self.world:
-            return False                                   # still balanced: keep the cuts
-        cuts = choose_cuts(hist, self.world)
-        if cuts == self.cuts:
-            return False
         dest = np.searchsorted(np.asarray(cuts[1:-1]), layers, side="right")    # rank that owns each layer now
         rec = np.zeros((pos.shape[0], REC), np.float32)
         rec[:, 0:3] = pos; rec[:, 3] = idx.view(np.float32); rec[:, 4:7] = vel
@@ -556,6 +576,12 @@ class NativeSlabSimulation(SlabSimulation):
                 self._tr = rccl_transport(self.rank, self.world, self._device_index, self.comm.broadcast_bytes)
                 capi._check(L.sph_rccl_transport_selftest(self._tr, 1 << 16))    # fail here, loudly, not inside a step
             tr = self._tr
+        elif self._transport_kind == "local":
+            # device pointers between the streams of this process (csrc/sph_slab.hip: local_exchange); the ranks share
+            # one capi.LocalHub, handed over as `comm.local_hub`
+            if self._tr is None:
+                self._tr = self.comm.local_hub.transport(self.rank)
+            tr = self._tr
         else:
             self._tr = host_transport(self.comm)
             tr = C.pointer(self._tr)
@@ -584,48 +610,212 @@ class NativeSlabSimulation(SlabSimulation):
 
     def _pull_stats(self):
         import ctypes as C
-        out = (C.c_uint64 * 5)()
-        capi._check(capi.load().sph_slab_stats(self._slab, out))
-        base = getattr(self, "_stats_base", {"migrants": 0, "resorts": 0, "ghosts": 0, "host_waits": 0, "steps": 0})
-        self.stats.update(steps=base["steps"] + int(out[0]), migrants=base["migrants"] + int(out[1]),
-                          resorts=base["resorts"] + int(out[2]), ghosts=base["ghosts"] + int(out[3]),
-                          host_waits=base["host_waits"] + int(out[4]),
-                          in_place_merges=base.get("in_place_merges", 0) + int(capi.load().sph_slab_in_place_merges(self._slab)))
+        out = (C.c_uint64 * 8)()
+        capi._check(capi.load().sph_slab_counters(self._slab, out))
+        base = getattr(self, "_stats_base", {})
+        names = ("steps", "migrants", "resorts", "ghosts", "host_waits", "in_place_merges", "far_steps", "rest_messages")
+        self.stats.update({k: base.get(k, 0) + int(out[i]) for i, k in enumerate(names)})
 
     def sync(self):
         capi._check(capi.load().sph_slab_sync(self._slab))
 
-    def rebalance(self, tolerance=0.02):
+    def rebalance(self, tolerance=0.02, cuts=None):
         self.sync()
+        if cuts is None:
+            cuts = self.plan_rebalance(tolerance)          # device-side histogram + one small all-reduce
+        if cuts is None:
+            return False                                   # balanced: the slab object and its buffers stay as they are
         self._pull_stats()
-        self._stats_base = {k: self.stats.get(k, 0) for k in ("migrants", "resorts", "ghosts", "host_waits", "steps", "in_place_merges")}
+        self._stats_base = {k: self.stats.get(k, 0) for k in ("migrants", "resorts", "ghosts", "host_waits", "steps",
+                                                              "in_place_merges", "far_steps", "rest_messages")}
         self._unbind()                 # the engine (context) is replaced when the cuts move
-        moved = super().rebalance(tolerance)
+        moved = super().rebalance(tolerance, cuts=cuts)
         self._bind()
         return moved
 
     def close(self):
-        self._unbind()
+        self._unbind()                 # before the context goes: sph_slab_destroy drains the context's stream
+        if self._transport_kind == "rccl" and self._tr is not None:
+            capi.load().sph_rccl_transport_destroy(self._tr)
+        if self._transport_kind == "local" and self._tr is not None:
+            capi.load().sph_local_transport_destroy(self._tr)
+        self._tr = None
         self.engine.close()
 
 
 # ------------------------------------------------------------------------------------------------
 # bench entry (bench.py --gpus N, one rank per GPU under torch.distributed.run)
 # ------------------------------------------------------------------------------------------------
-def bench_main(args):
+def bench_config(args, world):
+    """BASELINE.json's metric is "dam-break 16M particles, 1/2/4/8 MI355X": the SAME 16,777,216-particle dam (config
+    3) on N GPUs -- strong scaling, the default.  `--workload C4` = BASELINE config 4 (67,108,864 particles, strong);
+    `--scaling weak` = 16.7 M particles PER GPU (the box grows along z)."""
+    strong = getattr(args, "scaling", "strong") != "weak"
+    if strong:
+        name = getattr(args, "workload", "C3") or "C3"
+        cfg = dict(ic.CONFIGS[name], jitter_dims=ic.CONFIGS[name]["box"])
+        label = f"{name} (strong scaling: the same {cfg['lattice'][0] * cfg['lattice'][1] * cfg['lattice'][2]} particles on every N)"
+    else:
+        cfg = ic.weak_scaling_config(world)
+        label = "C3 per GPU (weak scaling)"
+    lat = getattr(args, "lattice", None)
+    if lat:                                            # e.g. one rank's share of C3 on 8 GPUs: --lattice 256,256,32
+        cfg["lattice"] = tuple(int(v) for v in lat.split(","))
+        label += f", lattice overridden to {lat}"
+    return cfg, strong, label
+
+
+def bench_rank(comm, local, args, transport, log=None):
+    """One rank of the multi-GPU bench (a process under torch.distributed.run, or a thread of the one-GPU rehearsal).
+    Returns the JSON record on rank 0, None elsewhere."""
     import torch
+    rank, world = comm.rank, comm.world
+    log = log or (lambda msg: print(msg, file=sys.stderr, flush=True))
+    cfg, strong, label = bench_config(args, world)
+    sim = NativeSlabSimulation(comm, cfg["box"], cfg["grid"], device_index=local, transport=transport,
+                               lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"])
+    layers = [b - a for a, b in zip(sim.cuts, sim.cuts[1:])]
+    assert min(layers) >= MIN_SLAB_LAYERS or world == 1, sim.cuts
+    mixed = getattr(args, "precision", "f32") == "mixed"        # BASELINE config 5's arithmetic (DESIGN.md section 4)
+    sim.engine.ctx.set_precision(mixed)
+    dt = float(ic.DEFAULT_DT)
+    strict_flow = getattr(args, "runup", None) is None          # the default configuration must be a flowing state
+    runup = args.runup if not strict_flow else 6000
+    every = int(getattr(args, "rebalance_every", 500) or 0)      # run-up only: the timed window keeps its cuts
+    tail = min(1000, runup)
+    t0 = time.perf_counter()
+    left, q0, t_tail = runup, None, None
+    while left > 0:                                    # state preparation: the flowing dam (as in the 1-GPU bench)
+        if left == tail:
+            sim.sync(); comm.barrier()
+            q0, t_tail = sim.engine.ctx.sort_stats(), time.perf_counter()
+        k = min(left - tail, 1000) if left > tail else min(left, 1000)
+        sim.run(dt, k, rebalance_every=every); sim.sync()
+        left -= k
+        if rank == 0:
+            log(f"[bench] run-up {runup - left}/{runup} steps, {time.perf_counter() - t0:.1f} s, cuts {sim.cuts}")
+    sim.sync(); comm.barrier()
+    tail_wall = comm.allreduce_max(time.perf_counter() - t_tail) if t_tail is not None else 0.0
+    q1 = sim.engine.ctx.sort_stats()
+    tail_movers = (q1["movers_total"] - q0["movers_total"]) if q0 is not None else 0
+    rebalances = sim.stats.get("rebalances", 0)
+    sim.run(dt, args.warmup)
+    sim.sync(); torch.cuda.synchronize(); comm.barrier()
+    s0 = sim.engine.ctx.sort_stats()
+    t0 = time.perf_counter()
+    sim.run(dt, args.steps)
+    sim.sync(); torch.cuda.synchronize(); comm.barrier()
+    wall = comm.allreduce_max(time.perf_counter() - t0)
+    s1 = sim.engine.ctx.sort_stats()
+    n_own = sim.engine.n
+    counts = comm.allreduce_sum(np.array([n_own, s1["movers_total"] - s0["movers_total"], s1["skips"] - s0["skips"],
+                                          tail_movers], dtype=np.int64))
+    n_max = comm.allreduce_max(n_own)
+    # per-phase device times of this rank's kernels (HIP events on the library's stream), outside the timed region
+    ctx = sim.engine.ctx
+    ctx.timing(True); ctx.timing_reset()
+    probe = max(2, min(args.steps, 5))
+    sim.run(dt, probe)
+    sim.sync(); comm.barrier()
+    ph, _ = ctx.timing_get()
+    ctx.timing(False)
+    phases_ms = {k: v / probe for k, v in ph.items()}
+    out = None
+    if rank == 0:
+        total = sim.total
+        movers_win = float(counts[1]) / max(args.steps, 1)
+        movers_tail = float(counts[3]) / max(tail, 1)
+        # the N = 1 bench's test (bench.py): no sort of the window skipped, particles changed cell in it, and over the
+        # last 1000 run-up steps at least 1e-3 N of them did so per step
+        flow_ok = bool(int(counts[2]) == 0 and movers_win >= 1e-4 * total and movers_tail >= 1e-3 * total)
+        t_force = max(phases_ms.get("force", 0.0), 1e-9) * 1e-3
+        out = {
+            "metric": "particle-steps/sec", "value": total * args.steps / wall, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32 state + packed-f16 density pairs (config 5)" if mixed else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"dam-break {label}: "
+                                   f"{cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} = {total} particles "
+                                   f"({total // world} per GPU), grid {list(cfg['grid'])}, dt 5e-7, "
+                                   f"{'FLOWING' if flow_ok else 'NOT a flowing state'}: timed after {runup} run-up steps; z-slabs, "
+                                   f"ghost layers and migrants over "
+                                   + {"rccl": "RCCL send/recv (library comm stream)", "host": "host-staged messages",
+                                      "local": "device-to-device copies between the streams of one process"}[transport],
+                       "particles": total, "grid": list(cfg["grid"]), "cuts": sim.cuts, "layers_per_slab": layers,
+                       "state": "flow" if flow_ok else "not-flowing", "runup_steps": runup,
+                       "runup_last_1000_steps": {"steps": tail, "movers_per_step": movers_tail, "rebalances": rebalances,
+                                                 "ms_per_step": tail_wall / max(tail, 1) * 1e3},
+                       "parallelism": f"{world} z-slabs, one per GPU", "transport": transport,
+                       "ranks_as": getattr(args, "ranks_as", "processes")},
+            # the sustained figure: the last 1000 run-up steps between two syncs (re-balancing included)
+            "value_sustained": total * tail / tail_wall if tail_wall > 0 else None,
+            "ms_per_step_sustained": tail_wall / max(tail, 1) * 1e3 if tail_wall > 0 else None,
+            # rank 0's fused force pass (its interior + boundary launches of one step), algorithmic bytes as at N = 1
+            "roofline": {"bound": "hbm", "kernel": "k_force<force+collision+integrate> (rank 0, launches of one step)",
+                         "achieved": 84.0 * n_own / t_force / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": 84.0 * n_own / t_force / 1e9 / 8000.0, "traffic": None, "traffic_source": None,
+                         "algorithmic_bytes_per_particle": 84, "avg_launch_ms": t_force * 1e3,
+                         "particles_rank0": int(n_own)},
+            "cpu_baseline": None,      # timed at N = 1 only (bench.py without --gpus)
+            "phases_ms_rank0": phases_ms, "slab_stats_rank0": sim.stats, "owned_sum": int(counts[0]),
+            "owned_max": int(n_max), "imbalance": float(n_max) * world / max(total, 1),
+            "movers_per_step": movers_win, "sort_skips": int(counts[2]), "flowing": flow_ok,
+        }
+    sim.close()
+    return out, (strict_flow and out is not None and not out["flowing"])
+
+
+def bench_main(args):
+    """bench.py --gpus N.  Under torch.distributed.run: one process per rank (RCCL, or gloo with --transport host).
+    `--one-gpu` WITHOUT a launcher: the N ranks run as N threads of this one process on device 0 (a GPU box admits at
+    most 6 processes on its card, so an 8-rank rehearsal cannot be 8 processes)."""
+    import torch
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    transport = getattr(args, "transport", "rccl")
+    launched = "RANK" in os.environ
+    if getattr(args, "one_gpu", False) and not launched and args.gpus > 1:
+        if transport == "rccl":
+            sys.exit("bench: --one-gpu needs --transport host or local (RCCL refuses two ranks on one device)")
+        args.ranks_as = "threads of one process"
+        torch.cuda.set_device(0)
+        hub = LocalComm.Hub(args.gpus)
+        hub_tr = capi.LocalHub(args.gpus) if transport == "local" else None
+        res, errors = [None] * args.gpus, []
+
+        def rank_main(r):
+            try:
+                comm = LocalComm(hub, r)
+                comm.local_hub = hub_tr
+                res[r] = bench_rank(comm, 0, args, transport)
+            except BaseException as e:     # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                errors.append(e)
+                hub.bar.abort()
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(args.gpus)]
+        for t in threads: t.start()
+        for t in threads: t.join()
+        if errors:
+            sys.exit(f"bench: a rank failed: {errors[0]!r}")
+        out, bad = res[0]
+        print(json.dumps(out), flush=True)
+        if bad:
+            sys.exit("bench: the timed window was not a flowing state (sort skipped or too few particles changed cell)")
+        return
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")     # only a direct single-rank run gets here without a launcher
-    transport = getattr(args, "transport", "rccl")
     if getattr(args, "one_gpu", False):               # rehearsal on a one-GPU box: every rank on device 0, host-staged
         if transport != "host":
-            sys.exit("bench: --one-gpu needs --transport host (RCCL refuses two ranks on one device)")
+            sys.exit("bench: --one-gpu under a launcher needs --transport host (processes cannot share device pointers)")
         local = 0
+    if transport == "local":
+        sys.exit("bench: --transport local moves data between the streams of ONE process: use it with --one-gpu and no launcher")
     torch.cuda.set_device(local)
     # torch.distributed is the launcher's plumbing: rendezvous, the RCCL id, barriers and the max over ranks.  The
     # data path (migrants, halos) is the library's own RCCL communicator on its comm stream -- or, with
@@ -636,70 +826,10 @@ def bench_main(args):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         comm = TorchDistComm(torch.device("cpu"))
-    strong = getattr(args, "scaling", "weak") == "strong"
-    if strong:
-        cfg = dict(ic.CONFIGS["C4"], jitter_dims=ic.CONFIGS["C4"]["box"])
-    else:
-        cfg = ic.weak_scaling_config(world)
-    sim = NativeSlabSimulation(comm, cfg["box"], cfg["grid"], device_index=local, transport=transport,
-                               lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"])
-    mixed = getattr(args, "precision", "f32") == "mixed"        # BASELINE config 5's arithmetic
-    sim.engine.ctx.set_precision(mixed)
-    dt = float(ic.DEFAULT_DT)
-    runup = args.runup if getattr(args, "runup", None) is not None else 6000
-    t0 = time.perf_counter()
-    left = runup
-    while left > 0:                                    # state preparation: the flowing dam (as in the 1-GPU bench)
-        k = min(left, 2000)
-        sim.run(dt, k); sim.sync()
-        left -= k
-        if rank == 0:
-            print(f"[bench] run-up {runup - left}/{runup} steps, {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
-    sim.run(dt, args.warmup)
-    sim.sync(); torch.cuda.synchronize(); comm.barrier()
-    s0 = sim.engine.ctx.sort_stats()
-    t0 = time.perf_counter()
-    sim.run(dt, args.steps)
-    sim.sync(); torch.cuda.synchronize(); comm.barrier()
-    wall = comm.allreduce_max(time.perf_counter() - t0)
-    s1 = sim.engine.ctx.sort_stats()
-    n_own = sim.engine.n
-    counts = comm.allreduce_sum(np.array([n_own, s1["movers_total"] - s0["movers_total"], s1["skips"] - s0["skips"]],
-                                         dtype=np.int64))
-    # per-phase device times of this rank's kernels (HIP events on the library's stream), outside the timed region
-    ctx = sim.engine.ctx
-    ctx.timing(True); ctx.timing_reset()
-    probe = max(2, min(args.steps, 5))
-    sim.run(dt, probe)
-    sim.sync(); comm.barrier()
-    ph, _ = ctx.timing_get()
-    ctx.timing(False)
-    phases_ms = {k: v / probe for k, v in ph.items()}
+    args.ranks_as = "processes"
+    out, bad = bench_rank(comm, local, args, transport)
     if rank == 0:
-        total = sim.total
-        out = {
-            "metric": "particle-steps/sec", "value": total * args.steps / wall, "unit": "particle-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32 state + packed-f16 density pairs (config 5)" if mixed else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"dam-break {'C4 (strong scaling)' if strong else 'C3 per GPU (weak scaling)'}: "
-                                   f"{cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} = {total} particles "
-                                   f"({total // world} per GPU), grid {list(cfg['grid'])}, dt 5e-7, FLOWING: timed after {runup} "
-                                   f"run-up steps; z-slabs, ghost layers and migrants over "
-                                   f"{'RCCL send/recv (library comm stream)' if transport == 'rccl' else 'host-staged messages'}",
-                       "particles": total, "grid": list(cfg["grid"]), "cuts": sim.cuts, "state": "flow", "runup_steps": runup,
-                       "parallelism": f"{world} z-slabs, one per GPU", "transport": transport},
-            # rank 0's fused force pass (its interior + boundary launches of one step), algorithmic bytes as at N = 1
-            "roofline": (lambda t: {"bound": "hbm", "kernel": "k_force<force+collision+integrate> (rank 0, launches of one step)",
-                                    "achieved": 84.0 * n_own / t / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                    "frac": 84.0 * n_own / t / 1e9 / 8000.0, "traffic": None,
-                                    "algorithmic_bytes_per_particle": 84, "avg_launch_ms": t * 1e3,
-                                    "particles_rank0": int(n_own)})(max(phases_ms.get("force", 0.0), 1e-9) * 1e-3),
-            "cpu_baseline": None,      # timed at N = 1 only (bench.py without --gpus)
-            "phases_ms_rank0": phases_ms, "slab_stats_rank0": sim.stats, "owned_sum": int(counts[0]),
-            "movers_per_step": float(counts[1]) / max(args.steps, 1), "sort_skips": int(counts[2]),
-        }
         print(json.dumps(out), flush=True)
-    sim.close()
     dist.destroy_process_group()
+    if bad:
+        sys.exit("bench: the timed window was not a flowing state (sort skipped or too few particles changed cell)")

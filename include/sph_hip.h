@@ -259,7 +259,7 @@ int sph_layer_histogram(sph_ctx* c, uint32_t* hist, uint32_t n_layers);
  *   host_buffers = 1 (tests): the pointers are pinned HOST buffers the library staged, the call blocks until its
  *                    receives are complete (several slabs of one GPU in one process; processes over gloo).
  * Return 0 or a negative SPH_E* code. */
-enum { SPH_TAG_MIGRANTS = 1, SPH_TAG_HALO_A = 2, SPH_TAG_HALO_B = 3 };
+enum { SPH_TAG_MIGRANTS = 1, SPH_TAG_HALO_A = 2, SPH_TAG_HALO_B = 3, SPH_TAG_MIGRANTS_REST = 4 };
 typedef struct sph_transport {
     void* self;
     int (*exchange)(void* self, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
@@ -276,6 +276,18 @@ void sph_rccl_transport_destroy(sph_transport* t);
  * ncclGroup), compared on the host: checks the dlopen binding of librccl with real traffic on a one-GPU box */
 int sph_rccl_transport_selftest(sph_transport* t, size_t bytes);
 
+/* Device-to-device transport between the slabs of ONE process that share a GPU (one thread per rank): the buffers are
+ * device pointers, the copies are queued on the caller's comm stream behind the sender's event, nothing blocks on the
+ * device -- the same stream/event edges as with RCCL, on a one-GPU box.  The host threads rendezvous with bounded
+ * waits; message sizes and tags of both ends are compared (a disagreement is SPH_E_STATE, not a hang).  One hub per
+ * group of ranks, one transport per rank; destroy the transports, then the hub. */
+typedef struct sph_local_hub sph_local_hub;
+int sph_local_hub_create(sph_local_hub** out, int world, int device);
+void sph_local_hub_destroy(sph_local_hub* hub);
+int sph_local_hub_set_timeout(sph_local_hub* hub, double seconds);
+int sph_local_transport_create(sph_transport** out, sph_local_hub* hub, int rank);
+void sph_local_transport_destroy(sph_transport* t);
+
 typedef struct sph_slab sph_slab;
 /* Bind a slab context (sph_create_slab, particles uploaded) to its place in the chain of `world` slabs.  The halo
  * capacity is the context's ghost capacity; migrant_capacity (records per side and step, 0 = a default) sizes the
@@ -284,11 +296,20 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
                     uint32_t migrant_capacity);
 void sph_slab_destroy(sph_slab* s);
 /* n time steps: sort, migrants, halo A, density, halo B, force + collision + integrate (csrc/sph_slab.hip), queued
- * on the context's stream and a second, high-priority stream; the host waits ONCE per step (for the layer counts). */
+ * on the context's stream and a second, high-priority stream; the host waits ONCE per step (for the layer counts),
+ * behind the density pass of the slab's deep interior, and that wait is bounded (below).  A particle that crosses
+ * more than one cell layer in a step ("far") is handled (one more wait on that step) as long as it lands in an
+ * interior layer of the receiving slab; anything else is reported as SPH_E_STATE, never merged out of order. */
 int sph_slab_step(sph_slab* s, float dt, uint32_t n_steps);
+/* drains both streams; also reports what device-side checks of the last steps flagged */
 int sph_slab_sync(sph_slab* s);
+/* the step's wait gives up after `seconds` (default 120, or SPH_SLAB_TIMEOUT_S) with SPH_E_DEVICE: a neighbour that
+ * stopped with an error never sends its messages */
+int sph_slab_set_wait_timeout(sph_slab* s, double seconds);
 /* {steps, particles sent away, steps with arrivals, ghosts received, host waits} */
 int sph_slab_stats(const sph_slab* s, uint64_t out[5]);
+/* the same five + {in-place merges, steps with far arrivals, steps that needed a second migrant message} */
+int sph_slab_counters(const sph_slab* s, uint64_t out[8]);
 /* of the steps with arrivals, those that merged them into the two boundary layers in place (the rest ran a pass over
  * all particles: more than 2048 arrivals on a side, or no valid cell table) */
 uint64_t sph_slab_in_place_merges(const sph_slab* s);

@@ -146,7 +146,47 @@ def gen_d24_flow():
     _gen_flow("d24_flow", (24, 24, 24), (4.0, 4.0, 4.0), 64, 4000, 3, 1)
 
 
-GENS = {"c1_flow": gen_c1_flow, "d24_flow": gen_d24_flow, "c1": gen_c1, "random": gen_random, "c2": gen_c2, "morton": gen_morton}
+def gen_c2_flow():
+    """BASELINE config 2 geometry (64^3 particles, box 8, grid 128^3) in DEVELOPED FLOW: the reference runs the dam
+    2600 steps (free fall of 0.09 = 1.5 cell edges; whole lattice layers change cell, the floor layers are compressed
+    and collide), the full state is the fixture's input; the reference restarts from it for 2 steps.  Outputs by
+    creation index are stored for every 61st particle + float64 checksums of the full arrays (as c2_sample does);
+    the collision counts of step 1 -- compared bit for bit -- are stored for EVERY particle (uint8)."""
+    cfg = ic.CONFIGS["C2"]
+    box, grid, runup, lock = cfg["box"], cfg["grid"][0], 2600, 2
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], box, jitter=True)
+    recs, stats = refio.run_ref(pos, vel, box, grid, ic.DEFAULT_DT, runup, dump_steps=(runup,), timeout=6 * 3600)
+    print(f"c2_flow: reference run-up of {runup} steps: {stats['seconds']:.1f} s")
+    st = recs[("state", runup)]
+    pos0, vel0 = np.ascontiguousarray(st[:, 0:3]), np.ascontiguousarray(st[:, 3:6])
+    sample = np.arange(0, pos0.shape[0], 61, dtype=np.int64)
+    arrs = {}
+
+    def put(name, a):
+        arrs[name + "_sample"] = a[sample]
+        arrs[name + "_sum"] = a.astype(np.float64).sum(axis=0)
+        arrs[name + "_abs_sum"] = np.abs(a.astype(np.float64)).sum(axis=0)
+
+    recs, _ = refio.run_ref(pos0, vel0, box, grid, ic.DEFAULT_DT, 1, phases=True)
+    for k in ("dens", "force", "coll", "state"):
+        put("s1_" + k, recs[(k, 1)])
+    arrs["s1_coll_count"] = recs[("coll", 1)][:, 3].astype(np.uint8)
+    assert (arrs["s1_coll_count"] == recs[("coll", 1)][:, 3]).all()
+    arrs["s1_ncells"] = np.uint32(recs[("bcells", 1)].shape[0])
+    arrs["s1_max_cell"] = np.uint32(recs[("bcells", 1)][:, 1].max())
+    recs, _ = refio.run_ref(pos0, vel0, box, grid, ic.DEFAULT_DT, lock, dump_steps=tuple(range(1, lock + 1)))
+    for s in range(1, lock + 1):
+        put(f"state_{s}", recs[("state", s)])
+    cells = lambda p: np.floor((p + np.float32(box[0] / 2)) / np.float32(box[0]) * np.float32(grid)).astype(np.int64)
+    moved = int((cells(recs[("state", lock)][:, 0:3]) != cells(pos0)).any(axis=1).sum())
+    print(f"c2_flow: {moved} of {pos0.shape[0]} particles change cell within the {lock} stored steps; "
+          f"|v|max {np.abs(vel0).max():.1f}, particles with collisions at step 1: {int((arrs['s1_coll_count'] > 0).sum())}")
+    _save("c2_flow", pos=pos0, vel=vel0, sample=sample, box=np.float32(box), grid=np.uint32(cfg["grid"]),
+          dt=np.float32(ic.DEFAULT_DT), runup=np.uint32(runup), lock_steps=np.uint32(lock), moved=np.uint32(moved), **arrs)
+
+
+GENS = {"c1_flow": gen_c1_flow, "d24_flow": gen_d24_flow, "c1": gen_c1, "random": gen_random, "c2": gen_c2, "morton": gen_morton,
+        "c2_flow": gen_c2_flow}   # c2_flow: ~40-60 min of reference CPU time
 
 if __name__ == "__main__":
     if not refio.available():

@@ -170,3 +170,68 @@ def test_c4_particle_count_on_one_gpu():
         assert st["sorts"] == 3 and st["merges"] == 2
         rho = c.download(want=("density",))["density"]
         assert np.isfinite(rho).all() and rho.min() > 0
+
+
+def test_c5_particle_count_mixed_precision_on_one_gpu():
+    """BASELINE config 5 as stated: 2^27 = 134,217,728 particles (512^3 lattice, box 64, 1024^3 cells), fp32 positions
+    with fp16 neighbour accumulators (sph_set_precision MIXED_F16), as ONE whole-domain context (~32 GB of HBM).
+      * device-generated lattice, two steps at the reference's dt: sorted keys, finite positive densities, and the
+        lattice corner block against the oracle run on that block alone, at the stated MIXED tolerance (DESIGN 4:
+        density 2 % max / 0.4 % rms of the fp32 oracle, velocity 5e-3 |v|max, position 2e-6 box);
+      * then 4 M particles get random velocities and the system runs 10 steps at dt 2e-5 (hundreds of thousands of
+        cell changes): the merge path of the sort against the full radix sort -- keys and state bit-identical."""
+    cfg = ic.CONFIGS["C5"]
+    nx, ny, nz = cfg["lattice"]
+    n = nx * ny * nz
+    assert n == 134217728
+    box = cfg["box"][0]
+    rng = np.random.default_rng(23)
+    nkick = 1 << 22
+    kick = rng.uniform(-80.0, 80.0, (nkick, 3)).astype(np.float32)
+    runs = []
+    with capi.Context(n, box=cfg["box"], grid=cfg["grid"]) as c:
+        c.set_precision(True)
+        for merge in (True, False):
+            c.set_sort_mode(merge=merge)
+            c.reset_lattice(cfg["lattice"], jitter=True)
+            if merge:
+                p0 = c.download(want=("pos",))["pos"]
+            c.step(DT, 2)
+            if merge:
+                keys = c.keys()
+                assert np.all(np.diff(keys.astype(np.int64)) >= 0), "keys not sorted"
+                assert np.unique(keys).size > n // 12
+                del keys
+                s2 = c.download()
+            c.set_by_index(0, vel=kick)
+            q0 = c.sort_stats()
+            c.step(2e-5, 10)
+            q1 = c.sort_stats()
+            st = c.download(want=("pos", "vel", "density"))
+            runs.append((st, c.keys(), q1["merges"] - q0["merges"], q1["movers_total"] - q0["movers_total"]))
+    # ---- two steps from the lattice: sanity everywhere, the corner block against the oracle ----
+    assert np.isfinite(s2["pos"]).all() and np.isfinite(s2["vel"]).all()
+    assert np.isfinite(s2["density"]).all() and s2["density"].min() > 0
+    assert np.all(np.abs(s2["pos"]) <= box / 2)
+    ii = np.arange(28, dtype=np.int64)
+    sub = (ii[None, None, :] + nx * (ii[None, :, None] + ny * ii[:, None, None])).ravel()     # ix, iy, iz < 28
+    o = oracle.Oracle(p0[sub], np.zeros((sub.size, 3), np.float32), cfg["box"], cfg["grid"], oracle.CELL_LINEAR)
+    o.step(DT, 2)
+    so = o.state()
+    o.close()
+    ix, iy, iz = sub % nx, (sub // nx) % ny, sub // (nx * ny)
+    inner = (ix < 22) & (iy < 22) & (iz < 22)                      # >= 2 cells inside the cut faces
+    g = sub[inner]
+    rel = s2["density"][g] / so["density"][inner] - 1
+    assert np.abs(rel).max() <= 2e-2 and np.sqrt(np.mean(rel ** 2)) <= 4e-3, (np.abs(rel).max(), np.sqrt(np.mean(rel ** 2)))
+    assert np.abs(s2["vel"][g] - so["vel"][inner]).max() <= 5e-3 * np.abs(so["vel"][inner]).max()
+    assert np.abs(s2["pos"][g] - so["pos"][inner]).max() <= 2e-6 * box
+    del s2, p0
+    # ---- merge path == full radix sort, at size, with particles changing cell ----
+    (sa, ka, merges_a, movers_a), (sb, kb, merges_b, _) = runs
+    assert merges_a == 10 and merges_b == 0
+    assert movers_a > 20000, movers_a          # 4 M kicked particles, a quarter of a cell in 10 steps
+    assert np.array_equal(ka, kb)
+    for k in ("pos", "vel", "density"):
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.isfinite(sa["vel"]).all() and (sa["density"] > 0).all()

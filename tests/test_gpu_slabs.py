@@ -1,7 +1,12 @@
 """GPU: the z-slab path through its product entry point, sph_slab_step (csrc/sph_slab.hip, C ABI): one call per rank
 and step queues sort, migrants, halo A, density, halo B and the fused force pass on two HIP streams.  Several slabs
-share the one GPU of the test box as in-process ranks (one thread each); the transport is the host-staged test
-transport over LocalComm -- on an N-GPU node the same step runs over RCCL (sph_rccl_transport_create)."""
+share the one GPU of the test box as in-process ranks (one thread each).  Two transports:
+  * "local": DEVICE pointers, copies queued on the comm stream behind the sender's event (sph_local_transport_create)
+    -- the product branch of slab_exchange (host_buffers = 0), the one RCCL takes on an N-GPU node: nothing drains a
+    stream inside an exchange, so a missing event edge between the two streams shows up as a wrong result here;
+  * "host": pinned host buffers handed to a Python callback (LocalComm) -- the branch the multi-process rehearsal over
+    gloo uses.
+The RCCL neighbour exchange itself needs >= 2 GPUs and has not run (only its one-rank self-send test below)."""
 import threading
 
 import numpy as np
@@ -14,16 +19,25 @@ pytestmark = pytest.mark.gpu
 DT = 5e-7
 
 
-def _run_slabs(world, box, grid, steps, particles=None, lattice=None):
+def _comm(hub, dev_hub, r):
+    comm = slab.LocalComm(hub, r)
+    comm.local_hub = dev_hub
+    return comm
+
+
+def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport="local", rebalance_every=0, expect_error=False):
     hub = slab.LocalComm.Hub(world)
+    dev_hub = capi.LocalHub(world, timeout_s=60) if transport == "local" else None
     results, errors = [None] * world, []
 
     def rank_main(r):
         try:
-            sim = slab.NativeSlabSimulation(slab.LocalComm(hub, r), box, grid, device_index=0, transport="host",
+            sim = slab.NativeSlabSimulation(_comm(hub, dev_hub, r), box, grid, device_index=0, transport=transport,
                                             particles=particles, lattice=lattice)
-            sim.run(DT, steps)
-            results[r] = (sim.gather_state(), dict(sim.stats), sim.cuts, sim.engine.n)
+            cuts0 = list(sim.cuts)
+            sim.run(DT, steps, rebalance_every=rebalance_every)
+            sim.sync()
+            results[r] = (sim.gather_state(), dict(sim.stats), sim.cuts, sim.engine.n, cuts0)
             sim.close()
         except BaseException as e:     # noqa: BLE001
             errors.append(e)
@@ -32,6 +46,10 @@ def _run_slabs(world, box, grid, steps, particles=None, lattice=None):
     threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in threads: t.start()
     for t in threads: t.join(timeout=900)
+    if dev_hub is not None:
+        dev_hub.close()
+    if expect_error:
+        return errors
     assert not errors, errors
     return results
 
@@ -43,11 +61,11 @@ def _whole_domain(pos, vel, box, grid, steps):
         return c.download()
 
 
-@pytest.mark.parametrize("case,world", [("up", 3), ("shear", 4)])
-def test_slabs_with_migration_match_whole_domain(case, world):
+@pytest.mark.parametrize("case,world,transport", [("up", 3, "local"), ("shear", 4, "local"), ("up", 3, "host")])
+def test_slabs_with_migration_match_whole_domain(case, world, transport):
     pos, vel, box, grid = make_case(case)
     steps = 24
-    res = _run_slabs(world, box, grid, steps, particles=(pos, vel))
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport)
     st = res[0][0]
     ref = _whole_domain(pos, vel, box, grid, steps)
     assert sum(r[1]["migrants"] for r in res) > 0
@@ -93,7 +111,7 @@ def test_c2_in_four_slabs_matches_whole_domain():
     cfg = ic.CONFIGS["C2"]
     steps = 3
     res = _run_slabs(4, cfg["box"], cfg["grid"], steps, lattice=cfg["lattice"])
-    st, _, cuts, _ = res[0]
+    st, _, cuts, _, _ = res[0]
     counts = [r[3] for r in res]
     assert sum(counts) == 262144 and max(counts) - min(counts) <= 2 * 64 * 64 * 2, counts
     pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
@@ -110,11 +128,12 @@ def test_weak_scaling_geometry_in_four_slabs():
     cfg = ic.weak_scaling_config(4, per_gpu=(32, 32, 32))
     hub_world, steps = 4, 3
     hub = slab.LocalComm.Hub(hub_world)
+    dev_hub = capi.LocalHub(hub_world, timeout_s=60)
     results, errors = [None] * hub_world, []
 
     def rank_main(r):
         try:
-            sim = slab.NativeSlabSimulation(slab.LocalComm(hub, r), cfg["box"], cfg["grid"], device_index=0, transport="host",
+            sim = slab.NativeSlabSimulation(_comm(hub, dev_hub, r), cfg["box"], cfg["grid"], device_index=0, transport="local",
                                             lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"])
             sim.run(DT, steps)
             results[r] = (sim.gather_state(), sim.cuts, sim.engine.n)
@@ -126,6 +145,7 @@ def test_weak_scaling_geometry_in_four_slabs():
     threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(hub_world)]
     for t in threads: t.start()
     for t in threads: t.join(timeout=900)
+    dev_hub.close()
     assert not errors, errors
     st, cuts, _ = results[0]
     assert cuts == [0, 16, 32, 48, cfg["grid"][2]]
@@ -177,36 +197,129 @@ def test_slab_entry_points_directly():
         assert c.n == len(mine) - want[3] and c.slab_counts()[0] == want[0]
 
 
-def test_rebalance_on_gpu_engines():
+@pytest.mark.parametrize("transport", ["local", "host"])
+def test_rebalance_on_gpu_engines(transport):
     """slab.SlabSimulation.rebalance() with the product engine: the fluid drifts out of its slabs, the
     cuts follow, whole layers change owner, the physics matches the whole-domain context."""
     pos, vel, box, grid = make_case("up")
     vel[:, 2] = 12000.0
     world, steps = 3, 65
-    hub = slab.LocalComm.Hub(world)
-    results, errors = [None] * world, []
-
-    def rank_main(r):
-        try:
-            sim = slab.NativeSlabSimulation(slab.LocalComm(hub, r), box, grid, device_index=0, transport="host",
-                                            particles=(pos, vel))
-            cuts0 = list(sim.cuts)
-            sim.run(DT, steps, rebalance_every=20)
-            results[r] = (sim.gather_state(), dict(sim.stats), cuts0, list(sim.cuts), sim.engine.n)
-            sim.close()
-        except BaseException as e:     # noqa: BLE001
-            errors.append(e)
-            hub.bar.abort()
-
-    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
-    for t in threads: t.start()
-    for t in threads: t.join(timeout=900)
-    assert not errors, errors
-    st, stats, cuts0, cuts1, _ = results[0]
+    results = _run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, rebalance_every=20)
+    st, stats, cuts1, _, cuts0 = results[0]
     assert stats.get("rebalances", 0) >= 1 and cuts1 != cuts0
-    owned = [r[4] for r in results]
+    owned = [r[3] for r in results]
     assert sum(owned) == pos.shape[0] and max(owned) <= 1.35 * pos.shape[0] / world, owned
     ref = _whole_domain(pos, vel, box, grid, steps)
+    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
+    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def _far_case():
+    """make_case's block at rest, except 20 particles of the two lattice layers under the first cut (cell layer 3,
+    the top layer of slab 0 of 3): they fly up at 2.8e5 -- 0.14 = 2.24 cell layers per step."""
+    pos, vel, box, grid = make_case("up")
+    vel[:] = 0.0
+    idx = np.arange(pos.shape[0])
+    iz = idx // (12 * 12)
+    fast = np.concatenate([np.nonzero(iz == 7)[0][::15][:10], np.nonzero(iz == 6)[0][::15][:10]])
+    vel[fast, 2] = 2.8e5
+    return pos, vel, box, grid, fast
+
+
+def test_particle_crossing_two_layers_in_one_step():
+    """The slab twin of test_gpu_edge_cases.py::test_faster_than_one_cell_per_step.  A leaver that crossed MORE than
+    one cell layer does not land in the neighbour's boundary layer: its sender counts it as `far` in the migrant
+    header, the receiver then takes the step's arrivals in through the pass over all particles (any key is fine
+    there) instead of merging them into the boundary layer in place, counts its layers again (one more wait on that
+    step only), and both sides size their ghost messages accordingly.  Result: the whole-domain physics."""
+    pos, vel, box, grid, fast = _far_case()
+    steps, world = 4, 3
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel))
+    assert res[0][2] == [0, 4, 8, 64]
+    far = sum(r[1]["far_steps"] for r in res)
+    assert far >= 1, [r[1] for r in res]
+    for r in res:
+        assert r[1]["host_waits"] == steps + r[1]["far_steps"], r[1]
+    st = res[0][0]
+    ref = _whole_domain(pos, vel, box, grid, steps)
+    assert np.abs(ref["pos"][fast, 2] - pos[fast, 2]).min() > 0.14         # more than two cell layers (viscosity brakes them fast)
+    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
+    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def test_a_stopped_neighbour_is_an_error_not_a_hang():
+    """Rank 1 never steps.  Rank 0's exchange (and with it the step's one wait) is bounded: it returns an error that
+    names the missing message instead of spinning for ever."""
+    pos, vel, box, grid = make_case("up")
+    world = 2
+    hub = slab.LocalComm.Hub(world)
+    dev_hub = capi.LocalHub(world, timeout_s=2.0)
+    ready = threading.Barrier(world)
+    errors = [None] * world
+
+    def rank_main(r):
+        sim = None
+        try:
+            sim = slab.NativeSlabSimulation(_comm(hub, dev_hub, r), box, grid, device_index=0, transport="local",
+                                            particles=(pos, vel))
+            capi._check(capi.load().sph_slab_set_wait_timeout(sim._slab, 2.0))
+            ready.wait()
+            if r == 0:
+                sim.run(DT, 1)
+        except BaseException as e:     # noqa: BLE001
+            errors[r] = e
+        finally:
+            if r == 0:
+                done.set()
+            else:
+                done.wait(timeout=60)          # rank 1 keeps its slab alive until rank 0 has given up
+            if sim is not None:
+                sim.close()
+
+    done = threading.Event()
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=120)
+    dev_hub.close()
+    assert errors[1] is None, errors
+    assert isinstance(errors[0], capi.SphError) and ("never sent" in str(errors[0]) or "no migrant header" in str(errors[0])), errors
+
+
+def test_eight_slabs_on_one_gpu():
+    """The 8-rank layout of the metric's strong-scaling point in small (BASELINE config 2 cut into 8 slabs of 4 cell
+    layers): every slab keeps >= 2 layers, counts are balanced, the result is the whole-domain result."""
+    cfg = ic.CONFIGS["C2"]
+    steps = 3
+    res = _run_slabs(8, cfg["box"], cfg["grid"], steps, lattice=cfg["lattice"])
+    st, _, cuts, _, _ = res[0]
+    assert len(cuts) == 9 and all(b - a >= slab.MIN_SLAB_LAYERS for a, b in zip(cuts, cuts[1:])), cuts
+    counts = [r[3] for r in res]
+    assert sum(counts) == 262144 and max(counts) - min(counts) <= 2 * 64 * 64, counts
+    assert all(r[1]["host_waits"] == steps for r in res)
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
+    ref = _whole_domain(pos, vel, cfg["box"], cfg["grid"], steps)
+    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * 8.0
+    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def test_a_burst_of_leavers_takes_the_second_migrant_message():
+    """More than 255 particles cross one cut in one step: the fixed-size migrant message carries the first 255, the
+    rest follows in an exact-size message (both ends know both counts from the headers)."""
+    box, grid = (4.0, 4.0, 4.0), (64, 64, 64)
+    steps, world = 3, 3
+    # a 24 x 24 x 24 block: 576 particles per lattice layer.  The lattice layers just under the two cuts (cell layers 4
+    # and 8: lattice layers 7 and 15 sit at 3.75 / 7.75 cells) move 0.32 cells per step: they cross at the first step
+    pos2, vel2 = ic.dam_break_lattice((24, 24, 24), box, jitter=True)
+    iz2 = np.arange(pos2.shape[0]) // (24 * 24)
+    vel2[(iz2 == 7) | (iz2 == 15), 2] = 4.0e4
+    res = _run_slabs(world, box, grid, steps, particles=(pos2, vel2))
+    assert sum(r[1]["rest_messages"] for r in res) >= 2, [r[1] for r in res]
+    assert sum(r[1]["migrants"] for r in res) >= 2 * 576
+    st = res[0][0]
+    ref = _whole_domain(pos2, vel2, box, grid, steps)
     assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
     assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
     assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5

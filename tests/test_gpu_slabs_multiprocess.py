@@ -47,3 +47,40 @@ def test_slab_processes_match_whole_domain(case, world, tmp_path):
     assert np.abs(got["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
     assert np.abs(got["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
     assert np.abs(got["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def _bench_line(cmd, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_rehearsal_eight_ranks_on_one_gpu():
+    """`bench.py --gpus 8` is STRONG scaling of one dam (BASELINE's metric: the same particles on 1/2/4/8 GPUs).  Rehearsed at
+    reduced size (config 2: 262,144 particles) with the 8 ranks as 8 threads of one process on the one GPU -- a GPU box
+    admits at most 6 processes on its card -- over the device-to-device transport: launcher path, cuts, slab-by-slab
+    lattice, run-up with re-balancing checks, the native step, the JSON line."""
+    out = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--one-gpu", "--transport", "local",
+                       "--workload", "C2", "--runup", "300", "--steps", "5", "--warmup", "2", "--no-cpu"])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong"
+    assert out["config"]["particles"] == 262144 == out["owned_sum"]
+    assert len(out["config"]["layers_per_slab"]) == 8 and min(out["config"]["layers_per_slab"]) >= 2
+    assert out["config"]["ranks_as"].startswith("threads")
+    assert out["slab_stats_rank0"]["host_waits"] == out["slab_stats_rank0"]["steps"]
+    assert out["imbalance"] < 1.1
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+def test_bench_strong_scaling_rehearsal_four_processes():
+    """The same bench as 4 PROCESSES under torch.distributed.run (host-staged messages over gloo): the launch shape the
+    driver uses, `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`."""
+    out = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                       "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--one-gpu",
+                       "--transport", "host", "--workload", "C2", "--runup", "200", "--steps", "5", "--warmup", "2", "--no-cpu"])
+    assert out["n_gpus"] == 4 and out["scaling"] == "strong"
+    assert out["config"]["particles"] == 262144 == out["owned_sum"]
+    assert min(out["config"]["layers_per_slab"]) >= 2 and out["config"]["ranks_as"] == "processes"
