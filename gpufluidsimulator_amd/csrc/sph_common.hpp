@@ -114,6 +114,12 @@ struct sph_ctx {
     bool sort_merge_always = false; // sph_set_sort_mode(c, 2): merge whatever the mover count (tests)
     bool order_valid = false;       // [own_off, own_off+n) is still in the order of the last sort, keyS = its keys
     bool last_sort_skipped = false;
+    // A slab context is stepped by sph_slab_step, whose host waits for the device once per step: the host cannot run
+    // ahead, so the event ring that bounds the run-ahead (mm_done) is not needed, and the "count is ready" event
+    // (mm_counted) only while the fluid is at rest (the skip it serves needs a count of 0).  Every event recorded on
+    // the stream costs the device ~5 us of idle at the next dispatch: 10 us per step at 2 M particles per GPU.
+    bool host_paced = false;
+    bool mm_counted_valid = false;  // mm_counted was recorded behind the scan of the CURRENT marks
     uint64_t sort_merges = 0, sort_calls = 0, sort_skips = 0;   // skips: merges with no mover at all (nothing done)
     uint64_t* mm_mask = nullptr;    // one bit per slot: key changed since the last sort
     uint32_t* mm_M64 = nullptr;     // movers before each 64-slot chunk

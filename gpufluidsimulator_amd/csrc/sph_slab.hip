@@ -8,7 +8,7 @@
 //   hash + sort owned particles
 //   k_slab_bounds_pack: layer bounds, leavers
 //     + header {#leavers, #boundary, #far}     -> exchange MIGRANTS (header + 255 inline records: 8 KB)
-//   density of the DEEP interior (layers >= 3        k_slab_post_headers: own bounds + the neighbours' headers
+//   density of the DEEP interior (layers >= 4        k_slab_post_headers: own bounds + the neighbours' headers
 //     from either cut; its slot range is read        into mapped host memory, then a sequence word
 //     from DEVICE memory: the host does not
 //     know the bounds yet)
@@ -46,7 +46,7 @@ namespace sph {
 enum {
     HL_LB = 0,        // [0..3] own layer bounds: first slot (relative to the owned range) with a key >= layer, 2*layer,
                       //        (zl-2)*layer, (zl-1)*layer
-    HL_DEEP = 4,      // [4..5] the deep interior [first key >= 3*layer, first key >= (zl-3)*layer), ABSOLUTE slots
+    HL_DEEP = 4,      // [4..5] the deep interior [first key >= 4*layer, first key >= (zl-4)*layer), ABSOLUTE slots
     HL_FAR = 6,       // [6..7] my leavers (down, up) that are NOT in the neighbour's adjacent layer (crossed > 1 layer)
     HL_HDR_LO = 8,    // [8..11]  header received from the lower neighbour {#arrivals, #its boundary layer, #far, 0}
     HL_HDR_HI = 12,   // [12..15] ... from the upper neighbour
@@ -84,25 +84,48 @@ __global__ void k_slab_bounds(const uint32_t* __restrict__ keys, uint32_t n, uin
 // into my ghost layer, so only its position can tell).  The block that finishes last writes record 0 of both
 // messages, the header {#leavers, #particles that stay in my boundary layer on that side, #far leavers, 0}, and the
 // device words the deep-interior density launch reads its slot range from.
+// first slot in [0, n) with keys[slot] >= v, by ONE WAVE: 64 probes per round at equal spacing, 4 rounds for 16.7 M keys
+// (a lane-per-target binary search is 24 DEPENDENT loads, ~0.8 us each from a cold L2: this kernel sits between the
+// sort and the migrant exchange, on every rank's critical path)
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t* __restrict__ keys, uint32_t n, uint32_t v) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lo = 0, hi = n;                              // invariant: keys[lo - 1] < v <= keys[hi] (virtual ends)
+    while (hi - lo > 1u) {
+        const uint32_t len = hi - lo, step = (len + 63u) / 64u;
+        const uint32_t p = lo + min((lane + 1u) * step, len) - 1u;          // probes lo+step-1, lo+2 step-1, ..., hi-1
+        const bool less = keys[p] < v;
+        const uint64_t m = __ballot(less);                                   // monotone: a prefix of the lanes
+        const uint32_t k = (uint32_t)__popcll(m);                            // probes 0 .. k-1 are < v
+        const uint32_t new_lo = lo + min(k * step, len);
+        const uint32_t new_hi = k >= 64u ? hi : lo + min((k + 1u) * step, len) - 1u;
+        lo = new_lo; hi = max(new_hi, new_lo);
+        if (k >= 64u) break;
+    }
+    if (hi - lo == 1u) lo += keys[lo] < v ? 1u : 0u;
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __restrict__ keys, const float4* __restrict__ posi,
                                                           const float4* __restrict__ velr, uint32_t n, uint32_t own_off,
                                                           uint32_t layer, uint32_t cap, GridDesc g,
                                                           uint32_t* __restrict__ dl, float4* __restrict__ out_lo,
                                                           float4* __restrict__ out_hi) {
-    __shared__ uint32_t s_lb[6];
+    __shared__ uint32_t s_lb[8];
     __shared__ uint32_t s_last;
     const uint32_t zl = g.zl;
-    if (threadIdx.x < 6) {
-        // deep interior = local layers [3, zl-3); empty for slabs of fewer than 5 owned layers
-        const uint32_t d0 = min(3u, zl - 1u), d1 = zl >= 6u ? zl - 3u : d0;
-        const uint32_t targets[6] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer, d0 * layer, max(d1, d0) * layer};
-        const uint32_t v = targets[threadIdx.x];
-        uint32_t lo = 0, hi = n;
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (keys[mid] < v) lo = mid + 1; else hi = mid;
+    {
+        // deep interior = local layers [4, zl-4): owned layers at least THREE layers away from either cut (empty for
+        // slabs of fewer than 7 owned layers).  Two would do for the density itself (arrivals land in the boundary
+        // layer, the ghosts beyond it); the third keeps the force pass of the boundary layers -- which, rounded to whole
+        // 64-slot chunks, reaches a few slots into the second layer and so reads densities of the third -- independent of
+        // what the deep launch writes: the two run on different streams without an event between them.
+        const uint32_t d0 = min(4u, zl - 1u), d1 = zl >= 8u ? zl - 4u : d0;
+        const uint32_t targets[8] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer, d0 * layer, max(d1, d0) * layer, 0u, 0u};
+        const uint32_t wave = threadIdx.x >> 6;
+        for (uint32_t t = wave; t < 6u; t += 4u) {                          // wave w: targets w and w + 4
+            const uint32_t r = wave_lower_bound(keys, n, targets[t]);
+            if ((threadIdx.x & 63u) == 0u) s_lb[t] = r;
         }
-        s_lb[threadIdx.x] = lo;
     }
     __syncthreads();
     const uint32_t lb0 = s_lb[0], lb3 = s_lb[3];
@@ -119,17 +142,19 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
         out_hi[2 + 2 * k] = p; out_hi[3 + 2 * k] = velr[lb3 + k];
         far_h = (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]) != g.z_off + (int)zl - 1;   // global layer z_hi
     }
+    // far counts and the "last block" ticket: RETURNING device-scope atomics (performed at the memory side; the
+    // returned value is awaited, so an add has been performed before its wave passes the barrier below) -- no fence
     const uint64_t bl = __ballot(far_l), bh = __ballot(far_h);
+    uint32_t seen = 0;
     if ((threadIdx.x & 63u) == 0) {
-        if (bl) atomicAdd(&dl[DL_CTR + 0], (uint32_t)__popcll(bl));
-        if (bh) atomicAdd(&dl[DL_CTR + 1], (uint32_t)__popcll(bh));
+        if (bl) seen += atomicAdd(&dl[DL_CTR + 0], (uint32_t)__popcll(bl));
+        if (bh) seen += atomicAdd(&dl[DL_CTR + 1], (uint32_t)__popcll(bh));
     }
-    __threadfence();                       // the counts and the records before the ticket
+    asm volatile("" :: "v"(seen));                                        // keep the returns (and their waits)
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(&dl[DL_CTR + 2], 1u) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
     if (!s_last || threadIdx.x != 0) return;
-    __threadfence();
     const uint32_t far_lo = atomicExch(&dl[DL_CTR + 0], 0u), far_hi = atomicExch(&dl[DL_CTR + 1], 0u);
     atomicExch(&dl[DL_CTR + 2], 0u);                                                   // re-armed for the next step
     out_lo[0] = make_float4(__uint_as_float(m_lo), __uint_as_float(s_lb[1] - lb0), __uint_as_float(far_lo), 0.f);
@@ -146,16 +171,17 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
 // sequence word last (a system-scope fence in between: the host polls that word and then reads the rest)
 __global__ void k_slab_post_headers(const uint32_t* __restrict__ dl, const float4* __restrict__ hdr_lo,
                                     const float4* __restrict__ hdr_hi, volatile uint32_t* __restrict__ host, uint32_t seq) {
-    if (threadIdx.x != 0) return;
-    for (int t = 0; t < 8; t++) host[t] = dl[t];
-    for (int side = 0; side < 2; side++) {
-        const float4* h = side == 0 ? hdr_lo : hdr_hi;
-        const float4 v = h ? h[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-        volatile uint32_t* o = host + (side == 0 ? HL_HDR_LO : HL_HDR_HI);
-        o[0] = __float_as_uint(v.x); o[1] = __float_as_uint(v.y); o[2] = __float_as_uint(v.z); o[3] = 0u;
+    const uint32_t t = threadIdx.x;                       // one wave: a lane per word, all stores in flight together
+    if (t < 8u) host[t] = dl[t];
+    else if (t < 16u) {
+        const float4* h = t < 12u ? hdr_lo : hdr_hi;
+        const uint32_t w = (t - 8u) & 3u;
+        const uint32_t* hw = reinterpret_cast<const uint32_t*>(h);
+        host[t] = (h && w < 3u) ? hw[w] : 0u;
     }
     __threadfence_system();
-    host[HL_SEQ] = seq;
+    __builtin_amdgcn_wave_barrier();
+    if (t == 0u) host[HL_SEQ] = seq;
 }
 
 // both boundary layers -> their halo messages, one launch
@@ -542,6 +568,13 @@ int after_comm(sph_slab* s) {
     return SPH_OK;
 }
 
+// launchers use the context's stream: this runs them on the comm stream instead
+struct OnComm {
+    sph_ctx* c; hipStream_t saved;
+    OnComm(sph_slab* s) : c(s->c), saved(s->c->stream) { c->stream = s->comm; }
+    ~OnComm() { c->stream = saved; }
+};
+
 // the step's one wait: poll the sequence word the comm stream writes behind the migrant exchange.  Polled, not slept
 // on (hipEventSynchronize hands the thread to the kernel and comes back tens of microseconds late); BOUNDED: a
 // neighbour that left its step with an error never sends, and this rank must report that instead of spinning forever.
@@ -592,9 +625,9 @@ int slab_step_once(sph_slab* s, float dt) {
     SPH_HIP(hipGetLastError());
     rc = after_main(s); if (rc) return rc;
     // ---- the density of the deep interior goes into the main stream's queue BEFORE the host waits: its slot range
-    //      comes from device memory (k_slab_bounds_pack wrote it).  Layers >= 3 from either cut see neither ghosts nor
+    //      comes from device memory (k_slab_bounds_pack wrote it).  Layers >= 4 from either cut see neither ghosts nor
     //      arrivals (those land in the boundary layers), and no slot of them moves before the force pass.
-    bool deep_valid = c->grid.zl >= 7u;
+    bool deep_valid = c->grid.zl >= 9u;
     if (deep_valid) {
         PhaseTimer t(c, SPH_PH_DENS);
         rc = launch_density_dev_range(c, s->d_lb + DL_DEEP, n0);
@@ -635,10 +668,21 @@ int slab_step_once(sph_slab* s, float dt) {
         if (rc) return rc;
         s->rest_msgs++;
     }
-    // ---- drop the leavers (their cells hold nothing else until the ghosts arrive) ------------------------------------
+    // A step without arrivals (the usual one) hands the rest of the halo work to the COMM stream at once: the main
+    // stream is busy with the deep density, and pack -> HALO A -> ghost unpack need nothing from it (the slices they
+    // read have been final since the sort).  The ghosts are then in place when the deep density ends, and everything
+    // that is left of the density pass is ONE launch.
+    const bool early_halo = deep_valid && in_lo == 0 && in_hi == 0;
+    // ---- drop the leavers (their cells hold nothing else until the ghosts arrive; the clearing must precede the
+    //      ghost cells, so it runs on the stream that builds those) ---------------------------------------------------
     if (m_lo || m_hi) {
         if (c->cells_valid && c->cells_lo == c->own_off && c->cells_hi == c->own_off + c->n) {
-            rc = launch_cells_clear_2ranges(c, c->own_off, c->own_off + m_lo, c->own_off + c->n - m_hi, c->own_off + c->n);
+            if (early_halo) {
+                OnComm on(s);
+                rc = launch_cells_clear_2ranges(c, c->own_off, c->own_off + m_lo, c->own_off + c->n - m_hi, c->own_off + c->n);
+            } else {
+                rc = launch_cells_clear_2ranges(c, c->own_off, c->own_off + m_lo, c->own_off + c->n - m_hi, c->own_off + c->n);
+            }
             if (rc) return rc;
             c->cells_lo += m_lo;
             c->cells_hi -= m_hi;
@@ -739,22 +783,24 @@ int slab_step_once(sph_slab* s, float dt) {
                     c->own_off + n + g_hi <= c->tot, SPH_E_CAPACITY,
                 "rank %d: a boundary layer of %u/%u (ghosts %u/%u) exceeds the ghost capacity %u", s->rank, h_lo, h_hi, g_lo, g_hi,
                 s->gcap);
-    // ---- halo A: boundary layers -> neighbours' ghost layers; the interior density runs meanwhile ------------------
-    if (h_lo + h_hi)
-        hipLaunchKernelGGL(k_slab_pack2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, c->stream, c->posi, c->velr, c->own_off, h_lo,
-                           c->own_off + n - h_hi, h_hi, s->halo_send[0], s->halo_send[1]);
-    SPH_HIP(hipGetLastError());
-    rc = after_main(s); if (rc) return rc;                      // the comm stream may start once the slices are packed
     // interior = everything but the two boundary layers, in whole 64-slot chunks (the fused force pass marks the
-    // movers of the next sort per chunk).  Queued BEFORE the transfers are handed to the transport: the main stream
-    // has the bulk of the step's work in its queue while the halo travels.  What the deep launch already did is left out.
+    // movers of the next sort per chunk)
     uint32_t a = c->own_off + ((h_lo + 63u) & ~63u), b = c->own_off + ((n - h_hi) & ~63u);
     if (b < a || a > c->own_off + n) { a = c->own_off; b = c->own_off; }     // a thin slab: everything is "boundary"
-    {
+    // ---- halo A: boundary layers -> neighbours' ghost layers -----------------------------------------------------------
+    hipStream_t pack_stream = early_halo ? s->comm : c->stream;
+    if (h_lo + h_hi)
+        hipLaunchKernelGGL(k_slab_pack2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, pack_stream, c->posi, c->velr, c->own_off, h_lo,
+                           c->own_off + n - h_hi, h_hi, s->halo_send[0], s->halo_send[1]);
+    SPH_HIP(hipGetLastError());
+    if (!early_halo) {
+        rc = after_main(s); if (rc) return rc;                  // the comm stream may start once the slices are packed
+        // the interior density runs while the halo travels: queued BEFORE the transfers are handed to the transport.
+        // What the deep launch already did is left out.
         PhaseTimer t(c, SPH_PH_DENS);
         rc = deep_valid ? launch_density_hole(c, a, b, deep_lo, deep_hi) : launch_density_range(c, a, b);
+        if (rc) return rc;
     }
-    if (rc) return rc;
     rc = slab_exchange(s, SPH_TAG_HALO_A, s->halo_send[0], h_lo * rec, s->halo_recv[0], g_lo * rec, s->halo_send[1], h_hi * rec,
                        s->halo_recv[1], g_hi * rec);
     if (rc) return rc;
@@ -768,16 +814,40 @@ int slab_step_once(sph_slab* s, float dt) {
     s->ghosts += g_lo + g_hi;
     c->cells_lo = c->own_off - g_lo; c->cells_hi = c->own_off + n + g_hi; c->cells_valid = true;
     c->stage = sph_ctx::ST_CELLS;
-    rc = after_comm(s); if (rc) return rc;
-    { PhaseTimer t(c, SPH_PH_DENS); rc = launch_density_hole(c, c->own_off, c->own_off + n, a, b); }   // the two boundary layers
-    if (rc) return rc;
+    if (early_halo) {
+        // all that is left of the density pass (the boundary layers and the two layers next to them), queued on the COMM
+        // stream behind the ghosts: it runs BESIDE the tail of the deep launch instead of behind it (a launch this
+        // small is one partly filled round of workgroups; back to back the two launches cost a round more).  The
+        // boundary layers' (rho, p) come out of this launch, so their halo-B message is packed on the same stream:
+        // after the event behind k_slab_bounds_pack the comm stream never waits for the main stream again, and every
+        // event recorded on a stream costs the device ~5 us of idle at the next dispatch.
+        OnComm on(s);
+        {
+            PhaseTimer t(c, SPH_PH_DENS);
+            rc = launch_density_hole(c, c->own_off, c->own_off + n, deep_lo, deep_hi);
+            if (rc) return rc;
+        }
+        if (h_lo + h_hi)
+            hipLaunchKernelGGL(k_slab_copy_dp2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, c->stream, c->dp + c->own_off,
+                               s->dens_send[0], h_lo, c->dp + c->own_off + n - h_hi, s->dens_send[1], h_hi);
+        SPH_HIP(hipGetLastError());
+    }
+    rc = after_comm(s); if (rc) return rc;                      // main: the ghosts (and, early, the boundary densities) are in
+    if (!early_halo) {
+        {
+            PhaseTimer t(c, SPH_PH_DENS);                        // the two boundary layers
+            rc = launch_density_hole(c, c->own_off, c->own_off + n, a, b);
+            if (rc) return rc;
+        }
+        // ---- halo B: (density, pressure) of the same boundary particles, same order ---------------------------------
+        if (h_lo + h_hi)
+            hipLaunchKernelGGL(k_slab_copy_dp2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, c->stream, c->dp + c->own_off,
+                               s->dens_send[0], h_lo, c->dp + c->own_off + n - h_hi, s->dens_send[1], h_hi);
+        SPH_HIP(hipGetLastError());
+        rc = after_main(s); if (rc) return rc;
+    }
     c->have_dens = true;
-    // ---- halo B: (density, pressure) of the same boundary particles, same order; interior forces meanwhile ---------
-    if (h_lo + h_hi)
-        hipLaunchKernelGGL(k_slab_copy_dp2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, c->stream, c->dp + c->own_off, s->dens_send[0],
-                           h_lo, c->dp + c->own_off + n - h_hi, s->dens_send[1], h_hi);
-    SPH_HIP(hipGetLastError());
-    rc = after_main(s); if (rc) return rc;
+    // the interior forces run while halo B travels
     const bool mark = force_begin(c, true);
     { PhaseTimer t(c, SPH_PH_FORCE); rc = launch_force_range(c, a, b, true, true, true, dt, mark); }   // interior: queued before the transfer
     if (rc) return rc;
@@ -788,13 +858,19 @@ int slab_step_once(sph_slab* s, float dt) {
         hipLaunchKernelGGL(k_slab_copy_dp2, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->dens_recv[0],
                            c->dp + c->own_off - g_lo, g_lo, s->dens_recv[1], c->dp + c->own_off + n, g_hi);
     SPH_HIP(hipGetLastError());
-    rc = after_comm(s); if (rc) return rc;
-    { PhaseTimer t(c, SPH_PH_FORCE); rc = launch_force_hole(c, c->own_off, c->own_off + n, a, b, true, true, true, dt, mark); }
-    if (rc) return rc;
+    // the boundary layers' force pass: on the comm stream, behind the ghosts' (rho, p) -- beside the interior launch
+    // (it reads what that one reads and writes other slots of the ping-pong arrays), not behind it
+    {
+        OnComm on(s);
+        PhaseTimer t(c, SPH_PH_FORCE);
+        rc = launch_force_hole(c, c->own_off, c->own_off + n, a, b, true, true, true, dt, mark);
+        if (rc) return rc;
+    }
+    rc = after_comm(s); if (rc) return rc;                      // the mover count (force_finish) needs both launches
     force_finish(c, true, mark);
     c->have_force = c->have_coll = false;
-    // the comm stream must not start the next step's transfers into buffers the main stream still reads
-    rc = after_main(s); if (rc) return rc;
+    // (no event here: the comm stream's first action of the next step waits for an event the main stream records behind
+    // k_slab_bounds_pack, i.e. behind everything queued above)
     s->steps++;
     if (c->timing) { c->timed_steps++; if (c->events.size() > 3 * 4096) timing_collect(c); }
     return SPH_OK;
@@ -992,6 +1068,7 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
     }
     if (!ok) { set_error("sph_slab_create: allocation failed"); slab_free(s); return SPH_E_NOMEM; }
     for (int k = 0; k < HL_WORDS; k++) s->h_lb[k] = 0u;
+    ctx->host_paced = true;            // sph_slab_step waits for the device once per step
     *out = s;
     return SPH_OK;
 }
@@ -1002,6 +1079,7 @@ void sph_slab_destroy(sph_slab* s) {
     hipSetDevice(s->device);
     hipStreamSynchronize(s->comm);
     hipStreamSynchronize(s->c->stream);
+    s->c->host_paced = false;
     slab_free(s);
 }
 

@@ -129,10 +129,11 @@ template <int BITS>
 __global__ __launch_bounds__(SORT_THREADS) void k_os_hist(const uint32_t* __restrict__ keys, uint32_t n_arg,
                                                           const uint32_t* __restrict__ n_dev, uint32_t pass0,
                                                           uint32_t passes, uint32_t group_tiles,
-                                                          uint32_t* __restrict__ hist) {
+                                                          uint32_t* __restrict__ hist, uint32_t small_max) {
     constexpr int RADIX = 1 << BITS;
     __shared__ uint32_t h[4 * RADIX];
     const uint32_t n = sort_count(n_arg, n_dev);
+    if (n <= small_max) return;                              // k_os_small sorts it (small_max = 0: never)
     const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
     const uint32_t nchunks = (ntiles + OS_HIST_TILES - 1) / OS_HIST_TILES;
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -172,9 +173,11 @@ template <int BITS>
 __global__ __launch_bounds__(256) void k_os_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ base,
                                                  uint32_t* __restrict__ tot, uint32_t n_arg,
                                                  const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ tickets,
-                                                 uint32_t tickets_stride, uint32_t pass0, uint32_t group_tiles) {
+                                                 uint32_t tickets_stride, uint32_t pass0, uint32_t group_tiles,
+                                                 uint32_t small_max) {
     constexpr uint32_t RADIX = 1u << BITS;
     const uint32_t n = sort_count(n_arg, n_dev);
+    if (n <= small_max) return;                              // nothing was counted, no ticket was drawn
     const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
     const uint32_t ngroups = group_tiles == OS_ALL_TILES ? 1u : (ntiles + group_tiles - 1) / group_tiles;
     const uint32_t p = pass0 + blockIdx.y;
@@ -244,9 +247,10 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
                                                           uint32_t group_tiles, os_word* __restrict__ status,
                                                           uint32_t* __restrict__ status32,
                                                           uint32_t* __restrict__ ticket, uint32_t epoch,
-                                                          uint32_t* __restrict__ err) {
+                                                          uint32_t* __restrict__ err, uint32_t small_max) {
     constexpr int RADIX = 1 << BITS;
     constexpr int DPT = RADIX > PASS_THREADS ? RADIX / PASS_THREADS : 1;   // digits per thread: 1 or 2 (consecutive digits)
+    if (sort_count(n_arg, n_dev) <= small_max) return;      // k_os_small sorts it (block-uniform, before any barrier)
     static_assert(DPT <= 2, "a thread publishes at most two digits in one store");
     __shared__ uint32_t wh[PASS_WAVES][RADIX];      // per-wave digit counts -> running positions inside the tile
     __shared__ uint32_t s_delta[RADIX];             // global position minus LDS position of a digit's keys of this tile
@@ -532,6 +536,136 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
     }
 }
 
+// ---- the whole sort of up to one tile (4096 pairs) in ONE block ----------------------------------------------------------
+// The movers of a step are usually a few thousand (flowing C3 on 8 GPUs: ~5 000 per rank and step).  Sorting them with
+// the kernels above is P + 2 launches that each handle a single tile: ~10 us apiece of launch, prologue and latency
+// chain, 56 us per step -- 8 % of a 0.7 ms step.  Here one block of 1024 threads keeps the pairs in LDS and runs every
+// pass itself (the same stable ranking: rows of 64 keys in order, equal digits of a row by ballot match-any), then
+// -- the sorted movers still in LDS -- also ranks the coarse tile boundaries of the merge (k_mm_tile_rank's job).
+// The count lives on the device, so the generic kernels are still launched behind it; they, and this one, look at the
+// count first and leave at once when it is not theirs (count <= OS_SMALL_MAX: this kernel; else: the others).
+constexpr int SMALL_THREADS = 1024;
+constexpr int SMALL_WAVES = SMALL_THREADS / WAVE;                 // 16
+constexpr int SMALL_KPT = OS_TILE / SMALL_THREADS;                // 4 rows of 64 keys per wave
+constexpr uint32_t OS_SMALL_MAX = OS_TILE;
+// first r in [0, m) with (sk[r], sv[r]) >= (key, slot), the arrays in LDS
+__device__ __forceinline__ uint32_t small_lower_bound(const uint32_t* sk, const uint32_t* sv, uint32_t m, uint32_t key,
+                                                      uint32_t slot) {
+    uint32_t lo = 0, hi = m;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint32_t k = sk[mid];
+        if (k < key || (k == key && sv[mid] < slot)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(SMALL_THREADS) void k_os_small(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                            uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                            const uint32_t* __restrict__ n_dev, uint32_t n_cap, uint32_t passes,
+                                                            const uint32_t* __restrict__ A, uint32_t n_slots,
+                                                            uint32_t* __restrict__ tileL, uint32_t* __restrict__ tileA) {
+    constexpr int RADIX = 1 << BITS;
+    __shared__ uint32_t s_key[2][OS_TILE], s_val[2][OS_TILE];
+    __shared__ uint32_t wh[SMALL_WAVES][RADIX];
+    __shared__ uint32_t s_wtot[SMALL_WAVES];
+    const uint32_t m = min(*n_dev, n_cap);
+    if (m > OS_SMALL_MAX) return;                               // block-uniform, before any barrier
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t wbase = wave * (WAVE * SMALL_KPT);
+    uint32_t key[SMALL_KPT], val[SMALL_KPT];
+#pragma unroll
+    for (int t = 0; t < SMALL_KPT; t++) {
+        const uint32_t i = wbase + t * WAVE + lane;
+        key[t] = i < m ? kin[i] : 0xFFFFFFFFu;
+        val[t] = i < m ? vin[i] : 0u;
+    }
+    int cur = 0;
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t shift = p * BITS;
+        for (int d = threadIdx.x; d < SMALL_WAVES * RADIX; d += SMALL_THREADS) (&wh[0][0])[d] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < SMALL_KPT; t++)
+            wave_count_digit(wh[wave], (key[t] >> shift) & (RADIX - 1), wbase + t * WAVE + lane < m);
+        __syncthreads();
+        // per digit: exclusive offsets of the waves, then the digit's start in the tile
+        uint32_t cnt = 0;
+        const bool has_d = threadIdx.x < (uint32_t)RADIX;
+        if (has_d) {
+#pragma unroll
+            for (int w = 0; w < SMALL_WAVES; w++) { const uint32_t c = wh[w][threadIdx.x]; wh[w][threadIdx.x] = cnt; cnt += c; }
+        }
+        const uint32_t start = block_excl_scan<SMALL_WAVES>(cnt, s_wtot, nullptr);
+        if (has_d) {
+#pragma unroll
+            for (int w = 0; w < SMALL_WAVES; w++) wh[w][threadIdx.x] += start;
+        }
+        __syncthreads();
+        const lds_u32_ptr pos = (lds_u32_ptr)wh[wave];
+        const int nxt = cur ^ 1;
+#pragma unroll
+        for (int t = 0; t < SMALL_KPT; t++) {
+            const uint32_t i = wbase + t * WAVE + lane;
+            if (wbase + t * WAVE >= m) break;                   // wave-uniform: the rows behind the last pair
+            const bool valid = i < m;
+            const uint32_t d = (key[t] >> shift) & (RADIX - 1);
+            uint32_t dif_lo = 0u, dif_hi = 0u;
+#pragma unroll
+            for (int b = 0; b < BITS; b++) {
+                const uint32_t bm = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+                const uint64_t mm = __ballot(bm != 0u);
+                dif_lo |= (uint32_t)mm ^ bm;
+                dif_hi |= (uint32_t)(mm >> 32) ^ bm;
+            }
+            const uint64_t vmask = __ballot(valid);
+            const uint32_t peers_lo = ~dif_lo & (uint32_t)vmask, peers_hi = ~dif_hi & (uint32_t)(vmask >> 32);
+            const uint32_t rank = (uint32_t)__popc(peers_lo & (uint32_t)lt_mask) + (uint32_t)__popc(peers_hi & (uint32_t)(lt_mask >> 32));
+            uint32_t base = 0;
+            if (valid) base = pos[d];
+            os_wave_lds_order();
+            if (valid && rank == 0) pos[d] = base + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi);
+            os_wave_lds_order();
+            if (valid) { s_key[nxt][base + rank] = key[t]; s_val[nxt][base + rank] = val[t]; }
+        }
+        __syncthreads();
+        cur = nxt;
+#pragma unroll
+        for (int t = 0; t < SMALL_KPT; t++) {
+            const uint32_t i = wbase + t * WAVE + lane;
+            key[t] = i < m ? s_key[cur][i] : 0xFFFFFFFFu;
+            val[t] = i < m ? s_val[cur][i] : 0u;
+        }
+        // (the next pass's first barrier separates these reads from its writes into the other buffer's twin: the
+        //  ranking writes s_key[cur ^ 1], which nobody reads any more)
+    }
+#pragma unroll
+    for (int t = 0; t < SMALL_KPT; t++) {
+        const uint32_t i = wbase + t * WAVE + lane;
+        if (i < m) { kout[i] = key[t]; vout[i] = val[t]; }
+    }
+    if (passes == 0u) {                                          // (never: a key has at least one digit) keep LDS valid
+#pragma unroll
+        for (int t = 0; t < SMALL_KPT; t++) {
+            const uint32_t i = wbase + t * WAVE + lane;
+            if (i < m) { s_key[cur][i] = key[t]; s_val[cur][i] = val[t]; }
+        }
+        __syncthreads();
+    }
+    // the merge's coarse ranks, from the sorted movers in LDS (k_mm_tile_rank leaves at once for these counts)
+    if (A) {
+        const uint32_t ntiles = (n_slots + OS_TILE - 1) / OS_TILE;
+        for (uint32_t t = threadIdx.x; t <= ntiles; t += SMALL_THREADS) {
+            const uint32_t slot = t * OS_TILE;
+            const uint32_t a = t == ntiles ? 0xFFFFFFFFu : A[slot];
+            tileA[t] = a;
+            tileL[t] = t == ntiles ? m : small_lower_bound(s_key[cur], s_val[cur], m, a, slot);
+        }
+    }
+}
+
 // ---- reorder: gather the SoA payload into sorted order (full-sort path) -----------------------------
 __global__ __launch_bounds__(256) void k_reorder(const uint32_t* __restrict__ ks, const uint32_t* __restrict__ vs,
                                                  uint32_t n, const float4* __restrict__ posi,
@@ -619,27 +753,39 @@ int launch_hash(sph_ctx* c) {
 // LSD radix sort of (key, value) pairs over the context's significant key bits.  `first`: the values of
 // the first pass are the element indices (vin unused).  n_dev != null: the count lives on the device
 // (<= n) and `grid` blocks share the tiles by ticket.  Returns through kin/vin the buffers that hold the result.
+// what k_os_small also does for the merge: the coarse ranks of the tile boundaries (A = null: nothing)
+struct SmallTail {
+    const uint32_t* A = nullptr;
+    uint32_t n_slots = 0;
+};
+
+#ifndef SPH_OS_SMALL
+#define SPH_OS_SMALL 1          // 0: never take the one-block sort (A/B runs)
+#endif
 template <int BITS>
 static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, bool first, uint32_t passes,
-                           uint32_t*& kin, uint32_t*& vin, uint32_t*& kout, uint32_t*& vout) {
+                           uint32_t*& kin, uint32_t*& vin, uint32_t*& kout, uint32_t*& vout, const SmallTail& tail) {
     constexpr uint32_t RADIX = 1u << BITS;
+    // counts the device may hand to the one-block sort (only when the count lives on the device: the movers' sort)
+    const uint32_t small_max = (SPH_OS_SMALL && n_dev && !first) ? OS_SMALL_MAX : 0u;
+    const uint32_t* kin0 = kin; const uint32_t* vin0 = vin;
     const bool one_group = grid <= OS_ONE_GROUP_TILES;          // `grid` = tiles expected (exact, or from the hint)
     const uint32_t group_tiles = one_group ? OS_ALL_TILES : OS_GROUP;
     const uint32_t hist_grid = min(ceil_div(grid, OS_HIST_TILES), 4096u);
     const uint32_t gcap = c->os_groups_cap;                     // tickets: [pass][group]
     if (one_group) {                                            // every pass from one histogram of the input
         hipLaunchKernelGGL(k_os_hist<BITS>, dim3(hist_grid), dim3(SORT_THREADS), 0, c->stream, kin, n, n_dev, 0u, passes,
-                           group_tiles, c->os_hist);
+                           group_tiles, c->os_hist, small_max);
         hipLaunchKernelGGL(k_os_scan<BITS>, dim3(RADIX / 4, passes), dim3(256), 0, c->stream, c->os_hist, c->os_base, c->os_tot,
-                           n, n_dev, c->os_tickets, gcap, 0u, group_tiles);
+                           n, n_dev, c->os_tickets, gcap, 0u, group_tiles, small_max);
         SPH_HIP(hipGetLastError());
     }
     for (uint32_t p = 0; p < passes; p++) {
         if (!one_group) {                                       // the groups' counts of the keys as this pass finds them
             hipLaunchKernelGGL(k_os_hist<BITS>, dim3(hist_grid), dim3(SORT_THREADS), 0, c->stream, kin, n, n_dev, p, 1u,
-                               group_tiles, c->os_hist);
+                               group_tiles, c->os_hist, small_max);
             hipLaunchKernelGGL(k_os_scan<BITS>, dim3(RADIX / 4, 1), dim3(256), 0, c->stream, c->os_hist, c->os_base, c->os_tot,
-                               n, n_dev, c->os_tickets, gcap, p, group_tiles);
+                               n, n_dev, c->os_tickets, gcap, p, group_tiles, small_max);
             SPH_HIP(hipGetLastError());
         }
         // the epoch tags the look-back words of this pass: 19 bits in the grouped form (never 0: that is what a cleared
@@ -655,7 +801,7 @@ static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32
         hipLaunchKernelGGL((k_os_pass<BITS, F, G>), dim3(G ? min((grid + 7u) & ~7u, OS_PASS_GRID_MAX) : grid), dim3(PASS_THREADS), 0, c->stream, kin, vin, kout, vout, n, \
                            n_dev, p * BITS, c->os_base + p * 512u, c->os_tot + p * 512u, group_tiles, c->os_status,         \
                            c->os_status32, tk, epoch,                                                                    \
-                           c->os_err_dev)
+                           c->os_err_dev, small_max)
         if (first && p == 0) { if (one_group) SPH_OS_LAUNCH(true, false); else SPH_OS_LAUNCH(true, true); }
         else { if (one_group) SPH_OS_LAUNCH(false, false); else SPH_OS_LAUNCH(false, true); }
 #undef SPH_OS_LAUNCH
@@ -664,15 +810,22 @@ static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32
         t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
     }
+    if (small_max) {
+        // the one-block sort: from the ORIGINAL input into the buffers the passes above would have ended in (they left at
+        // once if this kernel takes the count, and this kernel leaves at once if it does not)
+        hipLaunchKernelGGL(k_os_small<BITS>, dim3(1), dim3(SMALL_THREADS), 0, c->stream, kin0, vin0, kin, vin, n_dev, n, passes,
+                           tail.A, tail.n_slots, c->mm_tileL, c->mm_tileA);
+        SPH_HIP(hipGetLastError());
+    }
     return SPH_OK;
 }
 
 static int radix_sort_pairs(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, bool first,
-                            uint32_t*& kin, uint32_t*& vin, uint32_t*& kout, uint32_t*& vout) {
+                            uint32_t*& kin, uint32_t*& vin, uint32_t*& kout, uint32_t*& vout, const SmallTail& tail = SmallTail()) {
     // 9-bit digits when they save a pass over 8-bit ones (27 bits: 3 x 9), else 8-bit digits
     const uint32_t p8 = (c->key_bits + 7) / 8, p9 = (c->key_bits + 8) / 9;
-    if (p9 < p8) return radix_sort_bits<9>(c, n, n_dev, grid, first, p9, kin, vin, kout, vout);
-    return radix_sort_bits<8>(c, n, n_dev, grid, first, p8, kin, vin, kout, vout);
+    if (p9 < p8) return radix_sort_bits<9>(c, n, n_dev, grid, first, p9, kin, vin, kout, vout, tail);
+    return radix_sort_bits<8>(c, n, n_dev, grid, first, p8, kin, vin, kout, vout, tail);
 }
 
 // ---- the sort as a merge: only the particles whose cell changed are sorted -----------------------------------
@@ -784,11 +937,12 @@ constexpr uint32_t MM_RANK_TILE = 4096;
 __global__ __launch_bounds__(256) void k_mm_tile_rank(const uint32_t* __restrict__ A, uint32_t n,
                                                       const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
                                                       const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ tileL,
-                                                      uint32_t* __restrict__ tileA) {
+                                                      uint32_t* __restrict__ tileA, uint32_t small_max) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t ntiles = (n + MM_RANK_TILE - 1) / MM_RANK_TILE;
     if (t > ntiles) return;
     const uint32_t m = *m_dev;
+    if (m <= small_max) return;                              // k_os_small ranked the tiles from its LDS copy
     const uint32_t slot = t * MM_RANK_TILE;
     const uint32_t a = t == ntiles ? 0xFFFFFFFFu : A[slot];
     tileA[t] = a;                      // first key of every tile: the coarse level of k_mm_place_movers' searches
@@ -798,14 +952,14 @@ __global__ __launch_bounds__(256) void k_mm_tile_rank(const uint32_t* __restrict
 // non-movers: one thread per slot, the particle goes straight to its final slot.  The bracket [L0, L1] of a
 // whole wave is found with wave-uniform (scalar) searches inside the tile's coarse bracket; it is a single
 // point unless a mover lands inside the wave's key span.
-__global__ __launch_bounds__(256) void k_mm_scatter(const uint32_t* __restrict__ A, uint32_t n,
-                                                    const uint64_t* __restrict__ mask, const uint32_t* __restrict__ M64,
-                                                    const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
-                                                    const uint32_t* __restrict__ tileL, const float4* __restrict__ posi,
-                                                    const float4* __restrict__ velr, float4* __restrict__ posi_out,
-                                                    float4* __restrict__ velr_out, uint32_t* __restrict__ key_out,
-                                                    uint32_t* __restrict__ perm_out) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__device__ __forceinline__ void mm_scatter_body(uint32_t bid, const uint32_t* __restrict__ A, uint32_t n,
+                                                const uint64_t* __restrict__ mask, const uint32_t* __restrict__ M64,
+                                                const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
+                                                const uint32_t* __restrict__ tileL, const float4* __restrict__ posi,
+                                                const float4* __restrict__ velr, float4* __restrict__ posi_out,
+                                                float4* __restrict__ velr_out, uint32_t* __restrict__ key_out,
+                                                uint32_t* __restrict__ perm_out) {
+    const uint32_t i = bid * 256u + threadIdx.x;
     const uint32_t first = __builtin_amdgcn_readfirstlane(i);          // slot of lane 0
     if (first >= n) return;                                            // wave-uniform
     const uint32_t lane = threadIdx.x & 63u;
@@ -837,20 +991,18 @@ __global__ __launch_bounds__(256) void k_mm_scatter(const uint32_t* __restrict__
 // searched: the first key of every 4096-slot tile (tileA, 16 KB at C3, written by k_mm_tile_rank) brackets it, one
 // binary search inside the tile finds s, and e is galloped to from s (a cell holds a handful of particles).  Two
 // full-array searches per mover -- 2 x 24 dependent loads at C3 -- made this kernel 167 us on burst steps.
-__global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restrict__ A, uint32_t n, uint32_t nchunks,
-                                                         const uint64_t* __restrict__ mask,
-                                                         const uint32_t* __restrict__ M64,
-                                                         const uint32_t* __restrict__ mk,
-                                                         const uint32_t* __restrict__ mi,
-                                                         const uint32_t* __restrict__ m_dev,
-                                                         const uint32_t* __restrict__ tileA, const uint2* __restrict__ cells,
-                                                         uint32_t slot_base,
-                                                         const float4* __restrict__ posi, const float4* __restrict__ velr,
-                                                         float4* __restrict__ posi_out, float4* __restrict__ velr_out,
-                                                         uint32_t* __restrict__ key_out, uint32_t* __restrict__ perm_out) {
+__device__ __forceinline__ void mm_place_body(uint32_t bid, uint32_t nblocks, const uint32_t* __restrict__ A, uint32_t n,
+                                              uint32_t nchunks, const uint64_t* __restrict__ mask,
+                                              const uint32_t* __restrict__ M64, const uint32_t* __restrict__ mk,
+                                              const uint32_t* __restrict__ mi, const uint32_t* __restrict__ m_dev,
+                                              const uint32_t* __restrict__ tileA, const uint2* __restrict__ cells,
+                                              uint32_t slot_base, const float4* __restrict__ posi,
+                                              const float4* __restrict__ velr, float4* __restrict__ posi_out,
+                                              float4* __restrict__ velr_out, uint32_t* __restrict__ key_out,
+                                              uint32_t* __restrict__ perm_out) {
     const uint32_t m = *m_dev;
     const uint32_t ntiles = (n + MM_RANK_TILE - 1) / MM_RANK_TILE;
-    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < m; r += gridDim.x * 256u) {
+    for (uint32_t r = bid * 256u + threadIdx.x; r < m; r += nblocks * 256u) {
         const uint32_t key = mk[r], slot = mi[r];
         uint32_t s, e;
         uint2 ce = make_uint2(0u, 0u);
@@ -882,6 +1034,26 @@ __global__ __launch_bounds__(256) void k_mm_place_movers(const uint32_t* __restr
     }
 }
 
+// ONE launch moves everybody: the first `place_blocks` blocks place the movers (few, latency-bound: dependent
+// searches), the others stream the non-movers -- the two read the same old arrays and write disjoint slots of the new
+// ones, so the movers' placement hides behind the stream instead of running in front of it (26 us at C3).
+__global__ __launch_bounds__(256) void k_mm_move(uint32_t place_blocks, const uint32_t* __restrict__ A, uint32_t n,
+                                                 uint32_t nchunks, const uint64_t* __restrict__ mask,
+                                                 const uint32_t* __restrict__ M64, const uint32_t* __restrict__ mk,
+                                                 const uint32_t* __restrict__ mi, const uint32_t* __restrict__ m_dev,
+                                                 const uint32_t* __restrict__ tileL, const uint32_t* __restrict__ tileA,
+                                                 const uint2* __restrict__ cells, uint32_t slot_base,
+                                                 const float4* __restrict__ posi, const float4* __restrict__ velr,
+                                                 float4* __restrict__ posi_out, float4* __restrict__ velr_out,
+                                                 uint32_t* __restrict__ key_out, uint32_t* __restrict__ perm_out) {
+    if (blockIdx.x < place_blocks)
+        mm_place_body(blockIdx.x, place_blocks, A, n, nchunks, mask, M64, mk, mi, m_dev, tileA, cells, slot_base, posi, velr,
+                      posi_out, velr_out, key_out, perm_out);
+    else
+        mm_scatter_body(blockIdx.x - place_blocks, A, n, mask, M64, mk, mi, tileL, posi, velr, posi_out, velr_out, key_out,
+                        perm_out);
+}
+
 // Blocks for the movers' radix sort.  The count is only a hint (the previous report; whole lattice layers cross a
 // cell face together: x100 from one step to the next), and blocks without a tile leave at once, so the grid is
 // generous: never fewer than a full one-group grid (64 blocks: 262,144 movers at one tile each), twice the hint
@@ -901,10 +1073,15 @@ static void mm_tilescan(sph_ctx* c, uint32_t n, bool counted) {
 // Called right after the integrate epilogue has marked the movers: count them at the END of the step, so that
 // the next sort finds the number ready (a caller in lockstep with the device can then skip a sort that has
 // nothing to do without ever waiting for the device).
+static void mm_record_counted(sph_ctx* c) {
+    c->mm_counted_valid = !c->host_paced || *c->mm_count_host == 0u;
+    if (c->mm_counted_valid) hipEventRecord(c->mm_counted, c->stream);
+}
+
 void mm_scan_marks(sph_ctx* c) {
     if (!c->mm_marked || c->mm_scanned) return;
     mm_tilescan(c, c->mm_marked_n, true);
-    hipEventRecord(c->mm_counted, c->stream);
+    mm_record_counted(c);
     c->mm_scanned = true;
 }
 
@@ -926,7 +1103,7 @@ static void launch_merge_count(sph_ctx* c, uint32_t n) {
     }
     if (!c->mm_scanned) {
         mm_tilescan(c, n, true);
-        hipEventRecord(c->mm_counted, c->stream);
+        mm_record_counted(c);
     }
     c->mm_marked = false;
     c->mm_scanned = false;
@@ -958,23 +1135,22 @@ static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_
     hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, n, c->mm_tile_off, A, B,
                        c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr);
     SPH_HIP(hipGetLastError());
-    int rc = radix_sort_pairs(c, n_tot, c->mm_count, merge_grid_for(hint, n_tot), false, mk, mi, mk2, mi2);
+    SmallTail tail;
+    tail.A = A; tail.n_slots = n;
+    int rc = radix_sort_pairs(c, n_tot, c->mm_count, merge_grid_for(hint, n_tot), false, mk, mi, mk2, mi2, tail);
     if (rc) return rc;
     const uint32_t rank_tiles = ceil_div(n, MM_RANK_TILE) + 1u;
     hipLaunchKernelGGL(k_mm_tile_rank, dim3(ceil_div(rank_tiles, 256u)), dim3(256), 0, c->stream, A, n, mk, mi, c->mm_count,
-                       c->mm_tileL, c->mm_tileA);
+                       c->mm_tileL, c->mm_tileA, SPH_OS_SMALL ? OS_SMALL_MAX : 0u);
     SPH_HIP(hipGetLastError());
     uint32_t* perm = c->keep_perm ? c->v1 : (uint32_t*)nullptr;
     const float4* ps = c->posi + c->own_off; const float4* vs = c->velr + c->own_off;
     float4* po = c->posi2 + c->gcap; float4* vo = c->velr2 + c->gcap; uint32_t* ko = c->keyS2 + c->gcap;
-    // generous grid (grid-stride loop over the device-side count): a burst is not left to a handful of blocks
+    // generous grid for the movers (grid-stride loop over the device-side count): a burst is not left to a handful of blocks
     const uint32_t place_blocks = min(max(ceil_div(2u * hint + 1u, 256u) + 15u, 512u), 65535u);
-    hipLaunchKernelGGL(k_mm_place_movers, dim3(place_blocks), dim3(256), 0, c->stream,
-                       A, n, nchunks, c->mm_mask, c->mm_M64, mk, mi, c->mm_count, c->mm_tileA,
+    hipLaunchKernelGGL(k_mm_move, dim3(place_blocks + ceil_div(n, 256)), dim3(256), 0, c->stream, place_blocks, A, n, nchunks,
+                       c->mm_mask, c->mm_M64, mk, mi, c->mm_count, c->mm_tileL, c->mm_tileA,
                        table_live ? c->cells : (const uint2*)nullptr, c->own_off, ps, vs, po, vo, ko, perm);
-    SPH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_mm_scatter, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, A, n, c->mm_mask, c->mm_M64, mk, mi,
-                       c->mm_tileL, ps, vs, po, vo, ko, perm);
     SPH_HIP(hipGetLastError());
     c->last_perm = perm;
     return SPH_OK;
@@ -992,7 +1168,7 @@ int launch_sort(sph_ctx* c) {
     // steps without synchronising would decide all of them on one stale value, so the host never runs more
     // than four sorts ahead of the device (the queue stays several steps deep: the device never waits).
     const uint32_t ring = (uint32_t)(c->sort_calls & 3u);
-    if (c->sort_merge && c->sort_calls >= 4) SPH_HIP(hipEventSynchronize(c->mm_done[ring]));
+    if (c->sort_merge && !c->host_paced && c->sort_calls >= 4) SPH_HIP(hipEventSynchronize(c->mm_done[ring]));
     c->sort_calls++;
     c->last_sort_skipped = false;
     const bool can_merge = c->sort_merge && c->order_valid;
@@ -1011,11 +1187,11 @@ int launch_sort(sph_ctx* c) {
             // end of the previous step, so a caller in lockstep with the device -- one update() per frame --
             // finds it); a host that runs ahead of the device queues the merge, which does the same job for 0
             // movers.  sph_step stays asynchronous.
-            if (hipEventQuery(c->mm_counted) == hipSuccess && *c->mm_count_host == 0u) {
+            if (c->mm_counted_valid && hipEventQuery(c->mm_counted) == hipSuccess && *c->mm_count_host == 0u) {
                 c->sort_merges++;
                 c->sort_skips++;
                 c->last_sort_skipped = true;
-                SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
+                if (!c->host_paced) SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
                 c->last_perm = nullptr;            // identity
                 c->order_valid = true;             // cells_valid / cells_lo / cells_hi: unchanged and still true
                 return SPH_OK;
@@ -1066,7 +1242,7 @@ int launch_sort(sph_ctx* c) {
     c->cells_valid = false;
     int rc = launch_cells_build_range(c, c->gcap, c->gcap + n);
     if (rc) return rc;
-    if (c->sort_merge) SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
+    if (c->sort_merge && !c->host_paced) SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
     c->order_valid = true;
     c->cells_lo = c->gcap; c->cells_hi = c->gcap + n; c->cells_valid = true;
     return SPH_OK;

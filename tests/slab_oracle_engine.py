@@ -170,6 +170,10 @@ def make_case(name):
     """Small systems that force particles across slab boundaries within a few steps."""
     from gpufluidsimulator_amd import ic
     box, grid = (4.0, 4.0, 4.0), (64, 64, 64)
+    if name == "tall_up":           # 24 cell layers: two slabs of 12 layers each have a deep interior (>= 7 layers)
+        pos, vel = ic.dam_break_lattice((12, 12, 48), box, jitter=True)
+        vel[:, 2] = 4000.0
+        return pos, vel, box, grid
     pos, vel = ic.dam_break_lattice((12, 12, 24), box, jitter=True)
     if name == "up":
         vel[:, 2] = 4000.0          # 0.002 per step at dt 5e-7: crosses a cell layer every ~8 steps

@@ -28,15 +28,21 @@ def test_reference_update_runs_on_the_hip_seam(name):
 
 
 def test_reference_update_random_clump():
+    """Step 1 starts from identical inputs: the full bar (1e-6 x box, 1e-5, no outliers).  Step 2 is a free run of the
+    reference's update(): the documented free-run clause (at most 0.1 % of the particles beyond 1e-5, none beyond 1e-4)."""
     g = load_golden("random_clump")
     recs, _ = refio.run_ref(g["pos"], g["vel"], g["box"], int(g["grid"][0]), float(g["dt"]), 2,
                             dump_steps=(1, 2), binary=refio.DROPIN_BIN)
-    for s in (1, 2):
-        st, ref = recs[("state", s)], g[f"s{s}_state"]
-        assert np.abs(st[:, 0:3] - ref[:, 0:3]).max() <= 4e-6 * 2.0
-        assert np.abs(st[:, 6] / ref[:, 6] - 1).max() <= 1e-5
-        bad = np.abs(st[:, 3:6] - ref[:, 3:6]).max(axis=1) > 4e-5 * np.abs(ref[:, 3:6]).max()
-        assert bad.mean() <= 2e-3
+    st, ref = recs[("state", 1)], g["s1_state"]
+    assert np.abs(st[:, 0:3] - ref[:, 0:3]).max() <= 1e-6 * 2.0
+    assert np.abs(st[:, 3:6] - ref[:, 3:6]).max() <= 1e-5 * np.abs(ref[:, 3:6]).max()
+    assert np.abs(st[:, 6] / ref[:, 6] - 1).max() <= 1e-5
+    st, ref = recs[("state", 2)], g["s2_state"]
+    assert np.abs(st[:, 6] / ref[:, 6] - 1).max() <= 1e-5
+    ev = np.abs(st[:, 3:6] - ref[:, 3:6]).max(axis=1) / np.abs(ref[:, 3:6]).max()
+    assert ev.max() <= 1e-4 and (ev > 1e-5).mean() <= 1e-3
+    ep = np.abs(st[:, 0:3] - ref[:, 0:3]).max(axis=1)
+    assert ep.max() <= 1e-5 * 2.0 and (ep > 1e-6 * 2.0).mean() <= 1e-3
 
 
 def _morton_decode(z):

@@ -61,7 +61,8 @@ def _whole_domain(pos, vel, box, grid, steps):
         return c.download()
 
 
-@pytest.mark.parametrize("case,world,transport", [("up", 3, "local"), ("shear", 4, "local"), ("up", 3, "host")])
+@pytest.mark.parametrize("case,world,transport", [("up", 3, "local"), ("shear", 4, "local"), ("up", 3, "host"),
+                                                  ("tall_up", 2, "local"), ("tall_up", 2, "host")])
 def test_slabs_with_migration_match_whole_domain(case, world, transport):
     pos, vel, box, grid = make_case(case)
     steps = 24

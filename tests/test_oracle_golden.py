@@ -131,3 +131,30 @@ def test_grid_path_is_not_the_n2_path():
     n2_rho = o.by_index("density")
     rel = np.abs(grid_rho / n2_rho - 1).max()
     assert rel > 1e-4, rel      # measured 3.1e-4: 30x the stated parity tolerance
+
+
+def test_c2_developed_flow_golden():
+    """The restatement against the reference's developed flow at BASELINE config 2's size (tests/golden/c2_flow.npz:
+    262,144 particles after 2600 reference steps).  The fixture does not store the reference's within-cell order, so
+    the oracle sums in its own (stable) order: floating point within the stated tolerance, the collision COUNTS of
+    all 262,144 particles bit-exact."""
+    g = load_golden("c2_flow")
+    sample = g["sample"]
+    o = oracle.Oracle(g["pos"], g["vel"], g["box"], g["grid"])
+    o.map_zindex(); o.sort(); o.construct_bgrid()
+    o.compute_densities(); o.compute_forces(); o.particle_collisions()
+    assert np.array_equal(o.by_index("collision_count").astype(np.uint8), g["s1_coll_count"])
+    assert int(np.count_nonzero(o.B["nParticles"])) == int(g["s1_ncells"])
+    assert int(o.B["nParticles"].max()) == int(g["s1_max_cell"])
+    assert np.abs(o.by_index("density")[sample] / g["s1_dens_sample"][:, 0] - 1).max() <= REL_TOL
+    fs = np.abs(g["s1_force_sample"]).max()
+    assert np.abs(o.by_index("force_press")[sample] - g["s1_force_sample"][:, 0:3]).max() <= REL_TOL * fs
+    assert np.abs(o.by_index("force_visc")[sample] - g["s1_force_sample"][:, 3:6]).max() <= REL_TOL * fs
+    o.integrate(float(g["dt"]))
+    st = o.state()
+    ref = g["state_1_sample"]
+    assert np.abs(st["pos"][sample] - ref[:, 0:3]).max() <= POS_ABS_TOL_PER_BOX * 8.0
+    assert np.abs(st["vel"][sample] - ref[:, 3:6]).max() <= REL_TOL * np.abs(ref[:, 3:6]).max()
+    full = np.concatenate([st["pos"], st["vel"], st["density"][:, None], st["pressure"][:, None]], axis=1)
+    assert np.all(np.abs(np.abs(full.astype(np.float64)).sum(axis=0) / g["state_1_abs_sum"] - 1) <= REL_TOL)
+    o.close()
