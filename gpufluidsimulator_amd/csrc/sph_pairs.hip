@@ -228,6 +228,10 @@ constexpr int UNROLL = 4;        // density: candidates per unrolled group
 #ifndef SPH_COLL_EXACT_DIV
 #define SPH_COLL_EXACT_DIV 0
 #endif
+// 1: viscosity accumulated as sum w_j v_j and sum w_j (see k_force); 0: as sum w_j (v_j - v_i), for A/B runs
+#ifndef SPH_VISC_SPLIT
+#define SPH_VISC_SPLIT 1
+#endif
 
 // Per-row hulls of the wave's candidate ranges (wave-uniform).
 struct Hulls {
@@ -596,7 +600,12 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     // in the reference's operation order, unfused, against the exact threshold coll_dist2 (see derive()) -- is
     // applied to the few masked candidates in the drain loop below.
     const float coll_next_v = in_vgpr(__uint_as_float(__float_as_uint(ph.coll_dist2) + 8u));
-    float fpx = 0.f, fpy = 0.f, fpz = 0.f, fvx = 0.f, fvy = 0.f, fvz = 0.f;
+    // viscosity: sum_j w_j (v_j - v_i) is accumulated as sum_j w_j v_j and sum_j w_j; v_i sum_j w_j comes off once per
+    // particle in the epilogue -- 3 fma + 1 add per candidate instead of 3 sub + 3 fma.  (The sum's terms are |v| / |dv|
+    // times larger than those of the differences; at dt = 5e-7 that moves the new velocity by ~1e-9 |v|max, four orders
+    // below the stated tolerance, and the force arrays by ~1e-7 of the largest force.  The pressure term is NOT split
+    // this way: its r_ij would cancel ~300-fold.)
+    float fpx = 0.f, fpy = 0.f, fpz = 0.f, fvx = 0.f, fvy = 0.f, fvz = 0.f, sw = 0.f;
     float cvx = 0.f, cvy = 0.f, cvz = 0.f;
     uint32_t ccount = 0;
     traverse(
@@ -647,7 +656,6 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                 const float r2 = fmaf(dz, dz, fmaf(dx, dx, fmaf(dy, dy, 1e-30f)));
                 if (FORCE) {
                     const v2f qc = e[2], qd = e[3];
-                    const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;   // v_j - v_i
                     const float rinv = inv_sqrt(r2);
                     // both kernels vanish continuously at r = h, so "r < h" is max(h - r, 0): one v_max instead
                     // of a compare and two selects
@@ -656,7 +664,12 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                     const float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
                     const float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
                     fpx += s * dx; fpy += s * dy; fpz += s * dz;
-                    fvx += w * ux; fvy += w * uy; fvz += w * uz;
+#if SPH_VISC_SPLIT
+                    fvx += w * qb.y; fvy += w * qc.x; fvz += w * qc.y;      // sum w_j v_j  (v_i sum w_j: epilogue)
+                    sw += w;
+#else
+                    fvx += w * (qb.y - vi.x); fvy += w * (qc.x - vi.y); fvz += w * (qc.y - vi.z);
+#endif
                 }
                 if (COLL) {
                     float t = r2 - coll_next_v;                      // negative <=> within collision range
@@ -724,6 +737,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                 }
             }
         });
+    if (FORCE && SPH_VISC_SPLIT) { fvx = fmaf(-vi.x, sw, fvx); fvy = fmaf(-vi.y, sw, fvy); fvz = fmaf(-vi.z, sw, fvz); }
     bool moved = false;
     if (active) {
         float dvx = 0.f, dvy = 0.f, dvz = 0.f;
