@@ -137,3 +137,29 @@ def test_rebalance_moves_the_cuts_and_keeps_the_physics():
     o.step(DT, steps)
     ref = o.state(); o.close()
     _check(st, ref, box)
+
+
+def test_bench_config_is_strong_scaling_of_config_3_by_default():
+    """BASELINE.json's metric: "dam-break 16M particles, 1/2/4/8 MI355X" -- the SAME 16,777,216 particles on every N.
+    `bench.py --gpus N` must default to that (round 2 defaulted to 16.7 M particles PER GPU); config 4 and weak scaling
+    stay available; at 8 ranks the count-balanced cuts of the C3 lattice give every rank 16 cell layers."""
+    import argparse
+    from gpufluidsimulator_amd import ic
+    a = argparse.Namespace(scaling="strong", workload="C3", lattice=None)
+    for world in (1, 2, 4, 8):
+        cfg, strong, label = slab.bench_config(a, world)
+        assert strong and cfg["lattice"] == (256, 256, 256) and cfg["grid"] == (512, 512, 512)
+        assert cfg["lattice"][0] * cfg["lattice"][1] * cfg["lattice"][2] == 16777216
+    cfg, strong, _ = slab.bench_config(argparse.Namespace(scaling="strong", workload="C4", lattice=None), 8)
+    assert strong and cfg["lattice"][0] * cfg["lattice"][1] * cfg["lattice"][2] == 67108864
+    cfg, strong, _ = slab.bench_config(argparse.Namespace(scaling="weak", workload="C3", lattice=None), 4)
+    assert not strong and cfg["lattice"] == (256, 256, 1024)
+    cfg, _, _ = slab.bench_config(argparse.Namespace(scaling="strong", workload="C3", lattice="256,256,32"), 1)
+    assert cfg["lattice"] == (256, 256, 32)
+    assert ic.CONFIGS["C5"]["lattice"] == (512, 512, 512) and ic.CONFIGS["C5"]["grid"] == (1024, 1024, 1024)
+    # the lattice is cell-aligned (2 lattice layers per cell layer): 256 lattice layers fill cell layers 0..127
+    hist = np.zeros(512, dtype=np.int64)
+    hist[:128] = 2 * 256 * 256
+    cuts = slab.choose_cuts(hist, 8)
+    assert cuts == [0, 16, 32, 48, 64, 80, 96, 112, 512]
+    assert all(b - a >= 7 for a, b in zip(cuts, cuts[1:]))        # every slab has a deep interior (>= 7 owned layers)
