@@ -219,7 +219,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 // a NaN is a NaN, so everything a lane can over-read must be finite: the arrays are zero-filled once
 // per block, and whatever is staged later comes from the (zero-padded) particle arrays.
 constexpr int LDS_ENT = (PAIR_WAVES + 1) * PIECE + 8;
-constexpr int UNROLL = 4;        // density: candidates per unrolled group
+#ifndef SPH_DENS_UNROLL
+#define SPH_DENS_UNROLL 4
+#endif
+constexpr int UNROLL = SPH_DENS_UNROLL;        // density: candidates per unrolled group
 #ifndef SPH_FORCE_UNROLL
 #define SPH_FORCE_UNROLL 2
 #endif

@@ -337,3 +337,27 @@ def test_rccl_binding_moves_real_bytes_on_one_rank():
             capi._check(L.sph_rccl_transport_selftest(tr, nbytes))
     finally:
         capi.load().sph_rccl_transport_destroy(tr)
+
+
+def test_slabs_under_heavy_two_way_migration():
+    """Stress of the step's rarely taken branches together: random z velocities both ways (a particle crosses a cell layer
+    every ~4 steps), thin 3-layer slabs next to a thick one, arrivals on both sides of a slab in the same step, steps with
+    arrivals next to steps without (the halo work switches between the comm-stream form and the main-stream form).
+    The result is the whole-domain result."""
+    box, grid = (4.0, 4.0, 4.0), (64, 64, 64)
+    pos, vel = ic.dam_break_lattice((24, 24, 24), box, jitter=True)
+    rng = np.random.default_rng(5)
+    vel[:, 2] = rng.uniform(-30000.0, 30000.0, pos.shape[0]).astype(np.float32)
+    steps, world = 12, 4
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel))
+    stats = [r[1] for r in res]
+    assert sum(s["migrants"] for s in stats) > 1500, stats          # (viscosity brakes the random motion within a few steps)
+    assert sum(s["resorts"] for s in stats) >= steps, stats
+    assert all(s["host_waits"] == steps + s["far_steps"] for s in stats)
+    assert sum(r[3] for r in res) == pos.shape[0]
+    st = res[0][0]
+    ref = _whole_domain(pos, vel, box, grid, steps)
+    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
+    ev = np.abs(st["vel"] - ref["vel"]).max(axis=1) / np.abs(ref["vel"]).max()
+    assert ev.max() <= 1e-4 and (ev > 1e-5).mean() <= 1e-3, (ev.max(), (ev > 1e-5).mean())
+    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
