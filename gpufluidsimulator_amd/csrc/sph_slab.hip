@@ -8,7 +8,7 @@
 //   hash + sort owned particles
 //   k_slab_bounds_pack: layer bounds, leavers
 //     + header {#leavers, #boundary, #far}     -> exchange MIGRANTS (header + 255 inline records: 8 KB)
-//   density of the DEEP interior (layers >= 4        k_slab_post_headers: own bounds + the neighbours' headers
+//   density of the DEEP interior (layers >= 3        k_slab_post_headers: own bounds + the neighbours' headers
 //     from either cut; its slot range is read        into mapped host memory, then a sequence word
 //     from DEVICE memory: the host does not
 //     know the bounds yet)
@@ -46,7 +46,7 @@ namespace sph {
 enum {
     HL_LB = 0,        // [0..3] own layer bounds: first slot (relative to the owned range) with a key >= layer, 2*layer,
                       //        (zl-2)*layer, (zl-1)*layer
-    HL_DEEP = 4,      // [4..5] the deep interior [first key >= 4*layer, first key >= (zl-4)*layer), ABSOLUTE slots
+    HL_DEEP = 4,      // [4..5] the deep interior [first key >= 3*layer, first key >= (zl-3)*layer), ABSOLUTE slots
     HL_FAR = 6,       // [6..7] my leavers (down, up) that are NOT in the neighbour's adjacent layer (crossed > 1 layer)
     HL_HDR_LO = 8,    // [8..11]  header received from the lower neighbour {#arrivals, #its boundary layer, #far, 0}
     HL_HDR_HI = 12,   // [12..15] ... from the upper neighbour
@@ -114,12 +114,10 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     __shared__ uint32_t s_last;
     const uint32_t zl = g.zl;
     {
-        // deep interior = local layers [4, zl-4): owned layers at least THREE layers away from either cut (empty for
-        // slabs of fewer than 7 owned layers).  Two would do for the density itself (arrivals land in the boundary
-        // layer, the ghosts beyond it); the third keeps the force pass of the boundary layers -- which, rounded to whole
-        // 64-slot chunks, reaches a few slots into the second layer and so reads densities of the third -- independent of
-        // what the deep launch writes: the two run on different streams without an event between them.
-        const uint32_t d0 = min(4u, zl - 1u), d1 = zl >= 8u ? zl - 4u : d0;
+        // deep interior = local layers [3, zl-3): owned layers at least TWO layers away from either cut (empty for slabs
+        // of fewer than 5 owned layers): arrivals land in the boundary layer, the ghosts beyond it, so the density of
+        // these layers needs neither
+        const uint32_t d0 = min(3u, zl - 1u), d1 = zl >= 6u ? zl - 3u : d0;
         const uint32_t targets[8] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer, d0 * layer, max(d1, d0) * layer, 0u, 0u};
         const uint32_t wave = threadIdx.x >> 6;
         for (uint32_t t = wave; t < 6u; t += 4u) {                          // wave w: targets w and w + 4
@@ -493,7 +491,7 @@ struct sph_slab {
     sph_transport tr{};
     bool host_staged = false;            // the transport wants host buffers (tests); else device pointers on the comm stream
     hipStream_t comm = nullptr;
-    hipEvent_t ev_main = nullptr, ev_comm = nullptr;
+    hipEvent_t ev_main = nullptr, ev_comm = nullptr, ev_deep = nullptr;
     uint32_t gcap = 0, mcap = 0;         // halo / migrant capacity per side, in records
     uint32_t* d_lb = nullptr;            // DL_* words: layer bounds, deep-interior range, far counts, block counters (device)
     volatile uint32_t* h_lb = nullptr;   // HL_* words (pinned, mapped): what the step's one wait reads
@@ -527,6 +525,7 @@ void slab_free(sph_slab* s) {
     if (s->h_lb) hipHostFree((void*)s->h_lb);
     if (s->ev_main) hipEventDestroy(s->ev_main);
     if (s->ev_comm) hipEventDestroy(s->ev_comm);
+    if (s->ev_deep) hipEventDestroy(s->ev_deep);
     if (s->comm) hipStreamDestroy(s->comm);
     delete s;
 }
@@ -625,13 +624,19 @@ int slab_step_once(sph_slab* s, float dt) {
     SPH_HIP(hipGetLastError());
     rc = after_main(s); if (rc) return rc;
     // ---- the density of the deep interior goes into the main stream's queue BEFORE the host waits: its slot range
-    //      comes from device memory (k_slab_bounds_pack wrote it).  Layers >= 4 from either cut see neither ghosts nor
+    //      comes from device memory (k_slab_bounds_pack wrote it).  Layers >= 3 from either cut see neither ghosts nor
     //      arrivals (those land in the boundary layers), and no slot of them moves before the force pass.
-    bool deep_valid = c->grid.zl >= 9u;
+    bool deep_valid = c->grid.zl >= 7u;
     if (deep_valid) {
-        PhaseTimer t(c, SPH_PH_DENS);
-        rc = launch_density_dev_range(c, s->d_lb + DL_DEEP, n0);
-        if (rc) return rc;
+        {
+            PhaseTimer t(c, SPH_PH_DENS);
+            rc = launch_density_dev_range(c, s->d_lb + DL_DEEP, n0);
+            if (rc) return rc;
+        }
+        // the boundary layers' force launch runs on the comm stream and, rounded to whole 64-slot chunks, reaches past the
+        // boundary layers -- on a side without a neighbour, or where layers hold few particles, into slots whose density
+        // THIS launch writes: it waits for this event (recorded here, with nothing else in the main stream's queue)
+        SPH_HIP(hipEventRecord(s->ev_deep, c->stream));
     }
     const uint32_t inl = min(MIG_INLINE, s->mcap);
     const size_t mig_bytes = (size_t)(1 + inl) * rec;
@@ -760,6 +765,10 @@ int slab_step_once(sph_slab* s, float dt) {
                 // size their ghost messages from the headers, so what the count must confirm is that every far arrival
                 // stayed clear of the OTHER boundary layer and of the ghost layers.
                 s->far_steps++;
+                if (getenv("SPH_SLAB_DEBUG"))
+                    fprintf(stderr, "[slab %d] step %llu: far arrivals %u/%u of %u/%u; leavers %u/%u (far %u/%u); bounds %u %u %u %u of %u; "
+                            "peer boundary %u/%u\n", s->rank, (unsigned long long)s->steps, far_in_lo, far_in_hi, in_lo, in_hi, m_lo, m_hi,
+                            far_lo, far_hi, lb0, lb1, lb2, lb3, n0, peer_own_lo, peer_own_hi);
                 hipLaunchKernelGGL(k_slab_bounds, dim3(1), dim3(64), 0, c->stream, c->keyS + c->own_off, c->n, layer, c->grid.zl,
                                    s->d_lb, s->h_lb_dev);
                 SPH_HIP(hipGetLastError());
@@ -818,9 +827,8 @@ int slab_step_once(sph_slab* s, float dt) {
         // all that is left of the density pass (the boundary layers and the two layers next to them), queued on the COMM
         // stream behind the ghosts: it runs BESIDE the tail of the deep launch instead of behind it (a launch this
         // small is one partly filled round of workgroups; back to back the two launches cost a round more).  The
-        // boundary layers' (rho, p) come out of this launch, so their halo-B message is packed on the same stream:
-        // after the event behind k_slab_bounds_pack the comm stream never waits for the main stream again, and every
-        // event recorded on a stream costs the device ~5 us of idle at the next dispatch.
+        // boundary layers' (rho, p) come out of this launch, so their halo-B message is packed on the same stream: no
+        // event recorded on the main stream in between (each costs the device ~5 us of idle at the next dispatch).
         OnComm on(s);
         {
             PhaseTimer t(c, SPH_PH_DENS);
@@ -861,6 +869,7 @@ int slab_step_once(sph_slab* s, float dt) {
     // the boundary layers' force pass: on the comm stream, behind the ghosts' (rho, p) -- beside the interior launch
     // (it reads what that one reads and writes other slots of the ping-pong arrays), not behind it
     {
+        if (early_halo) SPH_HIP(hipStreamWaitEvent(s->comm, s->ev_deep, 0));     // see the deep launch (else: ev_main above covers it)
         OnComm on(s);
         PhaseTimer t(c, SPH_PH_FORCE);
         rc = launch_force_hole(c, c->own_off, c->own_off + n, a, b, true, true, true, dt, mark);
@@ -1049,6 +1058,7 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
     bool ok = hipStreamCreateWithPriority(&s->comm, hipStreamNonBlocking, hi_pri) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_deep, hipEventDisableTiming) == hipSuccess &&
               hipMalloc((void**)&s->d_lb, DL_WORDS * sizeof(uint32_t)) == hipSuccess &&
               hipMemset(s->d_lb, 0, DL_WORDS * sizeof(uint32_t)) == hipSuccess &&
               hipHostMalloc((void**)&s->h_lb, HL_WORDS * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Overlap of the slab step's two streams, from a rocprofv3 --kernel-trace CSV of scratch/slab_timeline.py:
-how much of the time the comm-stream kernels (ghost unpack, ghost cell table) and copies run concurrently with a
-pair kernel (k_density / k_force) of the same process, and how many kernels of each kind ran per step.
+"""Overlap of the slab step's two streams, from a rocprofv3 --kernel-trace CSV of a run with several ranks in ONE process
+(bench.py --gpus N --one-gpu --transport local): how much of the time the halo kernels of the comm streams (pack, ghost
+unpack + cell table, (rho, p) copies, header post, the device-to-device copies of the local transport) run concurrently
+with a pair kernel (k_density / k_force) of the process, and how many kernels of each kind ran per step and rank.
 
     python profiles/slab_overlap.py <kernel_trace.csv> <steps> <ranks> [out.json]
 """
@@ -15,8 +16,15 @@ with open(path, newline="") as f:
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sph::", "")
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?"), r.get("Thread_Id", "?")))
 rows.sort()
-pair = [(s, e) for s, e, n, q, t in rows if n.startswith("k_density") or n.startswith("k_force")]
-comm = [(s, e, n) for s, e, n, q, t in rows if n.startswith("k_slab_unpack") or n.startswith("k_cells_build") or n.startswith("k_slab_pack")]
+pair_raw = [(s, e) for s, e, n, q, t in rows if n.startswith("k_density") or n.startswith("k_force")]
+n_pair = len(pair_raw)
+pair = []                                   # union of the pair kernels' intervals (several ranks overlap each other)
+for s_, e_ in pair_raw:
+    if pair and s_ <= pair[-1][1]:
+        pair[-1] = (pair[-1][0], max(pair[-1][1], e_))
+    else:
+        pair.append((s_, e_))
+comm = [(s, e, n) for s, e, n, q, t in rows if n.startswith("k_slab_") or n.startswith("__amd_rocclr_copyBuffer")]
 
 
 def overlap(a, b):
@@ -34,7 +42,7 @@ for s, e, n in comm:
         ov[n] += overlap((s, e), pair[j]); j += 1
 queues = sorted({q for _, _, _, q, _ in rows})
 res = {"steps": steps, "ranks": ranks, "queues_seen": queues,
-       "pair_kernel_launches_per_step_and_rank": len(pair) / steps / ranks,
+       "pair_kernel_launches_per_step_and_rank": n_pair / steps / ranks,
        "comm_kernels": {n: {"launches_per_step_and_rank": cnt[n] / steps / ranks, "total_us": tot[n] / 1e3,
                             "concurrent_with_a_pair_kernel_us": ov[n] / 1e3,
                             "share_concurrent": (ov[n] / tot[n]) if tot[n] else 0.0} for n in sorted(tot)}}
