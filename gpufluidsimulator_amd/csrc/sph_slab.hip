@@ -1051,7 +1051,9 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
     s->tr = *transport;
     s->host_staged = transport->host_buffers != 0;
     s->gcap = ctx->gcap;
-    s->mcap = migrant_capacity ? migrant_capacity : (ctx->gcap / 8u + 1024u);
+    // default: half a ghost layer's capacity -- a whole lattice layer can cross a cut in one step; only the first 255 records
+    // of a side travel every step (the fixed-size message), so the capacity costs memory, not bandwidth
+    s->mcap = migrant_capacity ? migrant_capacity : (ctx->gcap / 2u + 1024u);
     if (s->mcap > ctx->gcap) s->mcap = ctx->gcap;
     int lo_pri = 0, hi_pri = 0;
     hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);

@@ -361,3 +361,28 @@ def test_slabs_under_heavy_two_way_migration():
     ev = np.abs(st["vel"] - ref["vel"]).max(axis=1) / np.abs(ref["vel"]).max()
     assert ev.max() <= 1e-4 and (ev > 1e-5).mean() <= 1e-3, (ev.max(), (ev > 1e-5).mean())
     assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def test_mid_size_slabs_with_deep_interiors_and_migration():
+    """857,375 particles (a 95 x 95 x 95 block in BASELINE config 2's box) in 2 slabs of 24 cell layers, moving up through
+    the cut: both slabs have a deep interior (its density pass is queued before the step's host wait, the rest of the halo
+    work runs on the comm stream), the upper slab has no neighbour above (its force launch for the 'boundary' chunks reaches
+    into deep slots: the event that orders it behind the deep density was missing in the first version and showed only at
+    sizes where kernels take tens of microseconds), and neither slab's particle count is a multiple of 64.  Kernels here
+    run 50-300 us, so the two streams of a rank really overlap.  40 steps, against the whole-domain context."""
+    cfg = ic.CONFIGS["C2"]
+    pos, vel = ic.dam_break_lattice((95, 95, 95), cfg["box"], jitter=True)
+    vel[:, 2] = 4000.0
+    steps = 40
+    res = _run_slabs(2, cfg["box"], cfg["grid"], steps, particles=(pos, vel))
+    stats = [r[1] for r in res]
+    assert sum(s["migrants"] for s in stats) > 5000 and all(s["far_steps"] == 0 for s in stats), stats
+    assert all(r[3] % 64 for r in res), [r[3] for r in res]
+    assert sum(r[3] for r in res) == pos.shape[0]
+    st = res[0][0]
+    ref = _whole_domain(pos, vel, cfg["box"], cfg["grid"], steps)
+    assert np.isfinite(st["vel"]).all() and np.isfinite(st["density"]).all()
+    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * 8.0
+    ev = np.abs(st["vel"] - ref["vel"]).max(axis=1) / np.abs(ref["vel"]).max()
+    assert ev.max() <= 1e-4 and (ev > 1e-5).mean() <= 1e-3, (ev.max(), (ev > 1e-5).mean())
+    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
