@@ -18,7 +18,10 @@
 
 namespace sph {
 
-constexpr int PAIR_THREADS = 256;   // 4 independent waves
+#ifndef SPH_PAIR_THREADS
+#define SPH_PAIR_THREADS 256
+#endif
+constexpr int PAIR_THREADS = SPH_PAIR_THREADS;   // 4 independent waves
 constexpr int PAIR_WAVES = PAIR_THREADS / WAVE;
 constexpr int PIECE = 128;          // staged candidates per piece (2 coalesced loads per lane)
 
