@@ -199,3 +199,37 @@ def test_mode_transitions_over_a_long_run():
         assert a.sort_stats()["merges"] == 0
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("movers", [1, 63, 4095, 4096, 4097, 8200])
+def test_mover_counts_around_the_one_block_sort(movers):
+    """Up to 4096 movers the one-block sort (k_os_small) takes the movers and the generic kernels leave; from 4097 on it is
+    the other way round.  The count lives on the device, so both forms are launched every time: exactly `movers` particles
+    are pushed across a cell face (C2-size lattice, merge forced), and the order must be the full radix sort's, element for
+    element, on either side of the switch."""
+    cfg = ic.CONFIGS["C2"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=False)
+    n = pos.shape[0]
+    rng = np.random.default_rng(movers)
+    pick = rng.choice(n, size=movers, replace=False)
+    a, b = _ctx(n, cfg["box"], cfg["grid"], False), _ctx(n, cfg["box"], cfg["grid"], True)
+    b.set_sort_mode(2)
+    try:
+        for c in (a, b):
+            c.upload(pos, vel)
+            c.hash(); c.sort()                         # the order of the lattice
+        moved = pos.copy()
+        moved[pick, 0] += np.float32(1.0 / 16.0)       # one cell to the right (the lattice fills a quarter of the box)
+        # positions by creation index: rewrite all of them in one call
+        for c in (a, b):
+            c.set_by_index(0, pos=moved)
+            c.hash(); c.sort()
+        assert np.array_equal(a.keys(), b.keys())
+        assert np.array_equal(a.order(), b.order())
+        st = b.sort_stats()
+        assert st["last_movers"] == movers and st["merges"] == 1
+        c2 = [c.build_cells() or c.cells(max_cells=n) for c in (a, b)]
+        for x, y in zip(c2[0], c2[1]):
+            assert np.array_equal(x, y)
+    finally:
+        a.close(); b.close()
