@@ -386,3 +386,27 @@ def test_mid_size_slabs_with_deep_interiors_and_migration():
     ev = np.abs(st["vel"] - ref["vel"]).max(axis=1) / np.abs(ref["vel"]).max()
     assert ev.max() <= 1e-4 and (ev > 1e-5).mean() <= 1e-3, (ev.max(), (ev > 1e-5).mean())
     assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+
+
+def test_nearly_empty_slabs():
+    """Ragged input for the slab step: 40 particles in a 64^3 grid cut into 3 slabs -- two ranks own nothing at first, then a
+    few particles wander into one of them (arrivals into an EMPTY slab: no boundary layer to merge into, no cell table yet),
+    and an isolated particle sits alone in its layer.  Every kernel of the step must cope with zero-length ranges."""
+    box, grid = (4.0, 4.0, 4.0), (64, 64, 64)
+    rng = np.random.default_rng(11)
+    pos = np.zeros((40, 3), np.float32)
+    pos[:, 0:2] = rng.uniform(-0.3, 0.3, (40, 2)).astype(np.float32)
+    pos[:, 2] = rng.uniform(-0.05, 0.05, 40).astype(np.float32)          # a pancake around z = 0: cell layers 31 and 32
+    pos[0] = (1.5, 1.5, 1.9)                                             # alone near the ceiling
+    vel = np.zeros_like(pos)
+    vel[:, 2] = np.where(np.arange(40) % 2 == 0, 9000.0, -9000.0)       # half go up, half go down: ~14 steps per layer
+    steps, world = 45, 3
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel))
+    owned = [r[3] for r in res]
+    assert sum(owned) == 40
+    assert sum(r[1]["migrants"] for r in res) > 0
+    st = res[0][0]
+    ref = _whole_domain(pos, vel, box, grid, steps)
+    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
+    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
