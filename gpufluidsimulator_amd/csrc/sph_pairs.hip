@@ -659,14 +659,16 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                 // r^2 that matters.  r = 0 (the particle itself, coincident particles): 1/r is capped at 1e15,
                 // r*1/r = 0, and the huge but finite pressure weight multiplies r_ij = 0 -- no pressure term,
                 // as with Eigen's normalized() of a zero vector (Dot.h:124-134); the viscous term is exact.
-                const float r2 = fmaf(dz, dz, fmaf(dx, dx, fmaf(dy, dy, 1e-30f)));
+                float r2 = fmaf(dz, dz, fmaf(dx, dx, fmaf(dy, dy, 1e-30f)));
+                // a lane beyond its range (the tail of the walk): ONE select makes the candidate infinitely far away --
+                // h - r clamps to 0 (no force, no viscosity weight) and r2 - coll is positive (no collision bit)
+                r2 = valid ? r2 : 1e30f;
                 if (FORCE) {
                     const v2f qc = e[2], qd = e[3];
                     const float rinv = inv_sqrt(r2);
                     // both kernels vanish continuously at r = h, so "r < h" is max(h - r, 0): one v_max instead
                     // of a compare and two selects
-                    float hr = fmaxf(fmaf(-r2, rinv, h_v), 0.f);
-                    hr = valid ? hr : 0.f;
+                    const float hr = fmaxf(fmaf(-r2, rinv, h_v), 0.f);
                     const float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
                     const float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
                     fpx += s * dx; fpy += s * dy; fpz += s * dz;
@@ -678,8 +680,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
 #endif
                 }
                 if (COLL) {
-                    float t = r2 - coll_next_v;                      // negative <=> within collision range
-                    t = valid ? t : 1.0f;
+                    const float t = r2 - coll_next_v;               // negative <=> within collision range
                     near = __builtin_amdgcn_alignbit(near, __float_as_uint(t), 31);   // (near << 1) | sign(t)
                 }
             };
