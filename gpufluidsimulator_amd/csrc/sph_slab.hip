@@ -8,7 +8,7 @@
 //   hash + sort owned particles
 //   k_slab_bounds_pack: layer bounds, leavers
 //     + header {#leavers, #boundary, #far}     -> exchange MIGRANTS (header + 255 inline records: 8 KB)
-//   density of the DEEP interior (layers >= 3        k_slab_post_headers: own bounds + the neighbours' headers
+//   density of the DEEP interior (layers >= 4        k_slab_post_headers: own bounds + the neighbours' headers
 //     from either cut; its slot range is read        into mapped host memory, then a sequence word
 //     from DEVICE memory: the host does not
 //     know the bounds yet)
@@ -46,18 +46,19 @@ namespace sph {
 enum {
     HL_LB = 0,        // [0..3] own layer bounds: first slot (relative to the owned range) with a key >= layer, 2*layer,
                       //        (zl-2)*layer, (zl-1)*layer
-    HL_DEEP = 4,      // [4..5] the deep interior [first key >= 3*layer, first key >= (zl-3)*layer), ABSOLUTE slots
+    HL_DEEP = 4,      // [4..5] the deep interior [first key >= 4*layer, first key >= (zl-4)*layer), ABSOLUTE slots
     HL_FAR = 6,       // [6..7] my leavers (down, up) that are NOT in the neighbour's adjacent layer (crossed > 1 layer)
     HL_HDR_LO = 8,    // [8..11]  header received from the lower neighbour {#arrivals, #its boundary layer, #far, 0}
     HL_HDR_HI = 12,   // [12..15] ... from the upper neighbour
     HL_SEQ = 16,      // written last: the step number
     HL_ERR = 17,      // [17..18] sticky error words set by device-side checks (plain stores of 1): SLAB_ERR_*
+    HL_NEAR = 20,     // [20..21] first slot of local layer 3 / of local layer zl-3 (ABSOLUTE): the layers next to the deep interior
     HL_WORDS = 32
 };
 enum { SLAB_ERR_INSERT_LAYER = 0, SLAB_ERR_ARRIVAL_OUTSIDE = 1 };
 // device words (sph_slab::d_lb): [0..3] bounds, [4..5] deep range (absolute), [6..7] far counts, [8..10] the
 // fused kernel's block counters {far down, far up, blocks done}
-enum { DL_DEEP = 4, DL_FAR = 6, DL_CTR = 8, DL_WORDS = 16 };
+enum { DL_DEEP = 4, DL_FAR = 6, DL_CTR = 8, DL_NEAR = 12, DL_WORDS = 16 };
 
 constexpr uint32_t MIG_INLINE = 255;   // leavers per side that ride in the first (fixed-size, 8 KB) migrant message
 
@@ -114,13 +115,17 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     __shared__ uint32_t s_last;
     const uint32_t zl = g.zl;
     {
-        // deep interior = local layers [3, zl-3): owned layers at least TWO layers away from either cut (empty for slabs
-        // of fewer than 5 owned layers): arrivals land in the boundary layer, the ghosts beyond it, so the density of
-        // these layers needs neither
-        const uint32_t d0 = min(3u, zl - 1u), d1 = zl >= 6u ? zl - 3u : d0;
-        const uint32_t targets[8] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer, d0 * layer, max(d1, d0) * layer, 0u, 0u};
+        // deep interior = local layers [4, zl-4): owned layers at least THREE layers away from either cut (empty for
+        // slabs of fewer than 7 owned layers).  Two would do for the density itself (arrivals land in the boundary
+        // layer, the ghosts beyond it); the third lets the boundary layers' force launch -- which, rounded to whole
+        // 64-slot chunks, reaches into the second layer and so reads densities of the third -- run on the comm stream
+        // without waiting for the deep launch (the host checks that it really stays inside: targets 6 and 7)
+        const uint32_t d0 = min(4u, zl - 1u), d1 = zl >= 8u ? zl - 4u : d0;
+        const uint32_t e0 = min(3u, zl - 1u), e1 = zl >= 6u ? zl - 3u : e0;
+        const uint32_t targets[8] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer, d0 * layer, max(d1, d0) * layer,
+                                     e0 * layer, max(e1, e0) * layer};
         const uint32_t wave = threadIdx.x >> 6;
-        for (uint32_t t = wave; t < 6u; t += 4u) {                          // wave w: targets w and w + 4
+        for (uint32_t t = wave; t < 8u; t += 4u) {                          // wave w: targets w and w + 4
             const uint32_t r = wave_lower_bound(keys, n, targets[t]);
             if ((threadIdx.x & 63u) == 0u) s_lb[t] = r;
         }
@@ -128,25 +133,25 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     __syncthreads();
     const uint32_t lb0 = s_lb[0], lb3 = s_lb[3];
     const uint32_t m_lo = lb0, m_hi = n - lb3;
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    bool far_l = false, far_h = false;
-    if (k < m_lo && k < cap) {
-        const float4 p = posi[k];
-        out_lo[2 + 2 * k] = p; out_lo[3 + 2 * k] = velr[k];
-        far_l = (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]) != g.z_off;              // global layer z_lo - 1
-    }
-    if (k < m_hi && k < cap) {
-        const float4 p = posi[lb3 + k];
-        out_hi[2 + 2 * k] = p; out_hi[3 + 2 * k] = velr[lb3 + k];
-        far_h = (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]) != g.z_off + (int)zl - 1;   // global layer z_hi
+    uint32_t far_l = 0, far_h = 0;                     // per thread (a thread packs several leavers when there are many)
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < cap && (k < m_lo || k < m_hi); k += gridDim.x * 256u) {
+        if (k < m_lo) {
+            const float4 p = posi[k];
+            out_lo[2 + 2 * k] = p; out_lo[3 + 2 * k] = velr[k];
+            far_l += (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]) != g.z_off ? 1u : 0u;              // global layer z_lo - 1
+        }
+        if (k < m_hi) {
+            const float4 p = posi[lb3 + k];
+            out_hi[2 + 2 * k] = p; out_hi[3 + 2 * k] = velr[lb3 + k];
+            far_h += (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]) != g.z_off + (int)zl - 1 ? 1u : 0u;   // global layer z_hi
+        }
     }
     // far counts and the "last block" ticket: RETURNING device-scope atomics (performed at the memory side; the
     // returned value is awaited, so an add has been performed before its wave passes the barrier below) -- no fence
-    const uint64_t bl = __ballot(far_l), bh = __ballot(far_h);
     uint32_t seen = 0;
-    if ((threadIdx.x & 63u) == 0) {
-        if (bl) seen += atomicAdd(&dl[DL_CTR + 0], (uint32_t)__popcll(bl));
-        if (bh) seen += atomicAdd(&dl[DL_CTR + 1], (uint32_t)__popcll(bh));
+    if (__ballot(far_l | far_h) != 0ull) {            // rare: somebody crossed more than one layer
+        if (far_l) seen += atomicAdd(&dl[DL_CTR + 0], far_l);
+        if (far_h) seen += atomicAdd(&dl[DL_CTR + 1], far_h);
     }
     asm volatile("" :: "v"(seen));                                        // keep the returns (and their waits)
     __syncthreads();
@@ -163,6 +168,7 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     dl[DL_DEEP] = own_off + s_lb[4];
     dl[DL_DEEP + 1] = own_off + max(s_lb[5], s_lb[4]);
     dl[DL_FAR] = far_lo; dl[DL_FAR + 1] = far_hi;
+    dl[DL_NEAR] = own_off + s_lb[6]; dl[DL_NEAR + 1] = own_off + max(s_lb[7], s_lb[6]);
 }
 
 // comm stream, right behind the migrant exchange: everything the host's one wait needs, in one mapped block, the
@@ -171,6 +177,7 @@ __global__ void k_slab_post_headers(const uint32_t* __restrict__ dl, const float
                                     const float4* __restrict__ hdr_hi, volatile uint32_t* __restrict__ host, uint32_t seq) {
     const uint32_t t = threadIdx.x;                       // one wave: a lane per word, all stores in flight together
     if (t < 8u) host[t] = dl[t];
+    else if (t == 16u || t == 17u) host[HL_NEAR + (t - 16u)] = dl[DL_NEAR + (t - 16u)];
     else if (t < 16u) {
         const float4* h = t < 12u ? hdr_lo : hdr_hi;
         const uint32_t w = (t - 8u) & 3u;
@@ -619,24 +626,19 @@ int slab_step_once(sph_slab* s, float dt) {
     const size_t rec = 2 * sizeof(float4);
     // ---- layer bounds, leavers and headers in ONE kernel; the comm stream ships the fixed-size part ------------------
     s->seq++;
-    hipLaunchKernelGGL(k_slab_bounds_pack, dim3(ceil_div(s->mcap, 256u)), dim3(256), 0, c->stream, c->keyS + off0, c->posi + off0,
+    // a few blocks: every block finds the bounds for itself, the leavers (few, at most mcap) are packed in a grid-stride loop
+    hipLaunchKernelGGL(k_slab_bounds_pack, dim3(min(ceil_div(s->mcap, 256u), 16u)), dim3(256), 0, c->stream, c->keyS + off0, c->posi + off0,
                        c->velr + off0, n0, off0, layer, s->mcap, c->grid, s->d_lb, s->mig_send[0], s->mig_send[1]);
     SPH_HIP(hipGetLastError());
     rc = after_main(s); if (rc) return rc;
     // ---- the density of the deep interior goes into the main stream's queue BEFORE the host waits: its slot range
-    //      comes from device memory (k_slab_bounds_pack wrote it).  Layers >= 3 from either cut see neither ghosts nor
+    //      comes from device memory (k_slab_bounds_pack wrote it).  Layers >= 4 from either cut see neither ghosts nor
     //      arrivals (those land in the boundary layers), and no slot of them moves before the force pass.
-    bool deep_valid = c->grid.zl >= 7u;
+    bool deep_valid = c->grid.zl >= 9u;
     if (deep_valid) {
-        {
-            PhaseTimer t(c, SPH_PH_DENS);
-            rc = launch_density_dev_range(c, s->d_lb + DL_DEEP, n0);
-            if (rc) return rc;
-        }
-        // the boundary layers' force launch runs on the comm stream and, rounded to whole 64-slot chunks, reaches past the
-        // boundary layers -- on a side without a neighbour, or where layers hold few particles, into slots whose density
-        // THIS launch writes: it waits for this event (recorded here, with nothing else in the main stream's queue)
-        SPH_HIP(hipEventRecord(s->ev_deep, c->stream));
+        PhaseTimer t(c, SPH_PH_DENS);
+        rc = launch_density_dev_range(c, s->d_lb + DL_DEEP, n0);
+        if (rc) return rc;
     }
     const uint32_t inl = min(MIG_INLINE, s->mcap);
     const size_t mig_bytes = (size_t)(1 + inl) * rec;
@@ -650,6 +652,7 @@ int slab_step_once(sph_slab* s, float dt) {
     rc = slab_wait_headers(s); if (rc) return rc;
     const uint32_t lb0 = s->h_lb[HL_LB], lb1 = s->h_lb[HL_LB + 1], lb2 = s->h_lb[HL_LB + 2], lb3 = s->h_lb[HL_LB + 3];
     const uint32_t deep_lo = s->h_lb[HL_DEEP], deep_hi = s->h_lb[HL_DEEP + 1];
+    const uint32_t near_lo = s->h_lb[HL_NEAR], near_hi = s->h_lb[HL_NEAR + 1];     // first slot of layer 3 / of layer zl-3
     const uint32_t far_lo = s->has_lo ? s->h_lb[HL_FAR] : 0u, far_hi = s->has_hi ? s->h_lb[HL_FAR + 1] : 0u;
     const uint32_t m_lo = lb0, m_hi = n0 - lb3;
     uint32_t own_lo = lb1 - lb0, own_hi = lb3 - lb2;
@@ -794,8 +797,18 @@ int slab_step_once(sph_slab* s, float dt) {
                 s->gcap);
     // interior = everything but the two boundary layers, in whole 64-slot chunks (the fused force pass marks the
     // movers of the next sort per chunk)
-    uint32_t a = c->own_off + ((h_lo + 63u) & ~63u), b = c->own_off + ((n - h_hi) & ~63u);
+    uint32_t a = c->own_off + ((h_lo + 63u) & ~63u), b = h_hi ? c->own_off + ((n - h_hi) & ~63u) : c->own_off + n;
     if (b < a || a > c->own_off + n) { a = c->own_off; b = c->own_off; }     // a thin slab: everything is "boundary"
+    // Early mode runs the boundary chunks' force launch on the comm stream with no event behind the deep density launch
+    // -- allowed only while none of its targets can see a density that launch writes: [own_off, a) must end inside layer
+    // 2 (it then reads layers <= 3; the deep interior starts at 4), [b, end) must start inside layer zl-3 (a side
+    // without a boundary layer has no such piece at all).  Sparse layers can break that (64 slots may span several
+    // layers): then the event is recorded now -- the main stream's queue holds nothing behind the deep launch yet.
+    // (An unconditional record costs the device ~6 us of idle per step; a MISSING one cost 18 NaN particles in one of
+    // three 2-rank rehearsals of round 3: the high-priority comm stream overtook a deep launch that queued behind
+    // another rank's kernels.)
+    const bool need_deep_event = early_halo && !(a <= near_lo && b >= near_hi);
+    if (need_deep_event) SPH_HIP(hipEventRecord(s->ev_deep, c->stream));
     // ---- halo A: boundary layers -> neighbours' ghost layers -----------------------------------------------------------
     hipStream_t pack_stream = early_halo ? s->comm : c->stream;
     if (h_lo + h_hi)
@@ -869,7 +882,7 @@ int slab_step_once(sph_slab* s, float dt) {
     // the boundary layers' force pass: on the comm stream, behind the ghosts' (rho, p) -- beside the interior launch
     // (it reads what that one reads and writes other slots of the ping-pong arrays), not behind it
     {
-        if (early_halo) SPH_HIP(hipStreamWaitEvent(s->comm, s->ev_deep, 0));     // see the deep launch (else: ev_main above covers it)
+        if (need_deep_event) SPH_HIP(hipStreamWaitEvent(s->comm, s->ev_deep, 0));  // (non-early: ev_main above covers the densities)
         OnComm on(s);
         PhaseTimer t(c, SPH_PH_FORCE);
         rc = launch_force_hole(c, c->own_off, c->own_off + n, a, b, true, true, true, dt, mark);

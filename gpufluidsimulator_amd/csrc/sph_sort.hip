@@ -539,15 +539,18 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
 // ---- the whole sort of up to one tile (4096 pairs) in ONE block ----------------------------------------------------------
 // The movers of a step are usually a few thousand (flowing C3 on 8 GPUs: ~5 000 per rank and step).  Sorting them with
 // the kernels above is P + 2 launches that each handle a single tile: ~10 us apiece of launch, prologue and latency
-// chain, 56 us per step -- 8 % of a 0.7 ms step.  Here one block of 1024 threads keeps the pairs in LDS and runs every
+// chain, 56 us per step -- 8 % of a 0.7 ms step.  Here one block of 1024 threads keeps up to 8192 pairs in LDS and runs every
 // pass itself (the same stable ranking: rows of 64 keys in order, equal digits of a row by ballot match-any), then
 // -- the sorted movers still in LDS -- also ranks the coarse tile boundaries of the merge (k_mm_tile_rank's job).
 // The count lives on the device, so the generic kernels are still launched behind it; they, and this one, look at the
 // count first and leave at once when it is not theirs (count <= OS_SMALL_MAX: this kernel; else: the others).
 constexpr int SMALL_THREADS = 1024;
 constexpr int SMALL_WAVES = SMALL_THREADS / WAVE;                 // 16
-constexpr int SMALL_KPT = OS_TILE / SMALL_THREADS;                // 4 rows of 64 keys per wave
-constexpr uint32_t OS_SMALL_MAX = OS_TILE;
+#ifndef SPH_OS_SMALL_TILES
+#define SPH_OS_SMALL_TILES 2                                      // pairs the one-block sort takes, in tiles of 4096
+#endif
+constexpr uint32_t OS_SMALL_MAX = SPH_OS_SMALL_TILES * OS_TILE;   // 8192 pairs: 64 KB of LDS for the pairs + 32 KB of counters
+constexpr int SMALL_KPT = OS_SMALL_MAX / SMALL_THREADS;           // rows of 64 keys per wave
 // first r in [0, m) with (sk[r], sv[r]) >= (key, slot), the arrays in LDS
 __device__ __forceinline__ uint32_t small_lower_bound(const uint32_t* sk, const uint32_t* sv, uint32_t m, uint32_t key,
                                                       uint32_t slot) {
@@ -567,29 +570,36 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_os_small(const uint32_t* __re
                                                             const uint32_t* __restrict__ A, uint32_t n_slots,
                                                             uint32_t* __restrict__ tileL, uint32_t* __restrict__ tileA) {
     constexpr int RADIX = 1 << BITS;
-    __shared__ uint32_t s_key[2][OS_TILE], s_val[2][OS_TILE];
+    // ONE buffer for the pairs: a pass ranks from registers into LDS, everybody reads its rows back, the next pass
+    // overwrites (the barriers in between are the block scan's and the one behind the ranking)
+    __shared__ uint32_t s_key[OS_SMALL_MAX], s_val[OS_SMALL_MAX];
     __shared__ uint32_t wh[SMALL_WAVES][RADIX];
     __shared__ uint32_t s_wtot[SMALL_WAVES];
     const uint32_t m = min(*n_dev, n_cap);
     if (m > OS_SMALL_MAX) return;                               // block-uniform, before any barrier
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const uint32_t wbase = wave * (WAVE * SMALL_KPT);
+    // rows of 64 pairs per wave: as few as the count needs, so that all 16 waves share a small sort (a wave ranks its rows
+    // one after the other: 2000 movers are 2 rows for each of 16 waves, not 8 rows for 4 of them)
+    const uint32_t R = max((((m + 63u) >> 6) + SMALL_WAVES - 1u) / SMALL_WAVES, 1u);        // <= SMALL_KPT
+    const uint32_t wbase = wave * (WAVE * R);
     uint32_t key[SMALL_KPT], val[SMALL_KPT];
 #pragma unroll
     for (int t = 0; t < SMALL_KPT; t++) {
         const uint32_t i = wbase + t * WAVE + lane;
-        key[t] = i < m ? kin[i] : 0xFFFFFFFFu;
-        val[t] = i < m ? vin[i] : 0u;
+        const bool mine = (uint32_t)t < R && i < m;
+        key[t] = mine ? kin[i] : 0xFFFFFFFFu;
+        val[t] = mine ? vin[i] : 0u;
     }
-    int cur = 0;
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t shift = p * BITS;
         for (int d = threadIdx.x; d < SMALL_WAVES * RADIX; d += SMALL_THREADS) (&wh[0][0])[d] = 0;
-        __syncthreads();
+        __syncthreads();                                        // (also: every row of the last pass has been read back)
 #pragma unroll
-        for (int t = 0; t < SMALL_KPT; t++)
+        for (int t = 0; t < SMALL_KPT; t++) {
+            if ((uint32_t)t >= R || wbase + t * WAVE >= m) break;                   // wave-uniform
             wave_count_digit(wh[wave], (key[t] >> shift) & (RADIX - 1), wbase + t * WAVE + lane < m);
+        }
         __syncthreads();
         // per digit: exclusive offsets of the waves, then the digit's start in the tile
         uint32_t cnt = 0;
@@ -605,11 +615,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_os_small(const uint32_t* __re
         }
         __syncthreads();
         const lds_u32_ptr pos = (lds_u32_ptr)wh[wave];
-        const int nxt = cur ^ 1;
 #pragma unroll
         for (int t = 0; t < SMALL_KPT; t++) {
             const uint32_t i = wbase + t * WAVE + lane;
-            if (wbase + t * WAVE >= m) break;                   // wave-uniform: the rows behind the last pair
+            if ((uint32_t)t >= R || wbase + t * WAVE >= m) break;   // wave-uniform: the rows behind the last pair
             const bool valid = i < m;
             const uint32_t d = (key[t] >> shift) & (RADIX - 1);
             uint32_t dif_lo = 0u, dif_hi = 0u;
@@ -628,31 +637,21 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_os_small(const uint32_t* __re
             os_wave_lds_order();
             if (valid && rank == 0) pos[d] = base + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi);
             os_wave_lds_order();
-            if (valid) { s_key[nxt][base + rank] = key[t]; s_val[nxt][base + rank] = val[t]; }
+            if (valid) { s_key[base + rank] = key[t]; s_val[base + rank] = val[t]; }
         }
         __syncthreads();
-        cur = nxt;
 #pragma unroll
         for (int t = 0; t < SMALL_KPT; t++) {
             const uint32_t i = wbase + t * WAVE + lane;
-            key[t] = i < m ? s_key[cur][i] : 0xFFFFFFFFu;
-            val[t] = i < m ? s_val[cur][i] : 0u;
+            const bool mine = (uint32_t)t < R && i < m;
+            key[t] = mine ? s_key[i] : 0xFFFFFFFFu;
+            val[t] = mine ? s_val[i] : 0u;
         }
-        // (the next pass's first barrier separates these reads from its writes into the other buffer's twin: the
-        //  ranking writes s_key[cur ^ 1], which nobody reads any more)
     }
 #pragma unroll
     for (int t = 0; t < SMALL_KPT; t++) {
         const uint32_t i = wbase + t * WAVE + lane;
-        if (i < m) { kout[i] = key[t]; vout[i] = val[t]; }
-    }
-    if (passes == 0u) {                                          // (never: a key has at least one digit) keep LDS valid
-#pragma unroll
-        for (int t = 0; t < SMALL_KPT; t++) {
-            const uint32_t i = wbase + t * WAVE + lane;
-            if (i < m) { s_key[cur][i] = key[t]; s_val[cur][i] = val[t]; }
-        }
-        __syncthreads();
+        if ((uint32_t)t < R && i < m) { kout[i] = key[t]; vout[i] = val[t]; }
     }
     // the merge's coarse ranks, from the sorted movers in LDS (k_mm_tile_rank leaves at once for these counts)
     if (A) {
@@ -661,7 +660,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_os_small(const uint32_t* __re
             const uint32_t slot = t * OS_TILE;
             const uint32_t a = t == ntiles ? 0xFFFFFFFFu : A[slot];
             tileA[t] = a;
-            tileL[t] = t == ntiles ? m : small_lower_bound(s_key[cur], s_val[cur], m, a, slot);
+            tileL[t] = t == ntiles ? m : small_lower_bound(s_key, s_val, m, a, slot);
         }
     }
 }

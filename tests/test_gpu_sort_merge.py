@@ -201,9 +201,9 @@ def test_mode_transitions_over_a_long_run():
         a.close(); b.close()
 
 
-@pytest.mark.parametrize("movers", [1, 63, 4095, 4096, 4097, 8200])
+@pytest.mark.parametrize("movers", [1, 63, 4095, 4096, 4097, 8191, 8192, 8193, 20000])
 def test_mover_counts_around_the_one_block_sort(movers):
-    """Up to 4096 movers the one-block sort (k_os_small) takes the movers and the generic kernels leave; from 4097 on it is
+    """Up to 8192 movers the one-block sort (k_os_small) takes the movers and the generic kernels leave; from 8193 on it is
     the other way round.  The count lives on the device, so both forms are launched every time: exactly `movers` particles
     are pushed across a cell face (C2-size lattice, merge forced), and the order must be the full radix sort's, element for
     element, on either side of the switch."""
