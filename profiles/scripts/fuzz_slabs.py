@@ -1,0 +1,48 @@
+"""Randomised slab runs against the whole-domain context (GPU box, repo root): world size, lattice, velocity field, steps.
+    python profiles/scripts/fuzz_slabs.py <first seed> <cases>     (round 3: seeds 100..129 and 1000..1249)"""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import torch  # noqa
+from gpufluidsimulator_amd import capi, ic, slab
+import test_gpu_slabs as T
+
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+bad = 0
+for case in range(ncases):
+    rng = np.random.default_rng(seed0 + case)
+    world = int(rng.integers(2, 6))
+    nx, ny = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+    nz = int(rng.integers(2 * world * 2, 110))
+    box, grid = (8.0, 8.0, 8.0), (128, 128, 128)
+    pos, vel = ic.dam_break_lattice((nx, ny, nz), box, jitter=True)
+    mode = int(rng.integers(0, 4))
+    if mode == 0:
+        vel[:, 2] = float(rng.uniform(-9000, 9000))
+    elif mode == 1:
+        vel[:, 2] = rng.uniform(-20000, 20000, pos.shape[0]).astype(np.float32)
+    elif mode == 2:
+        vel[:, 2] = np.where(pos[:, 2] > np.median(pos[:, 2]), 6000.0, -6000.0)
+    else:
+        vel[:] = rng.uniform(-3000, 3000, pos.shape).astype(np.float32)
+    steps = int(rng.integers(5, 40))
+    transport = "local" if rng.random() < 0.8 else "host"
+    t0 = time.time()
+    try:
+        res = T._run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport)
+        st = res[0][0]
+        ref = T._whole_domain(pos, vel, box, grid, steps)
+        ep = np.abs(st["pos"] - ref["pos"]).max() / 8.0
+        ev = np.abs(st["vel"] - ref["vel"]).max(axis=1) / max(np.abs(ref["vel"]).max(), 1e-30)
+        er = np.abs(st["density"] / ref["density"] - 1).max()
+        ok = ep <= 1e-6 and ev.max() <= 1e-4 and (ev > 1e-5).mean() <= 1e-3 and er <= 1e-5 and sum(r[3] for r in res) == pos.shape[0]
+        stats = {k: sum(r[1][k] for r in res) for k in ("migrants", "resorts", "in_place_merges", "far_steps", "rest_messages")}
+        print(f"case {seed0 + case}: world {world} lattice {nx}x{ny}x{nz} mode {mode} steps {steps} {transport}: "
+              f"{'ok ' if ok else 'BAD'} pos {ep:.1e} vel {ev.max():.1e} ({(ev > 1e-5).sum()} > 1e-5) rho {er:.1e} cuts {res[0][2]} {stats} {time.time() - t0:.1f}s", flush=True)
+        bad += 0 if ok else 1
+    except BaseException as e:
+        bad += 1
+        print(f"case {seed0 + case}: world {world} lattice {nx}x{ny}x{nz} mode {mode} steps {steps} {transport}: EXCEPTION {str(e)[:300]}", flush=True)
+print("bad:", bad)
+sys.exit(1 if bad else 0)
