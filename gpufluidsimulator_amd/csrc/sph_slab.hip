@@ -14,14 +14,19 @@
 //     know the bounds yet)
 //   ............ host polls the sequence word (bounded): the only wait of the step, hidden behind the deep density ...
 //   [more than 255 leavers on a side: the rest of them in a second, exact-size message]
-//   [arrivals: merged into their boundary layer in place; a particle that crossed more than one layer ("far") sends
-//    the step through the pass over all particles instead]
-//   pack boundary layers                       -> exchange HALO A (positions, velocities; exact size)
-//   density of the rest of the interior           unpack ghosts + cell table of the ghost layers (one kernel)
-//   density of the two boundary layers  <-(event)
-//   pack (rho, p) of the boundary layers       -> exchange HALO B
-//   force+collision+integrate, interior           unpack ghost (rho, p)
-//   force+collision+integrate, boundary <-(event)
+//   --- a step WITHOUT arrivals (the usual one): the halo work goes to the comm stream at once ---
+//                                                 clear the leavers' cells ; pack both boundary layers
+//                                                 exchange HALO A (positions, velocities; exact size)
+//                                                 unpack ghosts + their cell table (one kernel)
+//                                                 density of everything that is not deep (ONE launch, beside the
+//                                                   tail of the deep launch) ; pack (rho, p) of the boundary layers
+//   <-(event) force+collision+integrate, interior    exchange HALO B ; unpack ghost (rho, p)
+//                                                 force+collision+integrate, the boundary chunks (one launch)
+//   <-(event) mover count of the next sort
+//   --- a step WITH arrivals ---
+//   arrivals merged into their boundary layer in place (a "far" one -- it crossed more than one layer -- sends the
+//   step through the pass over all particles instead) ; pack boundary layers -> HALO A ; density interior-minus-deep
+//   while it travels ; (event) density boundary ; pack (rho, p) -> HALO B ; force interior ; force boundary on comm
 //
 // The interior layers (all but the first and last owned layer) never look at a ghost, so their passes run while
 // the halos travel.  Messages go point to point to the two z-neighbours only: RCCL ncclSend/ncclRecv in one group
