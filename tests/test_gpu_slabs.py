@@ -415,8 +415,8 @@ def test_nearly_empty_slabs():
 @pytest.mark.parametrize("seed", [100, 101, 104, 105, 107, 109, 119, 122, 124, 129])
 def test_slab_fuzz(seed):
     """Randomised slab runs (2-5 ranks, random block, four kinds of velocity field, 5-39 steps, local or host transport)
-    against the whole-domain context.  A sweep of 280 such cases (scratch fuzz of round 3) found no failure of the step;
-    the 5 cases beyond the bar were random-velocity fields after 28+ steps, where a particle at a cut sums its candidates
+    against the whole-domain context.  A sweep of 580 such cases (profiles/scripts/fuzz_slabs.py, round 3) found no failure
+    of the step; the 9 cases beyond the bar were random-velocity fields after 28+ steps, where a particle at a cut sums its candidates
     in another order than the whole-domain context does (arrivals follow the residents of their cell), the ~1e-6 that
     makes in an ill-conditioned force sum flips a collision count some steps later (free-run clause)."""
     rng = np.random.default_rng(seed)
