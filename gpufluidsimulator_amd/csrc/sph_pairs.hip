@@ -328,9 +328,18 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
                                                                         const uint2* __restrict__ cells,
                                                                         float2* __restrict__ dp, Targets tg,
                                                                         GridDesc g, Phys ph) {
-    __shared__ float2 s_xy[LDS_ENT];
-    __shared__ float s_z[LDS_ENT];
-    for (uint32_t k = threadIdx.x; k < LDS_ENT; k += PAIR_THREADS) {   // see LDS_ENT: keep over-reads finite
+#ifndef SPH_DENS_SKEW
+#define SPH_DENS_SKEW 0      // 1: one pad entry per 32 (entries 32 apart then sit on different banks); experiment, see DESIGN 5
+#endif
+#if SPH_DENS_SKEW
+#define DSK(j) ((j) + ((j) >> 5))
+#else
+#define DSK(j) (j)
+#endif
+    constexpr int DENS_ENT = SPH_DENS_SKEW ? LDS_ENT + LDS_ENT / 32 + 2 : LDS_ENT;
+    __shared__ float2 s_xy[DENS_ENT];
+    __shared__ float s_z[DENS_ENT];
+    for (uint32_t k = threadIdx.x; k < DENS_ENT; k += PAIR_THREADS) {   // see LDS_ENT: keep over-reads finite
         s_xy[k] = make_float2(0.f, 0.f);
         s_z[k] = 0.f;
     }
@@ -356,10 +365,10 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
             q1 = posi[a + WAVE + lane];
         },
         [&]() {
-            s_xy[slice + lane] = make_float2(q0.x, q0.y);
-            s_z[slice + lane] = q0.z;
-            s_xy[slice + WAVE + lane] = make_float2(q1.x, q1.y);
-            s_z[slice + WAVE + lane] = q1.z;
+            s_xy[DSK(slice + lane)] = make_float2(q0.x, q0.y);
+            s_z[DSK(slice + lane)] = q0.z;
+            s_xy[DSK(slice + WAVE + lane)] = make_float2(q1.x, q1.y);
+            s_z[DSK(slice + WAVE + lane)] = q1.z;
         },
         [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
@@ -368,8 +377,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
             // every lane has at least tmin candidates: that part of the walk needs no per-lane range test
             const uint32_t tmin = wave_min_u32_uniform_first(len) & ~(uint32_t)(UNROLL - 1);
             auto pair = [&](int u, bool valid) {
-                const v2f xy = ((lds_v2f_ptr)s_xy)[idx + u];
-                const float z = ((lds_f32_ptr)s_z)[idx + u];
+                const v2f xy = ((lds_v2f_ptr)s_xy)[DSK(idx + u)];
+                const float z = ((lds_f32_ptr)s_z)[DSK(idx + u)];
                 const float dx = pi.x - xy.x, dy = pi.y - xy.y, dz = pi.z - z;
                 // h^2 - r^2 in three fmas (the subtraction rides along); max(., 0) is the r < h test
                 float d = fmaxf(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, h2_v))), 0.f);
