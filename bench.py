@@ -67,11 +67,34 @@ def _median_rate(run, reps=3):
     return statistics.median(rates), rates
 
 
-def cpu_baseline(budget_s=24.0):
+def cpu_headline(cfg, pos, vel, threads_port, threads_ref, label):
+    """ONE step of the C restatement and of the reference binary on the HEADLINE configuration itself (the particles
+    of the GPU's timed window, by creation index): SURVEY 8d / BASELINE.md section 3, "same ICs, same step".  Team
+    sizes are the best ones of the 262,144-particle probe.  Each leg is a single run (a step takes seconds)."""
+    from oracle import oracle, refio
+    n = pos.shape[0]
+    dt = float(ic.DEFAULT_DT)
+    out = {"sample": label, "particles": int(n), "steps_per_run": 1}
+    o = oracle.Oracle(pos, vel, cfg["box"], cfg["grid"], oracle.CELL_MORTON, fast="native")
+    o.L.orc_set_num_threads(threads_port)
+    t0 = time.perf_counter(); o.step(dt, 1); sec = time.perf_counter() - t0
+    o.close()
+    out["port"] = {"value": n / sec, "cores": threads_port, "seconds_per_step": sec}
+    if refio.available():
+        _, st = refio.run_ref(pos, vel, cfg["box"], cfg["grid"][0], dt, 1, threads=threads_ref)
+        out["reference"] = {"value": st["particle_steps_per_s"], "cores": threads_ref,
+                            "seconds_per_step": n / max(st["particle_steps_per_s"], 1e-30)}
+    kind = "reference" if "reference" in out else "port"
+    out.update(value=out[kind]["value"], cores=out[kind]["cores"], kind=kind)
+    return out
+
+
+def cpu_baseline(budget_s=24.0, headline=None):
     """The reference's own OpenMP path (kind "reference", oracle/_ref/sph_ref: SPH/particleSystem.cpp compiled in
     the build container) and the C restatement (kind "port", oracle/sph_oracle.c compiled here with -O3
     -march=native) on a 64^3-particle dam break (BASELINE config 2 geometry): all host threads and one thread,
-    median of 3 runs each.  The headline `value` is the reference's figure when its binary is present."""
+    median of 3 runs each -- and, `headline` = (cfg, pos, vel, label), ONE step of both on the headline configuration
+    itself.  The headline `value` is the reference's figure on the headline configuration when its binary is present."""
     from oracle import oracle, refio
     cfg = ic.CONFIGS["C2"]
     pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
@@ -144,6 +167,18 @@ def cpu_baseline(budget_s=24.0):
     out.update(value=legs[kind]["value"], cores=legs[kind]["cores"], kind=kind,
                one_thread=legs[kind]["one_thread"]["value"])
     out.update(legs)
+    if headline is not None:
+        # the 262,144-particle legs above stay as `small_sample`; value / cores / sample now describe the headline config
+        hcfg, hpos, hvel, label = headline
+        small = {k: out[k] for k in ("sample", "value", "cores", "kind", "one_thread")}
+        try:
+            head = cpu_headline(hcfg, hpos, hvel, legs["port"]["cores"], legs.get("reference", legs["port"])["cores"], label)
+        except Exception as e:          # (out of host memory, a killed child): keep the bounded sample, say why
+            out["headline_error"] = f"{type(e).__name__}: {e}"
+            return out
+        out["small_sample"] = small
+        out["headline"] = head
+        out.update(value=head["value"], cores=head["cores"], kind=head["kind"], sample=head["sample"])
     return out
 
 
@@ -210,9 +245,12 @@ def run_single(args):
                    "last_movers": s1["last_movers"]}
     # per-phase device times (HIP events on the library's stream) from a second, instrumented pass over the same regime
     res["phases_ms"] = _phases(ctx, dt, args.steps)
-    st = ctx.download(want=("density", "vel"))
+    st = ctx.download(want=("density", "vel") if args.no_cpu else ("density", "vel", "pos"))
     res["finite"] = bool(np.isfinite(st["density"]).all() and np.isfinite(st["vel"]).all())
     res["vmax"] = float(np.abs(st["vel"]).max())
+    if not args.no_cpu:                     # the CPU legs step the SAME particles (by creation index) once
+        res["flow_state"] = (np.ascontiguousarray(st["pos"][:, :3], dtype=np.float32),
+                             np.ascontiguousarray(st["vel"][:, :3], dtype=np.float32))
     del st
 
     # ---- the same flowing state with the full radix sort every step --------------------------------------------------
@@ -345,7 +383,11 @@ def main():
         "phases_ms_at_rest": r["phases_ms_rest"], "sort_at_rest": r["sort_rest"],
     }
     if not args.no_cpu:
-        cb = cpu_baseline()
+        pos_f, vel_f = r["flow_state"]
+        label = (f"HEADLINE config: dam-break {args.workload}, {n} particles, grid {cfg['grid'][0]}^3, the flowing state of the "
+                 f"GPU's timed window (after {args.runup} + {args.warmup} + 2 x {args.steps} steps), ONE step, one run; "
+                 "team sizes from the 262,144-particle probe (small_sample)")
+        cb = cpu_baseline(headline=(cfg, pos_f, vel_f, label))
         out["cpu_baseline"] = cb
         out["gpu_over_cpu"] = value / cb["value"]
     print(json.dumps(out), flush=True)
