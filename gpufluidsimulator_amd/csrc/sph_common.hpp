@@ -177,7 +177,7 @@ int launch_hash(sph_ctx* c);
 int launch_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, const float jitter_dims[3], uint64_t start,
                          uint32_t count);
 int launch_sort(sph_ctx* c);          // radix sort of (k0,v0)[0,n) + reorder into posi2/velr2/keyS
-int launch_merge_arrivals(sph_ctx* c, uint32_t n_in);   // particles appended behind the sorted range join it
+int launch_merge_arrivals(sph_ctx* c, uint32_t n_in, uint32_t n_front = 0);   // particles appended behind the sorted range join it
 int launch_cells_clear(sph_ctx* c);
 int launch_cells_clear_range(sph_ctx* c, uint32_t lo, uint32_t hi);
 int launch_cells_build_range(sph_ctx* c, uint32_t lo, uint32_t hi);

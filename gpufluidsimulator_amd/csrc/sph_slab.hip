@@ -261,12 +261,17 @@ __global__ __launch_bounds__(256) void k_slab_unpack(const float4* __restrict__ 
 // crossed (the sender counted the exceptions -- "far" leavers -- into its header, and a step with any of those does
 // not come here), i.e. in the first or the last layer of the sorted owned range; the space in front of / behind the
 // owned range is free (the ghosts of the last step are gone, those of this step have not come yet).  So only that
-// layer is re-merged: the layer's nl particles and the k arrivals go, in key order (equal keys: residents first,
-// arrivals in arrival order -- the order the full stable sort of [owned, arrivals] would produce), to the slots
-// [d0, d0 + nl + k) of the scratch arrays, d0 = l0 - k on the low side and l0 on the high side, and are copied back;
-// every other slot stays where it is.  One thread per resident (counts the arrivals with a smaller key from LDS)
-// and per arrival (ranks itself among the arrivals, binary search among the residents).  An arrival whose key is
-// NOT in the expected layer would break the order: it is flagged (the step then fails with SPH_E_STATE).
+// layer is re-merged: the layer's nl particles and the k arrivals go, in key order, to the slots [d0, d0 + nl + k) of
+// the scratch arrays, d0 = l0 - k on the low side and l0 on the high side, and are copied back; every other slot stays
+// where it is.  EQUAL KEYS follow the order of the whole-domain sort, which is stable: a cell's particles are ordered
+// by their slot BEFORE the sort, and a particle that came up from the slab below had a smaller slot than every
+// resident of its new cell, one that came down from the slab above a larger one.  So on the low side the arrivals go
+// IN FRONT of the residents of their cell (`arrivals_first`), on the high side behind them, arrivals among themselves
+// in arrival order (= the sender's slot order) -- an N-slab run then holds every cell in exactly the order of the
+// one-context run, and every sum over neighbours has the same bits (tests/test_gpu_slabs.py compare with array_equal).
+// One thread per resident (counts the arrivals that go in front of it, from LDS) and per arrival (ranks itself among
+// the arrivals, binary search among the residents).  An arrival whose key is NOT in the expected layer would break
+// the order: it is flagged (the step then fails with SPH_E_STATE).
 #ifndef SPH_SLAB_INSERT
 #define SPH_SLAB_INSERT 1            // 0: arrivals always take the pass over all particles (launch_merge_arrivals)
 #endif
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void k_slab_insert(const float4* __restrict__ 
                                                      const float4* __restrict__ rec, uint32_t k, GridDesc g,
                                                      float4* __restrict__ posi_o, float4* __restrict__ velr_o,
                                                      uint32_t* __restrict__ key_o, uint32_t d0, uint32_t want_layer,
-                                                     volatile uint32_t* __restrict__ err_host) {
+                                                     bool arrivals_first, volatile uint32_t* __restrict__ err_host) {
     __shared__ uint32_t s_ak[SLAB_INSERT_MAX];
     const uint32_t layer = g.g[0] * g.g[1];
     for (uint32_t r = threadIdx.x; r < k; r += 256u) {
@@ -289,8 +294,9 @@ __global__ __launch_bounds__(256) void k_slab_insert(const float4* __restrict__ 
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t < nl) {
         const uint32_t key = keyS[l0 + t];
-        uint32_t less = 0;
-        for (uint32_t r = 0; r < k; r++) less += s_ak[r] < key ? 1u : 0u;
+        uint32_t less = 0;                              // arrivals in front of this resident
+        const uint32_t bound = key + (arrivals_first ? 1u : 0u);            // s_ak < key + 1  <=>  s_ak <= key
+        for (uint32_t r = 0; r < k; r++) less += s_ak[r] < bound ? 1u : 0u;
         const uint32_t dst = d0 + t + less;
         posi_o[dst] = posi[l0 + t];
         velr_o[dst] = velr[l0 + t];
@@ -299,10 +305,11 @@ __global__ __launch_bounds__(256) void k_slab_insert(const float4* __restrict__ 
         const uint32_t r = t - nl, key = s_ak[r];
         uint32_t among = 0;
         for (uint32_t q = 0; q < k; q++) among += (s_ak[q] < key || (s_ak[q] == key && q < r)) ? 1u : 0u;
-        uint32_t lo = 0, hi = nl;                       // residents with a key <= mine
+        uint32_t lo = 0, hi = nl;                       // residents in front of me: key < mine (low side) / <= mine (high side)
+        const uint32_t bound = key + (arrivals_first ? 0u : 1u);
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (keyS[l0 + mid] <= key) lo = mid + 1; else hi = mid;
+            if (keyS[l0 + mid] < bound) lo = mid + 1; else hi = mid;
         }
         const uint32_t dst = d0 + among + lo;
         posi_o[dst] = rec[2 * r];
@@ -726,7 +733,7 @@ int slab_step_once(sph_slab* s, float dt) {
                 rc = launch_cells_clear_range(c, l0, l0 + nl); if (rc) return rc;
                 hipLaunchKernelGGL(k_slab_insert, dim3(ceil_div(nl + k, 256u)), dim3(256), 0, c->stream, c->posi, c->velr, c->keyS, l0,
                                    nl, s->mig_recv[side] + 2, k, c->grid, c->posi2, c->velr2, c->keyS2, d0,
-                                   side == 0 ? 1u : c->grid.zl - 2u, s->h_lb_dev + HL_ERR);
+                                   side == 0 ? 1u : c->grid.zl - 2u, side == 0, s->h_lb_dev + HL_ERR);
                 hipLaunchKernelGGL(k_slab_copy_back, dim3(ceil_div(nl + k, 256u)), dim3(256), 0, c->stream, c->posi2, c->velr2, c->keyS2,
                                    c->posi, c->velr, c->keyS, d0, nl + k);
                 SPH_HIP(hipGetLastError());
@@ -743,11 +750,22 @@ int slab_step_once(sph_slab* s, float dt) {
             // behind the sorted owned range, with their cell keys: the merge path takes them in as movers without an old
             // slot (one pass over the particles; a full radix sort when the merge path is switched off).  Every slot
             // moves: the density of the deep interior is computed again with the rest.
+            // Equal keys must come out in the whole-domain order (see k_slab_insert): what came up from below in front
+            // of the residents of its cell, what came down from above behind them.  The merge takes that as a rule on
+            // the appended slots (launch_merge_arrivals: the first in_lo of them are `front` movers); the full radix
+            // sort is stable, so there the lower neighbour's particles are put physically IN FRONT of the owned range.
             deep_valid = false;
             uint32_t appended = 0;
+            const bool front_slots = !merge && in_lo <= c->own_off;
             for (int side = 0; side < 2; side++) {
                 const uint32_t cnt = side == 0 ? in_lo : in_hi;
                 if (!cnt) continue;
+                if (side == 0 && front_slots) {
+                    hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(cnt, 256u)), dim3(256), 0, c->stream, s->mig_recv[0] + 2, cnt,
+                                       c->posi + c->own_off - cnt, c->velr + c->own_off - cnt, (uint32_t*)nullptr, c->grid,
+                                       s->h_lb_dev + HL_ERR);
+                    continue;
+                }
                 const uint32_t at = c->own_off + c->n + appended;
                 hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(cnt, 256u)), dim3(256), 0, c->stream, s->mig_recv[side] + 2, cnt,
                                    c->posi + at, c->velr + at, merge ? c->k0 + c->n + appended : (uint32_t*)nullptr, c->grid,
@@ -756,8 +774,9 @@ int slab_step_once(sph_slab* s, float dt) {
             }
             SPH_HIP(hipGetLastError());
             if (merge) {
-                rc = launch_merge_arrivals(c, appended); if (rc) return rc;
+                rc = launch_merge_arrivals(c, appended, in_lo); if (rc) return rc;   // the first in_lo came up from below
             } else {
+                if (front_slots) { c->own_off -= in_lo; c->n += in_lo; }
                 c->n += appended;
                 c->keys_fresh = false;
                 c->order_valid = false;

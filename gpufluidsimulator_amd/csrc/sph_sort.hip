@@ -551,14 +551,26 @@ constexpr int SMALL_WAVES = SMALL_THREADS / WAVE;                 // 16
 #endif
 constexpr uint32_t OS_SMALL_MAX = SPH_OS_SMALL_TILES * OS_TILE;   // 8192 pairs: 64 KB of LDS for the pairs + 32 KB of counters
 constexpr int SMALL_KPT = OS_SMALL_MAX / SMALL_THREADS;           // rows of 64 keys per wave
+// Movers that go IN FRONT of the non-movers of their cell whatever their slot: the slots [lo, lo + cnt).  Only the merge
+// of a slab's arrivals uses it (launch_merge_arrivals: the particles that came up from the slab below are appended
+// behind the owned range, but in the whole-domain order -- a stable sort by (new key, old slot) -- they precede every
+// resident of their new cell); cnt = 0 everywhere else.
+struct Front {
+    uint32_t lo, cnt;
+};
+// (key, slot) order of a MOVER against a non-mover's slot `slot` of the same key
+__device__ __forceinline__ bool mover_slot_less(uint32_t mover_slot, uint32_t slot, Front f) {
+    return mover_slot < slot || mover_slot - f.lo < f.cnt;         // (unsigned: slots below f.lo wrap to huge values)
+}
+
 // first r in [0, m) with (sk[r], sv[r]) >= (key, slot), the arrays in LDS
 __device__ __forceinline__ uint32_t small_lower_bound(const uint32_t* sk, const uint32_t* sv, uint32_t m, uint32_t key,
-                                                      uint32_t slot) {
+                                                      uint32_t slot, Front f) {
     uint32_t lo = 0, hi = m;
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         const uint32_t k = sk[mid];
-        if (k < key || (k == key && sv[mid] < slot)) lo = mid + 1; else hi = mid;
+        if (k < key || (k == key && mover_slot_less(sv[mid], slot, f))) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -567,7 +579,7 @@ template <int BITS>
 __global__ __launch_bounds__(SMALL_THREADS) void k_os_small(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                             uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
                                                             const uint32_t* __restrict__ n_dev, uint32_t n_cap, uint32_t passes,
-                                                            const uint32_t* __restrict__ A, uint32_t n_slots,
+                                                            const uint32_t* __restrict__ A, uint32_t n_slots, Front front,
                                                             uint32_t* __restrict__ tileL, uint32_t* __restrict__ tileA) {
     constexpr int RADIX = 1 << BITS;
     // ONE buffer for the pairs: a pass ranks from registers into LDS, everybody reads its rows back, the next pass
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_os_small(const uint32_t* __re
             const uint32_t slot = t * OS_TILE;
             const uint32_t a = t == ntiles ? 0xFFFFFFFFu : A[slot];
             tileA[t] = a;
-            tileL[t] = t == ntiles ? m : small_lower_bound(s_key, s_val, m, a, slot);
+            tileL[t] = t == ntiles ? m : small_lower_bound(s_key, s_val, m, a, slot, front);
         }
     }
 }
@@ -756,6 +768,7 @@ int launch_hash(sph_ctx* c) {
 struct SmallTail {
     const uint32_t* A = nullptr;
     uint32_t n_slots = 0;
+    Front front{0u, 0u};
 };
 
 #ifndef SPH_OS_SMALL
@@ -813,7 +826,7 @@ static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32
         // the one-block sort: from the ORIGINAL input into the buffers the passes above would have ended in (they left at
         // once if this kernel takes the count, and this kernel leaves at once if it does not)
         hipLaunchKernelGGL(k_os_small<BITS>, dim3(1), dim3(SMALL_THREADS), 0, c->stream, kin0, vin0, kin, vin, n_dev, n, passes,
-                           tail.A, tail.n_slots, c->mm_tileL, c->mm_tileA);
+                           tail.A, tail.n_slots, tail.front, c->mm_tileL, c->mm_tileA);
         SPH_HIP(hipGetLastError());
     }
     return SPH_OK;
@@ -919,11 +932,11 @@ __global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__
 
 // first r in [lo, hi) with (mk[r], mi[r]) >= (key, slot)
 __device__ __forceinline__ uint32_t mm_lower_bound(const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
-                                                   uint32_t lo, uint32_t hi, uint32_t key, uint32_t slot) {
+                                                   uint32_t lo, uint32_t hi, uint32_t key, uint32_t slot, Front f) {
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         const uint32_t k = mk[mid];
-        const bool less = k < key || (k == key && mi[mid] < slot);
+        const bool less = k < key || (k == key && mover_slot_less(mi[mid], slot, f));
         if (less) lo = mid + 1; else hi = mid;
     }
     return lo;
@@ -936,7 +949,7 @@ constexpr uint32_t MM_RANK_TILE = 4096;
 __global__ __launch_bounds__(256) void k_mm_tile_rank(const uint32_t* __restrict__ A, uint32_t n,
                                                       const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
                                                       const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ tileL,
-                                                      uint32_t* __restrict__ tileA, uint32_t small_max) {
+                                                      uint32_t* __restrict__ tileA, uint32_t small_max, Front front) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t ntiles = (n + MM_RANK_TILE - 1) / MM_RANK_TILE;
     if (t > ntiles) return;
@@ -945,7 +958,7 @@ __global__ __launch_bounds__(256) void k_mm_tile_rank(const uint32_t* __restrict
     const uint32_t slot = t * MM_RANK_TILE;
     const uint32_t a = t == ntiles ? 0xFFFFFFFFu : A[slot];
     tileA[t] = a;                      // first key of every tile: the coarse level of k_mm_place_movers' searches
-    tileL[t] = t == ntiles ? m : mm_lower_bound(mk, mi, 0u, m, a, slot);
+    tileL[t] = t == ntiles ? m : mm_lower_bound(mk, mi, 0u, m, a, slot, front);
 }
 
 // non-movers: one thread per slot, the particle goes straight to its final slot.  The bracket [L0, L1] of a
@@ -957,7 +970,7 @@ __device__ __forceinline__ void mm_scatter_body(uint32_t bid, const uint32_t* __
                                                 const uint32_t* __restrict__ tileL, const float4* __restrict__ posi,
                                                 const float4* __restrict__ velr, float4* __restrict__ posi_out,
                                                 float4* __restrict__ velr_out, uint32_t* __restrict__ key_out,
-                                                uint32_t* __restrict__ perm_out) {
+                                                uint32_t* __restrict__ perm_out, Front front) {
     const uint32_t i = bid * 256u + threadIdx.x;
     const uint32_t first = __builtin_amdgcn_readfirstlane(i);          // slot of lane 0
     if (first >= n) return;                                            // wave-uniform
@@ -968,15 +981,15 @@ __device__ __forceinline__ void mm_scatter_body(uint32_t bid, const uint32_t* __
     const uint32_t b0 = tileL[tile], b1 = tileL[tile + 1];
     uint32_t L0 = b0, L1 = b0;
     if (b0 != b1) {                                                    // wave-uniform
-        L0 = mm_lower_bound(mk, mi, b0, b1, A[first], first);
-        L1 = mm_lower_bound(mk, mi, L0, b1, A[last], last);
+        L0 = mm_lower_bound(mk, mi, b0, b1, A[first], first, front);
+        L1 = mm_lower_bound(mk, mi, L0, b1, A[last], last, front);
     }
     if (i >= n) return;
     const uint64_t bits = mask[chunk];
     if ((bits >> lane) & 1ull) return;                                 // a mover: placed by k_mm_place_movers
     const uint32_t key = A[i];
     const uint32_t before = M64[chunk] + (uint32_t)__popcll(bits & ((1ull << lane) - 1ull));
-    const uint32_t L = L0 == L1 ? L0 : mm_lower_bound(mk, mi, L0, L1, key, i);
+    const uint32_t L = L0 == L1 ? L0 : mm_lower_bound(mk, mi, L0, L1, key, i, front);
     const uint32_t dst = i - before + L;
     posi_out[dst] = posi[i];
     velr_out[dst] = velr[i];
@@ -998,7 +1011,7 @@ __device__ __forceinline__ void mm_place_body(uint32_t bid, uint32_t nblocks, co
                                               uint32_t slot_base, const float4* __restrict__ posi,
                                               const float4* __restrict__ velr, float4* __restrict__ posi_out,
                                               float4* __restrict__ velr_out, uint32_t* __restrict__ key_out,
-                                              uint32_t* __restrict__ perm_out) {
+                                              uint32_t* __restrict__ perm_out, Front front) {
     const uint32_t m = *m_dev;
     const uint32_t ntiles = (n + MM_RANK_TILE - 1) / MM_RANK_TILE;
     for (uint32_t r = bid * 256u + threadIdx.x; r < m; r += nblocks * 256u) {
@@ -1022,7 +1035,8 @@ __device__ __forceinline__ void mm_place_body(uint32_t bid, uint32_t nblocks, co
             while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (A[mid] <= key) a = mid + 1; else b = mid; }
             e = a;
         }
-        const uint32_t j = min(max(slot, s), e);       // non-movers of cell `key` below `slot` end here
+        // non-movers of cell `key` below `slot` end here (a front mover -- an arrival from the slab below -- precedes them all)
+        const uint32_t j = slot - front.lo < front.cnt ? s : min(max(slot, s), e);
         uint32_t before = m;                           // movers among the slots [0, j)  (j <= n: the slots with an old key)
         if ((j >> 6) < nchunks) before = M64[j >> 6] + (uint32_t)__popcll(mask[j >> 6] & ((1ull << (j & 63u)) - 1ull));
         const uint32_t dst = r + (j - before);
@@ -1044,13 +1058,13 @@ __global__ __launch_bounds__(256) void k_mm_move(uint32_t place_blocks, const ui
                                                  const uint2* __restrict__ cells, uint32_t slot_base,
                                                  const float4* __restrict__ posi, const float4* __restrict__ velr,
                                                  float4* __restrict__ posi_out, float4* __restrict__ velr_out,
-                                                 uint32_t* __restrict__ key_out, uint32_t* __restrict__ perm_out) {
+                                                 uint32_t* __restrict__ key_out, uint32_t* __restrict__ perm_out, Front front) {
     if (blockIdx.x < place_blocks)
         mm_place_body(blockIdx.x, place_blocks, A, n, nchunks, mask, M64, mk, mi, m_dev, tileA, cells, slot_base, posi, velr,
-                      posi_out, velr_out, key_out, perm_out);
+                      posi_out, velr_out, key_out, perm_out, front);
     else
         mm_scatter_body(blockIdx.x - place_blocks, A, n, mask, M64, mk, mi, tileL, posi, velr, posi_out, velr_out, key_out,
-                        perm_out);
+                        perm_out, front);
 }
 
 // Blocks for the movers' radix sort.  The count is only a hint (the previous report; whole lattice layers cross a
@@ -1126,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_mm_mark_tail(uint32_t n_old, uint32_t n
 // The merged order, written straight into posi2 / velr2 / keyS2 at the canonical offset gcap.  Slots [0, n) carry
 // an old key (A) and a new one (B); slots [n, n_tot) -- particles that arrived from a neighbouring slab -- only a
 // new one, and all of them are movers.
-static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_live, uint32_t hint) {
+static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_live, uint32_t hint, Front front = Front{0u, 0u}) {
     const uint32_t* A = c->keyS + c->own_off;
     const uint32_t* B = c->k0;
     const uint32_t nchunks = ceil_div(n_tot, 64u), nt = ceil_div(nchunks, MM_TILE_CHUNKS);
@@ -1135,12 +1149,12 @@ static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_
                        c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr);
     SPH_HIP(hipGetLastError());
     SmallTail tail;
-    tail.A = A; tail.n_slots = n;
+    tail.A = A; tail.n_slots = n; tail.front = front;
     int rc = radix_sort_pairs(c, n_tot, c->mm_count, merge_grid_for(hint, n_tot), false, mk, mi, mk2, mi2, tail);
     if (rc) return rc;
     const uint32_t rank_tiles = ceil_div(n, MM_RANK_TILE) + 1u;
     hipLaunchKernelGGL(k_mm_tile_rank, dim3(ceil_div(rank_tiles, 256u)), dim3(256), 0, c->stream, A, n, mk, mi, c->mm_count,
-                       c->mm_tileL, c->mm_tileA, SPH_OS_SMALL ? OS_SMALL_MAX : 0u);
+                       c->mm_tileL, c->mm_tileA, SPH_OS_SMALL ? OS_SMALL_MAX : 0u, front);
     SPH_HIP(hipGetLastError());
     uint32_t* perm = c->keep_perm ? c->v1 : (uint32_t*)nullptr;
     const float4* ps = c->posi + c->own_off; const float4* vs = c->velr + c->own_off;
@@ -1149,7 +1163,7 @@ static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_
     const uint32_t place_blocks = min(max(ceil_div(2u * hint + 1u, 256u) + 15u, 512u), 65535u);
     hipLaunchKernelGGL(k_mm_move, dim3(place_blocks + ceil_div(n, 256)), dim3(256), 0, c->stream, place_blocks, A, n, nchunks,
                        c->mm_mask, c->mm_M64, mk, mi, c->mm_count, c->mm_tileL, c->mm_tileA,
-                       table_live ? c->cells : (const uint2*)nullptr, c->own_off, ps, vs, po, vo, ko, perm);
+                       table_live ? c->cells : (const uint2*)nullptr, c->own_off, ps, vs, po, vo, ko, perm, front);
     SPH_HIP(hipGetLastError());
     c->last_perm = perm;
     return SPH_OK;
@@ -1251,7 +1265,9 @@ int launch_sort(sph_ctx* c) {
 // k0[n ...]): merge them in -- the movers are exactly the appended slots, everybody else keeps rank and key.  One
 // pass over the particles instead of a full radix sort (the slab step, csrc/sph_slab.hip, every time a neighbour
 // sends particles).  The cell table of the owned range must be valid; it is rebuilt for the new order.
-int launch_merge_arrivals(sph_ctx* c, uint32_t n_in) {
+// The first n_front of them came from the slab BELOW: among equal keys they go in front of the residents (the order
+// of the whole-domain stable sort, see Front), the others behind them.
+int launch_merge_arrivals(sph_ctx* c, uint32_t n_in, uint32_t n_front) {
     const uint32_t n = c->n, n_tot = n + n_in;
     SPH_REQUIRE(c->order_valid && c->cells_valid && c->cells_lo == c->own_off && c->cells_hi == c->own_off + n, SPH_E_STATE,
                 "launch_merge_arrivals needs the sorted owned range and its cell table");
@@ -1264,7 +1280,7 @@ int launch_merge_arrivals(sph_ctx* c, uint32_t n_in) {
     hipLaunchKernelGGL(k_mm_tilescan, dim3(1), dim3(1024), 0, c->stream, c->mm_tile_cnt, nt, c->mm_tile_off, c->mm_count,
                        c->mm_count_host_dev, (unsigned long long*)nullptr);
     SPH_HIP(hipGetLastError());
-    int rc = launch_sort_merge(c, n, n_tot, true, n_in);
+    int rc = launch_sort_merge(c, n, n_tot, true, n_in, Front{n, n_front < n_in ? n_front : n_in});
     if (rc) return rc;
     float4* t4;
     t4 = c->posi; c->posi = c->posi2; c->posi2 = t4;

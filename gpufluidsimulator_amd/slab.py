@@ -464,10 +464,12 @@ class SlabSimulation:
                 inbox[peer] = e.buffer(int(m[peer, self.rank]), REC)
                 recvs.append((peer, inbox[peer]))
         c.exchange(sends, recvs)
-        parts = [rec[dest == self.rank]] + [inbox[p].cpu().numpy() for p in sorted(inbox)]
+        # Upload order = the order of the whole-domain sorted array restricted to my new layers: what the ranks below
+        # me held (each in its slot order), what I keep, what the ranks above me held.  The new context's first sort
+        # is a stable radix sort, so every cell keeps the order it has in a one-context run (bit-identical sums).
+        parts = ([inbox[p].cpu().numpy() for p in sorted(inbox) if p < self.rank] + [rec[dest == self.rank]] +
+                 [inbox[p].cpu().numpy() for p in sorted(inbox) if p > self.rank])
         rec = np.concatenate(parts) if parts else np.zeros((0, REC), np.float32)
-        order = np.argsort(np.ascontiguousarray(rec[:, 3]).view(np.uint32), kind="stable")   # deterministic upload order
-        rec = rec[order]
         # a fresh engine for the new layer range (cell table, key width and capacities depend on it)
         e.close()
         self.cuts = cuts

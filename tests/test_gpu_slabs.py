@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from gpufluidsimulator_amd import capi, ic, slab
+from conftest import bits
 from slab_oracle_engine import make_case
 
 pytestmark = pytest.mark.gpu
@@ -54,6 +55,17 @@ def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport=
     return results
 
 
+def _same_bits(st, ref):
+    """An N-slab run holds every cell in the order of the one-context run (arrivals from below in front of the residents
+    of their cell, from above behind them: csrc/sph_slab.hip k_slab_insert, sph_sort.hip Front), so every neighbour sum
+    adds the same terms in the same order: positions, velocities, densities and pressures agree in EVERY BIT.  Any
+    stream/event race, stale ghost or mis-sized message shows as a bit difference instead of hiding under a tolerance."""
+    for k in ("pos", "vel", "density", "pressure"):
+        a, b = bits(st[k]), bits(ref[k])
+        bad = np.nonzero(a != b)[0] if a.ndim == 1 else np.nonzero((a != b).any(axis=1))[0]
+        assert bad.size == 0, (k, bad.size, bad[:8], st[k][bad[:4]], ref[k][bad[:4]])
+
+
 def _whole_domain(pos, vel, box, grid, steps):
     with capi.Context(pos.shape[0], box=box, grid=grid) as c:
         c.upload(pos, vel)
@@ -74,9 +86,7 @@ def test_slabs_with_migration_match_whole_domain(case, world, transport):
     assert all(r[1]["host_waits"] == steps for r in res), "one host wait per step and rank"
     arrivals, in_place = sum(r[1]["resorts"] for r in res), sum(r[1]["in_place_merges"] for r in res)
     assert arrivals > 0 and in_place == arrivals, "arrivals join their boundary layer in place (k_slab_insert)"
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
-    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
 def test_python_driven_protocol_still_matches():
@@ -117,9 +127,7 @@ def test_c2_in_four_slabs_matches_whole_domain():
     assert sum(counts) == 262144 and max(counts) - min(counts) <= 2 * 64 * 64 * 2, counts
     pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
     ref = _whole_domain(pos, vel, cfg["box"], cfg["grid"], steps)
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * 8.0
-    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
 def test_weak_scaling_geometry_in_four_slabs():
@@ -153,9 +161,7 @@ def test_weak_scaling_geometry_in_four_slabs():
     assert [r[2] for r in results] == [32 * 32 * 32] * 4
     pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True, jitter_dims=cfg["jitter_dims"])
     ref = _whole_domain(pos, vel, cfg["box"], cfg["grid"], steps)
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(cfg["box"])
-    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
 def test_slab_entry_points_directly():
@@ -211,9 +217,7 @@ def test_rebalance_on_gpu_engines(transport):
     owned = [r[3] for r in results]
     assert sum(owned) == pos.shape[0] and max(owned) <= 1.35 * pos.shape[0] / world, owned
     ref = _whole_domain(pos, vel, box, grid, steps)
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
-    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
 def _far_case():
@@ -245,9 +249,7 @@ def test_particle_crossing_two_layers_in_one_step():
     st = res[0][0]
     ref = _whole_domain(pos, vel, box, grid, steps)
     assert np.abs(ref["pos"][fast, 2] - pos[fast, 2]).min() > 0.14         # more than two cell layers (viscosity brakes them fast)
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
-    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
 def test_a_stopped_neighbour_is_an_error_not_a_hang():
@@ -301,9 +303,7 @@ def test_eight_slabs_on_one_gpu():
     assert all(r[1]["host_waits"] == steps for r in res)
     pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
     ref = _whole_domain(pos, vel, cfg["box"], cfg["grid"], steps)
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * 8.0
-    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
 def test_a_burst_of_leavers_takes_the_second_migrant_message():
@@ -321,9 +321,7 @@ def test_a_burst_of_leavers_takes_the_second_migrant_message():
     assert sum(r[1]["migrants"] for r in res) >= 2 * 576
     st = res[0][0]
     ref = _whole_domain(pos2, vel2, box, grid, steps)
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
-    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
 def test_rccl_binding_moves_real_bytes_on_one_rank():
@@ -357,10 +355,7 @@ def test_slabs_under_heavy_two_way_migration():
     assert sum(r[3] for r in res) == pos.shape[0]
     st = res[0][0]
     ref = _whole_domain(pos, vel, box, grid, steps)
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
-    ev = np.abs(st["vel"] - ref["vel"]).max(axis=1) / np.abs(ref["vel"]).max()
-    assert ev.max() <= 1e-4 and (ev > 1e-5).mean() <= 1e-3, (ev.max(), (ev > 1e-5).mean())
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
 def test_mid_size_slabs_with_deep_interiors_and_migration():
@@ -382,10 +377,7 @@ def test_mid_size_slabs_with_deep_interiors_and_migration():
     st = res[0][0]
     ref = _whole_domain(pos, vel, cfg["box"], cfg["grid"], steps)
     assert np.isfinite(st["vel"]).all() and np.isfinite(st["density"]).all()
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * 8.0
-    ev = np.abs(st["vel"] - ref["vel"]).max(axis=1) / np.abs(ref["vel"]).max()
-    assert ev.max() <= 1e-4 and (ev > 1e-5).mean() <= 1e-3, (ev.max(), (ev > 1e-5).mean())
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
 def test_nearly_empty_slabs():
@@ -407,18 +399,19 @@ def test_nearly_empty_slabs():
     assert sum(r[1]["migrants"] for r in res) > 0
     st = res[0][0]
     ref = _whole_domain(pos, vel, box, grid, steps)
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * max(box)
-    assert np.abs(st["vel"] - ref["vel"]).max() <= 1e-5 * np.abs(ref["vel"]).max()
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
 
 
-@pytest.mark.parametrize("seed", [100, 101, 104, 105, 107, 109, 119, 122, 124, 129])
+@pytest.mark.parametrize("seed", [100, 101, 104, 105, 107, 109, 119, 122, 124, 129,
+                                  1031, 1072, 1174, 1186, 1194, 2008, 2039, 2226, 2257])
 def test_slab_fuzz(seed):
     """Randomised slab runs (2-5 ranks, random block, four kinds of velocity field, 5-39 steps, local or host transport)
-    against the whole-domain context.  A sweep of 580 such cases (profiles/scripts/fuzz_slabs.py, round 3) found no failure
-    of the step; the 9 cases beyond the bar were random-velocity fields after 28+ steps, where a particle at a cut sums its candidates
-    in another order than the whole-domain context does (arrivals follow the residents of their cell), the ~1e-6 that
-    makes in an ill-conditioned force sum flips a collision count some steps later (free-run clause)."""
+    against the whole-domain context, bit for bit.  Round 3 swept 580 such cases (profiles/scripts/fuzz_slabs.py, seeds
+    100..129, 1000..1249, 2000..2299) at a tolerance: no failure of the step, but 9 cases beyond the bar -- random
+    z-velocity fields after 27+ steps (density 1.0-2.3e-5, seed 1174 with flipped collision counts).  Cause: a particle
+    that crossed a cut was put BEHIND the residents of its new cell, whereas the one-context stable sort puts an
+    arrival from below in front of them; the ~1e-7 of a re-ordered fp32 sum grew from there.  With the whole-domain
+    order restored at the cuts (round 4) the comparison is array_equal; those 9 seeds are the last nine here."""
     rng = np.random.default_rng(seed)
     world = int(rng.integers(2, 6))
     nx, ny = int(rng.integers(8, 40)), int(rng.integers(8, 40))
@@ -441,7 +434,4 @@ def test_slab_fuzz(seed):
     ref = _whole_domain(pos, vel, box, grid, steps)
     assert sum(r[3] for r in res) == pos.shape[0]
     assert all(r[1]["host_waits"] == steps + r[1]["far_steps"] for r in res)
-    assert np.abs(st["pos"] - ref["pos"]).max() <= 1e-6 * 8.0
-    ev = np.abs(st["vel"] - ref["vel"]).max(axis=1) / max(np.abs(ref["vel"]).max(), 1e-30)
-    assert ev.max() <= 1e-4 and (ev > 1e-5).mean() <= 1e-3
-    assert np.abs(st["density"] / ref["density"] - 1).max() <= 1e-5
+    _same_bits(st, ref)
