@@ -94,6 +94,7 @@ SIGNATURES = {
     "sph_sort_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                  C.POINTER(C.c_uint64)]),
     "sph_set_sort_mode": (C.c_int, [_P, C.c_int]),
+    "sph_set_direct_hull": (C.c_int, [_P, C.c_uint32]),
     "sph_set_precision": (C.c_int, [_P, C.c_int]),
     "sph_get_precision": (C.c_int, [_P]),
     "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
@@ -393,6 +394,11 @@ class Context:
         """merge=False/0: full radix sort every step (the SPH_SORT_MERGE=0 behaviour); True/1: merge while few
         particles change cell; 2: merge whatever the count (tests)."""
         _check(self.L.sph_set_sort_mode(self.h, int(merge)))
+
+    def set_direct_hull(self, slots=512):
+        """Rows of the neighbour passes whose staged hull would exceed `slots` are read straight from global memory
+        (0: all of them, 0xFFFFFFFF: none); same bits either way."""
+        _check(self.L.sph_set_direct_hull(self.h, int(slots) & 0xFFFFFFFF))
 
     def timing_get(self):
         ms = (C.c_float * len(PHASES))()

@@ -954,6 +954,12 @@ int sph_set_sort_mode(sph_ctx* c, int merge) {
     return SPH_OK;
 }
 
+int sph_set_direct_hull(sph_ctx* c, uint32_t slots) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    c->direct_hull = slots;
+    return SPH_OK;
+}
+
 int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers,
                    uint64_t* movers_total) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");

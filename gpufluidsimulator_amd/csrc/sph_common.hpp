@@ -84,6 +84,10 @@ struct sph_ctx {
     float4* pos_out = nullptr;// (x,y,z,1) by creation index: the gl_pos analogue
     uint32_t pos_out_cap = 0;
 
+    // pair kernels: a (dz, dy) row whose staged hull would exceed this many slots is read straight from global memory
+    // by every lane instead (sph_pairs.hip: traverse; sph_set_direct_hull)
+    uint32_t direct_hull = 512;
+
     // cell table: {start, end} per local cell, zero = empty
     uint2* cells = nullptr;        // = cells_base + 1
     uint2* cells_base = nullptr;   // the allocation: ncells + one zero guard entry on either side

@@ -203,6 +203,28 @@ __device__ __forceinline__ void lane_rows(const uint2* __restrict__ cells, const
     }
 }
 
+// the same for ONE row with a run-time (dz, dy): the direct walk below looks its rows up again instead of keeping the
+// nine ranges of lane_rows alive in a second branch (that cost the staged walk of k_force a register spill)
+__device__ __forceinline__ void lane_row_one(const uint2* __restrict__ cells, const GridDesc& g, uint32_t key, bool active,
+                                             int dz, int dy, uint32_t& lo, uint32_t& hi) {
+    const uint32_t gx = g.g[0], gy = g.g[1];
+    uint32_t cx, cy, lz;
+    if (((gx & (gx - 1u)) | (gy & (gy - 1u))) == 0u) {   // powers of two, as in lane_rows
+        const uint32_t sx = 31u - (uint32_t)__clz((int)gx), sy = 31u - (uint32_t)__clz((int)gy);
+        cx = key & (gx - 1u); cy = (key >> sx) & (gy - 1u); lz = key >> (sx + sy);
+    } else {
+        cx = key % gx;
+        const uint32_t t = key / gx;
+        cy = t % gy; lz = t / gy;
+    }
+    const bool ok = active && (int)cy + dy >= 0 && (int)cy + dy < (int)gy && (int)lz + dz >= 0 && (int)lz + dz < (int)g.zl;
+    const uint2* p = cells + (ok ? (int)key + dz * (int)(gx * gy) + dy * (int)gx : (int)key);
+    const uint2 a = p[-1], b = p[0], d = p[1];
+    const bool na = ok && cx > 0u && a.y > a.x, nb = ok && b.y > b.x, nd = ok && cx + 1u < gx && d.y > d.x;
+    lo = na ? a.x : (nb ? b.x : (nd ? d.x : 0u));
+    hi = nd ? d.y : (nb ? b.y : (na ? a.y : 0u));
+}
+
 #ifndef SPH_DENS_OCC
 #define SPH_DENS_OCC 6      // waves per SIMD asked of the register allocator (<= 80 VGPRs)
 #endif
@@ -275,6 +297,7 @@ __device__ __forceinline__ void wave_hulls(const Rows& R, Hulls& H) {
 // slice (`load(a)` issues the global loads, `store()` writes them to LDS) and call `pieces(r, a, b)`
 // for the per-lane work.  The first piece of the NEXT row is requested before the current piece
 // is processed, so its global-memory latency hides behind the pair arithmetic.
+//
 template <class Load, class Store, class Work>
 __device__ __forceinline__ void traverse(const Hulls& H, Load&& load, Store&& store, Work&& work) {
     bool ready = false;
@@ -298,6 +321,46 @@ __device__ __forceinline__ void traverse(const Hulls& H, Load&& load, Store&& st
     }
 }
 
+// A hull is the image of the wave's key interval under the row's offset, i.e. about as many slots as the wave's own
+// 64 -- UNLESS the wave's particles are sparse and the row is dense: 64 particles of a nearly empty cell layer (the
+// first few of a lattice plane that crosses a z face, spray) span 5-8 y-rows, and their dz = -1 rows then cover 5-8
+// whole y-rows of the dense layer next door: hulls of 12,000-19,000 entries where 80 are usual, a hundred pieces
+// staged and walked for a handful of candidates each.  28 such waves out of 32,768 made k_density 2.1x and k_force
+// 1.7x slower as the kernel's TAIL (profiles/r04_stretch_cells.txt; it is what round 3 had taken for a clock effect).
+// A wave with such a row (hull > direct_hull slots) does not stage anything: `direct_rows` lets every lane read ITS
+// OWN candidates from global memory (gathers), row by row -- the same candidates in the same order through the same
+// arithmetic, so a particle's sums have the same bits whichever way its wave goes.  One copy of that loop per kernel,
+// in a branch of its own (a copy per unrolled row cost k_force a spill).
+#ifndef SPH_DIRECT_ROWS
+#define SPH_DIRECT_ROWS 1            // 0: no direct walk at all (A/B runs)
+#endif
+// `key` is the lane's own cell key.  Pre-filter: a hull covers the cells [first key - 1, last key + 1] shifted by the
+// row's offset, so a wave whose keys span at most 64 cells (any ordinary wave: 64 particles at ~8 per cell span ~8) has
+// hulls of at most 66 cells -- long only at > 30 particles per cell, which is dense, not pathological.  Two v_readlane,
+// a subtraction and a compare for those; the nine exact tests only for waves that straddle a row end or are sparse.
+__device__ __forceinline__ bool wave_has_long_hull(const Hulls& H, uint32_t key, uint32_t direct_hull) {
+    if (!SPH_DIRECT_ROWS) return false;
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 63);
+    if (k1 - k0 <= 64u && direct_hull >= 128u) return false;        // (thresholds below 128 are test settings: always the exact test)
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 9; r++) any = any || (H.B[r] > H.A[r] && H.B[r] - H.A[r] > direct_hull);     // wave-uniform (scalar)
+    return any;
+}
+
+template <class Row>
+__device__ __forceinline__ void direct_rows(const uint2* __restrict__ cells, const GridDesc& g, uint32_t key, bool active,
+                                            Row&& row) {
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < 9; r++) {                                  // (dz, dy) in the order of lane_rows
+        uint32_t l0, l1;
+        lane_row_one(cells, g, key, active, r / 3 - 1, r % 3 - 1, l0, l1);
+        const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
+        const uint32_t T = wave_max_u32(len);
+        if (T) row(l0, len, T);
+    }
+}
+
 // Which slots a launch of a pair kernel works on: [lo, hi) minus the hole [gap_lo, gap_lo + gap_len) -- thread t takes
 // slot lo + t, shifted up by gap_len from gap_lo on, so ONE launch covers a slab's two boundary layers (the hole is
 // its interior) or its interior around the part that was computed earlier.  gap_lo - lo is a multiple of 64: a wave
@@ -307,6 +370,7 @@ __device__ __forceinline__ void traverse(const Hulls& H, Load&& load, Store&& st
 struct Targets {
     uint32_t lo, hi, gap_lo, gap_len;
     const uint32_t* dev;
+    uint32_t direct_hull;       // rows whose hull is longer are read straight from global memory (see traverse)
 };
 
 __device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, uint32_t lane, uint32_t& i, uint32_t& hi,
@@ -352,12 +416,42 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
     const uint32_t ii = active ? i : tgt_hi - 1;
     const float4 pi = posi[ii];
     Rows R;
-    lane_rows(cells, g, keyS[ii], active, R);
+    const uint32_t my_key = keyS[ii];
+    lane_rows(cells, g, my_key, active, R);
     Hulls H;
     wave_hulls(R, H);
     float4 q0, q1;
     float acc = 0.f;
     const float h2_v = in_vgpr(ph.h2);
+    // one candidate; the staged walk and the direct walk share it, so a row gives the same bits either way
+    auto pair_math = [&](float x, float y, float z, bool valid) {
+        const float dx = pi.x - x, dy = pi.y - y, dz = pi.z - z;
+        // h^2 - r^2 in three fmas (the subtraction rides along); max(., 0) is the r < h test
+        float d = fmaxf(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, h2_v))), 0.f);
+        d = valid ? d : 0.f;
+        acc = fmaf(d * d, d, acc);
+    };
+    auto finish = [&]() {
+        if (active) {
+            float rho = acc * ph.poly6_mass;
+            float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
+            dp[i] = make_float2(rho, p);
+        }
+    };
+    if (wave_has_long_hull(H, my_key, tg.direct_hull)) {          // a branch of its own, to its own end: the staged walk keeps its registers
+        const uint32_t me = active ? i : tgt_hi - 1u;        // (= ii, derived again: nothing of this branch stays alive in the staged walk)
+        direct_rows(cells, g, keyS[me], active, [&](uint32_t l0, uint32_t len, uint32_t T) {      // a lane out of range reads itself (masked)
+            for (uint32_t t = 0; t < T; t += 2u) {
+                float4 q[2];
+#pragma unroll
+                for (uint32_t u = 0; u < 2u; u++) q[u] = posi[t + u < len ? l0 + t + u : me];
+#pragma unroll
+                for (uint32_t u = 0; u < 2u; u++) pair_math(q[u].x, q[u].y, q[u].z, t + u < len);
+            }
+        });
+        finish();
+        return;
+    }
     traverse(
         H,
         [&](uint32_t a) {   // the arrays are padded by 2*PIECE entries: no bounds predicate needed
@@ -379,11 +473,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
             auto pair = [&](int u, bool valid) {
                 const v2f xy = ((lds_v2f_ptr)s_xy)[DSK(idx + u)];
                 const float z = ((lds_f32_ptr)s_z)[DSK(idx + u)];
-                const float dx = pi.x - xy.x, dy = pi.y - xy.y, dz = pi.z - z;
-                // h^2 - r^2 in three fmas (the subtraction rides along); max(., 0) is the r < h test
-                float d = fmaxf(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, h2_v))), 0.f);
-                d = valid ? d : 0.f;
-                acc = fmaf(d * d, d, acc);
+                pair_math(xy.x, xy.y, z, valid);
             };
             uint32_t t = 0;
             for (; t < tmin; t += UNROLL) {
@@ -397,11 +487,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
                 idx += UNROLL;
             }
         });
-    if (active) {
-        float rho = acc * ph.poly6_mass;
-        float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
-        dp[i] = make_float2(rho, p);
-    }
+    finish();
 }
 
 // ---- mixed precision (BASELINE config 5): fp32 positions, fp16 neighbour accumulators -----------------------
@@ -470,7 +556,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
     const uint32_t ii = active ? i : tgt_hi - 1;
     const float4 pi = posi[ii];
     Rows R;
-    lane_rows(cells, g, keyS[ii], active, R);
+    const uint32_t my_key = keyS[ii];
+    lane_rows(cells, g, my_key, active, R);
     Hulls H;
     wave_hulls(R, H);
     // reference point: the wave's first particle (wave-uniform; every candidate of the wave lies within a few cells)
@@ -480,6 +567,42 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
     const h2 tx = h2_splat((pi.x - rx) * inv_h), ty = h2_splat((pi.y - ry) * inv_h), tz = h2_splat((pi.z - rz) * inv_h);
     float4 q0, q1, q2;
     float acc = 0.f;
+    // one PAIR of candidates (the two halves of every operand)
+    auto pair_math = [&](h2& row, h2 x, h2 y, h2 z, h2 m, bool masked) {
+        const h2 dx = tx - x, dy = ty - y, dz = tz - z;
+        h2 t = one - dx * dx;                                  // 1 - r'^2: three v_pk_fma_f16
+        t = t - dy * dy;
+        t = t - dz * dz;
+        t = __builtin_elementwise_max(t, zero);                // r' < 1  <=>  r < h
+        if (masked) t = t * m;
+        row = row + (t * t) * t;
+    };
+    auto finish = [&]() {
+        if (active) {
+            const float h2f = ph.h2;
+            float rho = acc * (ph.poly6_mass * (h2f * h2f * h2f));          // m POLY6 h^6 sum (1 - r'^2)^3
+            float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
+            dp[i] = make_float2(rho, p);
+        }
+    };
+    if (wave_has_long_hull(H, my_key, tg.direct_hull)) {
+        const uint32_t me = active ? i : tgt_hi - 1u;        // (= ii, derived again: nothing of this branch stays alive in the staged walk)
+        direct_rows(cells, g, keyS[me], active, [&](uint32_t l0, uint32_t len, uint32_t) {        // every lane gathers its own candidates, two at a time
+            const uint32_t T = wave_max_u32((len + 1u) >> 1);
+            h2 row = zero;
+            for (uint32_t k = 0; k < T; k++) {
+                const bool v0 = 2u * k < len, v1 = 2u * k + 1u < len;
+                const float4 a = posi[v0 ? l0 + 2u * k : me], b = posi[v1 ? l0 + 2u * k + 1u : me];
+                const h2 x = h2{(_Float16)((a.x - rx) * inv_h), (_Float16)((b.x - rx) * inv_h)};
+                const h2 y = h2{(_Float16)((a.y - ry) * inv_h), (_Float16)((b.y - ry) * inv_h)};
+                const h2 z = h2{(_Float16)((a.z - rz) * inv_h), (_Float16)((b.z - rz) * inv_h)};
+                pair_math(row, x, y, z, h2_mask(v0, v1), true);
+            }
+            acc += (float)row.x + (float)row.y;
+        });
+        finish();
+        return;
+    }
     traverse(
         H,
         [&](uint32_t a) {   // lane L stages candidates 2L, 2L+1 and 2L+2; the arrays are padded by 2*PIECE
@@ -506,13 +629,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
             auto pair = [&](int u, h2 m, bool masked) {
                 const h2 x = ((lds_h2_ptr)&s_xy[idx + u].x)[0], y = ((lds_h2_ptr)&s_xy[idx + u].x)[1];
                 const h2 z = ((lds_h2_ptr)s_z)[idx + u];
-                const h2 dx = tx - x, dy = ty - y, dz = tz - z;
-                h2 t = one - dx * dx;                                  // 1 - r'^2: three v_pk_fma_f16
-                t = t - dy * dy;
-                t = t - dz * dz;
-                t = __builtin_elementwise_max(t, zero);                // r' < 1  <=>  r < h
-                if (masked) t = t * m;
-                row = row + (t * t) * t;
+                pair_math(row, x, y, z, m, masked);
             };
             uint32_t k = 0;
             for (; k < w.kmin; k += HUNROLL) {
@@ -526,12 +643,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
             }
             acc += (float)row.x + (float)row.y;
         });
-    if (active) {
-        const float h2f = ph.h2;
-        float rho = acc * (ph.poly6_mass * (h2f * h2f * h2f));          // m POLY6 h^6 sum (1 - r'^2)^3
-        float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
-        dp[i] = make_float2(rho, p);
-    }
+    finish();
 }
 
 int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi);
@@ -612,10 +724,18 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     float4 vi = velr[ii];
     const float2 dpi = dp[ii];
     Rows R;
-    lane_rows(cells, g, keyS[ii], active, R);
+    const uint32_t my_key = keyS[ii];
+    lane_rows(cells, g, my_key, active, R);
     Hulls H;
     wave_hulls(R, H);
     PAIR_STAT(0, 1);
+#ifdef SPH_PAIR_STATS
+    {   // longest hull of the wave: how many waves would take the direct walk at which threshold
+        uint32_t hmax = 0;
+        for (int r = 0; r < 9; r++) hmax = max(hmax, H.B[r] > H.A[r] ? H.B[r] - H.A[r] : 0u);
+        PAIR_STAT(5, hmax > 256u ? 1 : 0); PAIR_STAT(6, hmax > 512u ? 1 : 0); PAIR_STAT(7, hmax > 2048u ? 1 : 0);
+    }
+#endif
     float4 q0, q1, w0, w1;
     float2 e0, e1;
     const float cps = ph.spiky_half_mass / ph.visc_coef;   // pressure coefficient relative to the viscous one
@@ -636,6 +756,122 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     float fpx = 0.f, fpy = 0.f, fpz = 0.f, fvx = 0.f, fvy = 0.f, fvz = 0.f, sw = 0.f;
     float cvx = 0.f, cvy = 0.f, cvz = 0.f;
     uint32_t ccount = 0;
+    // One candidate (position q, velocity u, cp_j, w_j): the pressure / viscosity sums; returns r2 - (collision range + 8
+    // ulps), whose sign is the candidate's bit of the collision SUPERSET.  Shared by the staged walk and the direct walk
+    // (traverse), so a row gives the same bits either way.
+    auto pair_math = [&](float qx, float qy, float qz, float ux, float uy, float uz, float cpj, float wj, bool valid) -> float {
+        const float dx = pi.x - qx, dy = pi.y - qy, dz = pi.z - qz;
+        // r^2 + 1e-30: the tiny term rides in the first fma for free and is far below one ulp of any
+        // r^2 that matters.  r = 0 (the particle itself, coincident particles): 1/r is capped at 1e15,
+        // r*1/r = 0, and the huge but finite pressure weight multiplies r_ij = 0 -- no pressure term,
+        // as with Eigen's normalized() of a zero vector (Dot.h:124-134); the viscous term is exact.
+        float r2 = fmaf(dz, dz, fmaf(dx, dx, fmaf(dy, dy, 1e-30f)));
+        // a lane beyond its range (the tail of the walk): ONE select makes the candidate infinitely far away --
+        // h - r clamps to 0 (no force, no viscosity weight) and r2 - coll is positive (no collision bit)
+        r2 = valid ? r2 : 1e30f;
+        if (FORCE) {
+            const float rinv = inv_sqrt(r2);
+            // both kernels vanish continuously at r = h, so "r < h" is max(h - r, 0): one v_max instead
+            // of a compare and two selects
+            const float hr = fmaxf(fmaf(-r2, rinv, h_v), 0.f);
+            const float w = wj * hr;                                // VISC m VISC_LAP (h-r) / rho_j
+            const float s = (cpi + cpj) * w * (hr * rinv);          // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
+            fpx += s * dx; fpy += s * dy; fpz += s * dz;
+#if SPH_VISC_SPLIT
+            fvx += w * ux; fvy += w * uy; fvz += w * uz;            // sum w_j v_j  (v_i sum w_j: epilogue)
+            sw += w;
+#else
+            fvx += w * (ux - vi.x); fvy += w * (uy - vi.y); fvz += w * (uz - vi.z);
+#endif
+        }
+        return r2 - coll_next_v;                                    // negative <=> within collision range
+    };
+    // One candidate of the collision superset, decided EXACTLY.
+    // computeCollision (particleSystem.cu:52-65) decides on dij = sqrtf(rij.squaredNorm()) <= 2R
+    // and rij.dot(vij) < 0, Eigen reducing a 3-vector as a0 + (a1 + a2) with one rounding per
+    // operation.  Both predicates are evaluated exactly that way (no contraction), so that on
+    // identical inputs the same pairs collide as in the reference: sqrtf is monotone, hence
+    // dij <= 2R  <=>  r2 <= coll_dist2 (the largest float whose root is <= 2R, derive()).
+    // j == i needs no test: r_ij = 0 gives r.v = -0, which is not < 0 (the reference skips
+    // the pair by index, :54; a coincident pair fails r.v < 0 there too).
+    auto collide_math = [&](float qx, float qy, float qz, float wx, float wy, float wz) {
+        const float dx = pi.x - qx, dy = pi.y - qy, dz = pi.z - qz;
+        const float ux = wx - vi.x, uy = wy - vi.y, uz = wz - vi.z;
+        float r2c, dot;
+        {
+#pragma clang fp contract(off)
+            r2c = dx * dx + (dy * dy + dz * dz);
+            dot = -(dx * ux + (dy * uy + dz * uz));                 // r_ij . (v_i - v_j)
+        }
+        const bool hit = r2c <= ph.coll_dist2 && dot < 0.f;
+#if SPH_COLL_EXACT_DIV
+        float cfac = 0.f;
+        if (hit) { const float dij = sqrtf(r2c); cfac = ph.coll_mass * (dot / (dij * dij)); }
+#else
+        const float cfac = hit ? ph.coll_mass * dot * __builtin_amdgcn_rcpf(r2c) : 0.f;
+#endif
+        cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
+        ccount += hit ? 1u : 0u;
+    };
+    auto finish = [&]() {
+        if (FORCE && SPH_VISC_SPLIT) { fvx = fmaf(-vi.x, sw, fvx); fvy = fmaf(-vi.y, sw, fvy); fvz = fmaf(-vi.z, sw, fvz); }
+        bool moved = false;
+        if (active) {
+            float dvx = 0.f, dvy = 0.f, dvz = 0.f;
+            if (COLL) {
+                const float den = ph.mass * (float)(1u + ccount);
+                dvx = -cvx / den; dvy = -cvy / den; dvz = -cvz / den;
+            }
+            if (INTEG) {
+                integrate_one(ph, dt, pi, vi, dpi.x, fpx + fvx, fpy + fvy, fpz + fvz, dvx, dvy, dvz);
+                posi_out[i] = pi;
+                velr_out[i] = vi;
+                if (pos_by_index) pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
+                // the next step's cell hash (kernelGetZIndex) while the new position is still in registers
+                const uint32_t key = cell_key(g, pi.x, pi.y, pi.z);
+                keys_out[i - slot0] = key;                      // slot0: first owned slot (the launch may cover a sub-range)
+                if (mm_mask) moved = key != keyS[i];
+            } else {
+                if (FORCE) {
+                    fpress[i] = make_float4(fpx, fpy, fpz, 0.f);
+                    fvisc[i] = make_float4(fvx, fvy, fvz, 0.f);
+                }
+                if (COLL) dvel[i] = make_float4(dvx, dvy, dvz, __uint_as_float(ccount));
+            }
+        }
+        if (INTEG && mm_mask) {
+            // movers of the next sort (sph_sort.hip: the merge path), one bit per slot: this wave IS one 64-slot chunk
+            // (a sub-range launch starts on a chunk boundary: lo - slot0, gap_lo - lo and gap_len are multiples of 64)
+            const uint64_t m = __ballot(moved);
+            const uint32_t chunk = (wave_first - slot0) >> 6;
+            if (lane == 0) {
+                mm_mask[chunk] = m;
+                if (m) atomicAdd(&mm_tile_cnt[chunk / MM_TILE_CHUNKS], (uint32_t)__popcll(m));
+            }
+        }
+    };
+    if (wave_has_long_hull(H, my_key, tg.direct_hull)) {          // a branch of its own, to its own end: the staged walk keeps its registers
+        const uint32_t me = active ? i : tgt_hi - 1u;        // (= ii, derived again: nothing of this branch stays alive in the staged walk)
+        direct_rows(cells, g, keyS[me], active, [&](uint32_t l0, uint32_t len, uint32_t T) {
+            for (uint32_t t = 0; t < T; t++) {
+                const bool valid = t < len;
+                const uint32_t j = valid ? l0 + t : me;              // a lane out of range reads itself (finite values, masked)
+                const float4 q = posi[j], w = velr[j];
+                float2 e = make_float2(0.f, 0.f);
+                if (FORCE) e = dp[j];
+                // cp_j, w_j exactly as the staging computes them
+                // (through in_vgpr: the staged walk reads these two back from LDS as ROUNDED products; left in the open
+                // here, hipcc would fuse cps * p_j into the (cp_i + cp_j) of pair_math and round once less)
+                const float cpj = in_vgpr(cps * e.y), wj = in_vgpr(e.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e.x) : 0.f);
+                const float tt = pair_math(q.x, q.y, q.z, w.x, w.y, w.z, cpj, wj, valid);
+                if (COLL && __ballot(tt < 0.f) != 0ull) {            // candidate order, as the staged walk's work-off
+                    if (tt < 0.f) collide_math(q.x, q.y, q.z, w.x, w.y, w.z);
+                }
+            }
+        });
+        finish();
+        return;
+    }
     traverse(
         H,
         [&](uint32_t a) {
@@ -676,35 +912,10 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             auto pair = [&](int u, bool valid) {
                 const lds_v2f_ptr e = (lds_v2f_ptr)s_e + (idx + u) * 5;
                 const v2f qa = e[0], qb = e[1];
-                const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
-                // r^2 + 1e-30: the tiny term rides in the first fma for free and is far below one ulp of any
-                // r^2 that matters.  r = 0 (the particle itself, coincident particles): 1/r is capped at 1e15,
-                // r*1/r = 0, and the huge but finite pressure weight multiplies r_ij = 0 -- no pressure term,
-                // as with Eigen's normalized() of a zero vector (Dot.h:124-134); the viscous term is exact.
-                float r2 = fmaf(dz, dz, fmaf(dx, dx, fmaf(dy, dy, 1e-30f)));
-                // a lane beyond its range (the tail of the walk): ONE select makes the candidate infinitely far away --
-                // h - r clamps to 0 (no force, no viscosity weight) and r2 - coll is positive (no collision bit)
-                r2 = valid ? r2 : 1e30f;
-                if (FORCE) {
-                    const v2f qc = e[2], qd = e[3];
-                    const float rinv = inv_sqrt(r2);
-                    // both kernels vanish continuously at r = h, so "r < h" is max(h - r, 0): one v_max instead
-                    // of a compare and two selects
-                    const float hr = fmaxf(fmaf(-r2, rinv, h_v), 0.f);
-                    const float w = qd.y * hr;                              // VISC m VISC_LAP (h-r) / rho_j
-                    const float s = (cpi + qd.x) * w * (hr * rinv);         // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
-                    fpx += s * dx; fpy += s * dy; fpz += s * dz;
-#if SPH_VISC_SPLIT
-                    fvx += w * qb.y; fvy += w * qc.x; fvz += w * qc.y;      // sum w_j v_j  (v_i sum w_j: epilogue)
-                    sw += w;
-#else
-                    fvx += w * (qb.y - vi.x); fvy += w * (qc.x - vi.y); fvz += w * (qc.y - vi.z);
-#endif
-                }
-                if (COLL) {
-                    const float t = r2 - coll_next_v;               // negative <=> within collision range
-                    near = __builtin_amdgcn_alignbit(near, __float_as_uint(t), 31);   // (near << 1) | sign(t)
-                }
+                v2f qc = {0.f, 0.f}, qd = {0.f, 0.f};
+                if (FORCE) { qc = e[2]; qd = e[3]; }
+                const float t = pair_math(qa.x, qa.y, qb.x, qb.y, qc.x, qc.y, qd.x, qd.y, valid);
+                if (COLL) near = __builtin_amdgcn_alignbit(near, __float_as_uint(t), 31);   // (near << 1) | sign(t)
             };
             for (uint32_t t0 = 0; t0 < T; t0 += 32u) {
                 const uint32_t tend = min(T, t0 + 32u);
@@ -737,76 +948,19 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                             const uint32_t ci = idx0 + (done - 1u - hb);
                             const float2* e = &s_e[(ci << 2) + ci];          // ci * 5 without v_mul_lo_u32
                             const float2 qa = e[0], qb = e[1], qc = e[2];
-                            const float dx = pi.x - qa.x, dy = pi.y - qa.y, dz = pi.z - qb.x;
-                            const float ux = qb.y - vi.x, uy = qc.x - vi.y, uz = qc.y - vi.z;
-                            // computeCollision (particleSystem.cu:52-65) decides on dij = sqrtf(rij.squaredNorm()) <= 2R
-                            // and rij.dot(vij) < 0, Eigen reducing a 3-vector as a0 + (a1 + a2) with one rounding per
-                            // operation.  Both predicates are evaluated exactly that way (no contraction), so that on
-                            // identical inputs the same pairs collide as in the reference: sqrtf is monotone, hence
-                            // dij <= 2R  <=>  r2 <= coll_dist2 (the largest float whose root is <= 2R, derive()).
-                            // j == i needs no test: r_ij = 0 gives r.v = -0, which is not < 0 (the reference skips
-                            // the pair by index, :54; a coincident pair fails r.v < 0 there too).
-                            float r2c, dot;
-                            {
-#pragma clang fp contract(off)
-                                r2c = dx * dx + (dy * dy + dz * dz);
-                                dot = -(dx * ux + (dy * uy + dz * uz));                 // r_ij . (v_i - v_j)
-                            }
-                            const bool hit = r2c <= ph.coll_dist2 && dot < 0.f;
-#if SPH_COLL_EXACT_DIV
-                            float cfac = 0.f;
-                            if (hit) { const float dij = sqrtf(r2c); cfac = ph.coll_mass * (dot / (dij * dij)); }
-#else
-                            const float cfac = hit ? ph.coll_mass * dot * __builtin_amdgcn_rcpf(r2c) : 0.f;
-#endif
-                            cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
-                            ccount += hit ? 1u : 0u;
+                            collide_math(qa.x, qa.y, qb.x, qb.y, qc.x, qc.y);
                         }
                     }
                 }
             }
         });
-    if (FORCE && SPH_VISC_SPLIT) { fvx = fmaf(-vi.x, sw, fvx); fvy = fmaf(-vi.y, sw, fvy); fvz = fmaf(-vi.z, sw, fvz); }
-    bool moved = false;
-    if (active) {
-        float dvx = 0.f, dvy = 0.f, dvz = 0.f;
-        if (COLL) {
-            const float den = ph.mass * (float)(1u + ccount);
-            dvx = -cvx / den; dvy = -cvy / den; dvz = -cvz / den;
-        }
-        if (INTEG) {
-            integrate_one(ph, dt, pi, vi, dpi.x, fpx + fvx, fpy + fvy, fpz + fvz, dvx, dvy, dvz);
-            posi_out[i] = pi;
-            velr_out[i] = vi;
-            if (pos_by_index) pos_by_index[__float_as_uint(pi.w)] = make_float4(pi.x, pi.y, pi.z, 1.0f);
-            // the next step's cell hash (kernelGetZIndex) while the new position is still in registers
-            const uint32_t key = cell_key(g, pi.x, pi.y, pi.z);
-            keys_out[i - slot0] = key;                      // slot0: first owned slot (the launch may cover a sub-range)
-            if (mm_mask) moved = key != keyS[i];
-        } else {
-            if (FORCE) {
-                fpress[i] = make_float4(fpx, fpy, fpz, 0.f);
-                fvisc[i] = make_float4(fvx, fvy, fvz, 0.f);
-            }
-            if (COLL) dvel[i] = make_float4(dvx, dvy, dvz, __uint_as_float(ccount));
-        }
-    }
-    if (INTEG && mm_mask) {
-        // movers of the next sort (sph_sort.hip: the merge path), one bit per slot: this wave IS one 64-slot chunk
-        // (a sub-range launch starts on a chunk boundary: lo - slot0, gap_lo - lo and gap_len are multiples of 64)
-        const uint64_t m = __ballot(moved);
-        const uint32_t chunk = (wave_first - slot0) >> 6;
-        if (lane == 0) {
-            mm_mask[chunk] = m;
-            if (m) atomicAdd(&mm_tile_cnt[chunk / MM_TILE_CHUNKS], (uint32_t)__popcll(m));
-        }
-    }
+    finish();
 }
 
 // [lo, hi) minus the hole [hole_lo, hole_hi): the hole's start is rounded UP to a whole wave from lo (see Targets),
 // what is cut off the hole that way is simply computed by this launch as well.
 static Targets targets_with_hole(uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi, uint32_t& threads) {
-    Targets t{lo, hi, hi, 0u, nullptr};
+    Targets t{lo, hi, hi, 0u, nullptr, 0u};
     threads = hi - lo;
     if (hole_lo < lo) hole_lo = lo;
     if (hole_hi > hi) hole_hi = hi;
@@ -825,7 +979,8 @@ int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, ui
     if (hi <= lo) return SPH_OK;
     SPH_REQUIRE(((lo - c->own_off) & 63u) == 0u, SPH_E_INVALID, "force sub-range does not start on a 64-slot chunk");
     uint32_t threads;
-    const Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
+    Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
+    tg.direct_hull = c->direct_hull;
     SPH_REQUIRE(tg.gap_len == 0u || (((tg.gap_lo - lo) | tg.gap_len) & 63u) == 0u || tg.gap_lo + tg.gap_len == hi, SPH_E_INVALID,
                 "force hole is not made of whole 64-slot chunks");
     if (threads == 0) return SPH_OK;
@@ -894,7 +1049,8 @@ static int launch_density_targets(sph_ctx* c, const Targets& tg, uint32_t thread
 int launch_density_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi) {
     if (hi <= lo) return SPH_OK;
     uint32_t threads;
-    const Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
+    Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
+    tg.direct_hull = c->direct_hull;
     return launch_density_targets(c, tg, threads);
 }
 
@@ -903,7 +1059,7 @@ int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi) { return launch_d
 // density over the slots [range_dev[0], range_dev[1]) -- two words of DEVICE memory written by an earlier kernel of
 // the stream; at most max_count slots (sizes the grid; waves beyond the range leave at once)
 int launch_density_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count) {
-    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev};
+    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev, c->direct_hull};
     return launch_density_targets(c, tg, max_count);
 }
 

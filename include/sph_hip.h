@@ -218,6 +218,12 @@ int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skip
  * environment selects at sph_create time); 2: the merge path whenever the previous order is intact, whatever
  * the count (it is exact for any count; for tests).  Takes effect at the next sort. */
 int sph_set_sort_mode(sph_ctx* c, int merge);
+/* The neighbour passes stage, per (dz, dy) row, the hull of a wave's candidate ranges through LDS.  A row whose hull
+ * is longer than `slots` (default 512; usual hulls are ~80) is read straight from global memory by every lane instead
+ * -- sparse particles next to a dense layer would otherwise stage thousands of slots for a handful of candidates each
+ * and become the tail of the whole launch.  Both ways give the same bits.  0: every row direct; 0xFFFFFFFF: never
+ * (for tests and A/B runs).  Takes effect at the next launch. */
+int sph_set_direct_hull(sph_ctx* c, uint32_t slots);
 /* 1 if the last sph_sort found that no particle had changed cell and left everything as it was (then
  * every count derived from the sorted order -- sph_slab_counts, sph_halo_count -- is that of the step
  * before), else 0.  No synchronisation. */

@@ -16,4 +16,4 @@ with capi.Context(n, box=cfg["box"], grid=cfg["grid"]) as c:
         lib.sph_debug_pair_stats(out, 0)
         w = out[0]
         print(label, "waves", w, "pieces/wave %.2f" % (out[1] / w), "walk T/wave %.1f" % (out[2] / w), "chunks/wave %.2f" % (out[3] / w),
-              "coll rounds/wave %.2f" % (out[4] / w), "lanes with near bits per chunk %.1f" % (out[5] / max(out[3], 1)))
+              "coll rounds/wave %.2f" % (out[4] / w), "waves with a hull > 256 / 512 / 2048 slots: %d / %d / %d" % (out[5], out[6], out[7]))
