@@ -95,6 +95,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_uint64)]),
     "sph_set_sort_mode": (C.c_int, [_P, C.c_int]),
     "sph_set_direct_hull": (C.c_int, [_P, C.c_uint32]),
+    "sph_sort_forms": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "sph_set_precision": (C.c_int, [_P, C.c_int]),
     "sph_get_precision": (C.c_int, [_P]),
     "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
@@ -394,6 +395,12 @@ class Context:
         """merge=False/0: full radix sort every step (the SPH_SORT_MERGE=0 behaviour); True/1: merge while few
         particles change cell; 2: merge whatever the count (tests)."""
         _check(self.L.sph_set_sort_mode(self.h, int(merge)))
+
+    def sort_forms(self):
+        """Movers' sorts launched as (both forms, one-block sort alone, multi-block passes alone)."""
+        out = (C.c_uint64 * 3)()
+        _check(self.L.sph_sort_forms(self.h, out))
+        return tuple(int(v) for v in out)
 
     def set_direct_hull(self, slots=512):
         """Rows of the neighbour passes whose staged hull would exceed `slots` are read straight from global memory

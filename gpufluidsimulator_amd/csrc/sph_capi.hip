@@ -954,6 +954,12 @@ int sph_set_sort_mode(sph_ctx* c, int merge) {
     return SPH_OK;
 }
 
+int sph_sort_forms(const sph_ctx* c, uint64_t out[3]) {
+    SPH_REQUIRE(c && out, SPH_E_INVALID, "null argument");
+    for (int k = 0; k < 3; k++) out[k] = c->sort_forms[k];
+    return SPH_OK;
+}
+
 int sph_set_direct_hull(sph_ctx* c, uint32_t slots) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     c->direct_hull = slots;

@@ -125,6 +125,7 @@ struct sph_ctx {
     bool host_paced = false;
     bool mm_counted_valid = false;  // mm_counted was recorded behind the scan of the CURRENT marks
     uint64_t sort_merges = 0, sort_calls = 0, sort_skips = 0;   // skips: merges with no mover at all (nothing done)
+    uint64_t sort_forms[3] = {0, 0, 0};   // movers' sorts launched as: both forms / the one-block sort alone / the multi-block passes alone
     uint64_t* mm_mask = nullptr;    // one bit per slot: key changed since the last sort
     uint32_t* mm_M64 = nullptr;     // movers before each 64-slot chunk
     uint32_t* mm_tile_cnt = nullptr; uint32_t* mm_tile_off = nullptr;

@@ -575,11 +575,19 @@ __device__ __forceinline__ uint32_t small_lower_bound(const uint32_t* sk, const 
     return lo;
 }
 
+__device__ __forceinline__ uint32_t mm_lower_bound(const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
+                                                   uint32_t lo, uint32_t hi, uint32_t key, uint32_t slot, Front f);
+
+// `alone`: no other sort kernel is launched beside this one (radix_sort_bits, when the host's last known count says the
+// movers fit): then a count beyond OS_SMALL_MAX -- the first step of a burst, one step ahead of the host's knowledge --
+// is sorted here all the same, by this ONE block, tile by tile through global memory (correct for any count, slow for
+// large ones: ~10 us per tile and pass; the next sort sees the count and takes the multi-block form).  The pairs
+// alternate between the buffers (ak, av) -- the input -- and (bk, bv); the result ends in (ak, av) after an even number
+// of passes, else in (bk, bv): where the multi-block passes would have left it.
 template <int BITS>
-__global__ __launch_bounds__(SMALL_THREADS) void k_os_small(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                            uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+__global__ __launch_bounds__(SMALL_THREADS) void k_os_small(uint32_t* ak, uint32_t* av, uint32_t* bk, uint32_t* bv,
                                                             const uint32_t* __restrict__ n_dev, uint32_t n_cap, uint32_t passes,
-                                                            const uint32_t* __restrict__ A, uint32_t n_slots, Front front,
+                                                            bool alone, const uint32_t* __restrict__ A, uint32_t n_slots, Front front,
                                                             uint32_t* __restrict__ tileL, uint32_t* __restrict__ tileA) {
     constexpr int RADIX = 1 << BITS;
     // ONE buffer for the pairs: a pass ranks from registers into LDS, everybody reads its rows back, the next pass
@@ -588,9 +596,97 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_os_small(const uint32_t* __re
     __shared__ uint32_t wh[SMALL_WAVES][RADIX];
     __shared__ uint32_t s_wtot[SMALL_WAVES];
     const uint32_t m = min(*n_dev, n_cap);
-    if (m > OS_SMALL_MAX) return;                               // block-uniform, before any barrier
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t* kin = ak; const uint32_t* vin = av;
+    uint32_t* kout = (passes & 1u) ? bk : ak; uint32_t* vout = (passes & 1u) ? bv : av;
+    if (m > OS_SMALL_MAX) {                                     // block-uniform, before any barrier
+        if (!alone) return;                                     // the multi-block kernels launched beside this one sort it
+        uint32_t* const gbase = s_key;                          // (the pair buffers are free on this path)
+        uint32_t* const ghist = s_val;
+        const uint32_t wbase_t = wave * (WAVE * SMALL_KPT);
+        for (uint32_t p = 0; p < passes; p++) {
+            const uint32_t shift = p * BITS;
+            const uint32_t* sk = (p & 1u) ? bk : ak; const uint32_t* sv = (p & 1u) ? bv : av;
+            uint32_t* dk = (p & 1u) ? ak : bk; uint32_t* dv = (p & 1u) ? av : bv;
+            for (int d = threadIdx.x; d < RADIX; d += SMALL_THREADS) ghist[d] = 0;
+            __syncthreads();
+            for (uint32_t i0 = wave * WAVE; i0 < m; i0 += SMALL_THREADS) {          // wave-uniform bounds
+                const uint32_t i = i0 + lane;
+                const uint32_t k = i < m ? sk[i] : 0u;
+                wave_count_digit(ghist, (k >> shift) & (RADIX - 1), i < m);
+            }
+            __syncthreads();
+            {
+                const uint32_t cnt = threadIdx.x < (uint32_t)RADIX ? ghist[threadIdx.x] : 0u;
+                const uint32_t start = block_excl_scan<SMALL_WAVES>(cnt, s_wtot, nullptr);
+                if (threadIdx.x < (uint32_t)RADIX) gbase[threadIdx.x] = start;
+            }
+            __syncthreads();
+            for (uint32_t tile0 = 0; tile0 < m; tile0 += OS_SMALL_MAX) {
+                const uint32_t mt = min(OS_SMALL_MAX, m - tile0);
+                uint32_t key[SMALL_KPT], val[SMALL_KPT];
+#pragma unroll
+                for (int t = 0; t < SMALL_KPT; t++) {
+                    const uint32_t j = wbase_t + t * WAVE + lane;
+                    key[t] = j < mt ? sk[tile0 + j] : 0xFFFFFFFFu;
+                    val[t] = j < mt ? sv[tile0 + j] : 0u;
+                }
+                for (int d = threadIdx.x; d < SMALL_WAVES * RADIX; d += SMALL_THREADS) (&wh[0][0])[d] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < SMALL_KPT; t++) {
+                    if (wbase_t + t * WAVE >= mt) break;                            // wave-uniform
+                    wave_count_digit(wh[wave], (key[t] >> shift) & (RADIX - 1), wbase_t + t * WAVE + lane < mt);
+                }
+                __syncthreads();
+                if (threadIdx.x < (uint32_t)RADIX) {            // first output position of (wave, digit); the digit's run moves on
+                    uint32_t run = gbase[threadIdx.x];
+#pragma unroll
+                    for (int w = 0; w < SMALL_WAVES; w++) { const uint32_t c = wh[w][threadIdx.x]; wh[w][threadIdx.x] = run; run += c; }
+                    gbase[threadIdx.x] = run;
+                }
+                __syncthreads();
+                const lds_u32_ptr pos = (lds_u32_ptr)wh[wave];
+#pragma unroll
+                for (int t = 0; t < SMALL_KPT; t++) {
+                    if (wbase_t + t * WAVE >= mt) break;                            // wave-uniform
+                    const bool valid = wbase_t + t * WAVE + lane < mt;
+                    const uint32_t d = (key[t] >> shift) & (RADIX - 1);
+                    uint32_t dif_lo = 0u, dif_hi = 0u;
+#pragma unroll
+                    for (int b = 0; b < BITS; b++) {
+                        const uint32_t bm = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+                        const uint64_t mm = __ballot(bm != 0u);
+                        dif_lo |= (uint32_t)mm ^ bm;
+                        dif_hi |= (uint32_t)(mm >> 32) ^ bm;
+                    }
+                    const uint64_t vmask = __ballot(valid);
+                    const uint32_t peers_lo = ~dif_lo & (uint32_t)vmask, peers_hi = ~dif_hi & (uint32_t)(vmask >> 32);
+                    const uint32_t rank = (uint32_t)__popc(peers_lo & (uint32_t)lt_mask) + (uint32_t)__popc(peers_hi & (uint32_t)(lt_mask >> 32));
+                    uint32_t base = 0;
+                    if (valid) base = pos[d];
+                    os_wave_lds_order();
+                    if (valid && rank == 0) pos[d] = base + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi);
+                    os_wave_lds_order();
+                    if (valid) { dk[base + rank] = key[t]; dv[base + rank] = val[t]; }
+                }
+                __syncthreads();                                // wh is zeroed for the next tile
+            }
+            __threadfence();                                    // the next pass (other waves of this block) reads what this one wrote
+            __syncthreads();
+        }
+        if (A) {                                                // the merge's coarse ranks (k_mm_tile_rank's job)
+            const uint32_t ntiles = (n_slots + OS_TILE - 1) / OS_TILE;
+            for (uint32_t t = threadIdx.x; t <= ntiles; t += SMALL_THREADS) {
+                const uint32_t slot = t * OS_TILE;
+                const uint32_t a = t == ntiles ? 0xFFFFFFFFu : A[slot];
+                tileA[t] = a;
+                tileL[t] = t == ntiles ? m : mm_lower_bound(kout, vout, 0u, m, a, slot, front);
+            }
+        }
+        return;
+    }
     // rows of 64 pairs per wave: as few as the count needs, so that all 16 waves share a small sort (a wave ranks its rows
     // one after the other: 2000 movers are 2 rows for each of 16 waves, not 8 rows for 4 of them)
     const uint32_t R = max((((m + 63u) >> 6) + SMALL_WAVES - 1u) / SMALL_WAVES, 1u);        // <= SMALL_KPT
@@ -769,7 +865,10 @@ struct SmallTail {
     const uint32_t* A = nullptr;
     uint32_t n_slots = 0;
     Front front{0u, 0u};
+    uint32_t hint = 0xFFFFFFFFu;     // the count the device last reported (one step old in a host-paced context)
+    int* form = nullptr;             // out: which kernels were launched (SORT_FORM_*)
 };
+enum { SORT_FORM_BOTH = 0, SORT_FORM_SMALL = 1, SORT_FORM_BIG = 2 };
 
 #ifndef SPH_OS_SMALL
 #define SPH_OS_SMALL 1          // 0: never take the one-block sort (A/B runs)
@@ -779,20 +878,37 @@ static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32
                            uint32_t*& kin, uint32_t*& vin, uint32_t*& kout, uint32_t*& vout, const SmallTail& tail) {
     constexpr uint32_t RADIX = 1u << BITS;
     // counts the device may hand to the one-block sort (only when the count lives on the device: the movers' sort)
-    const uint32_t small_max = (SPH_OS_SMALL && n_dev && !first) ? OS_SMALL_MAX : 0u;
-    const uint32_t* kin0 = kin; const uint32_t* vin0 = vin;
+    uint32_t small_max = (SPH_OS_SMALL && n_dev && !first) ? OS_SMALL_MAX : 0u;
+    // The count lives on the device, so in general BOTH forms are launched and each looks at the count first -- six
+    // dispatches that do nothing when the one-block sort takes it (37 us of a 0.63 ms slab step).  A host-paced context
+    // (a slab: its host waits for the device once per step) knows the count of the PREVIOUS sort exactly, and the movers
+    // of a flow change slowly except at the first step of a burst: there only the form that count asks for is launched.
+    // Each form is correct for any count on its own (k_os_small: `alone`); a wrong guess costs time once per burst.
+    int form = SORT_FORM_BOTH;
+    if (small_max && c->host_paced) form = tail.hint <= OS_SMALL_MAX ? SORT_FORM_SMALL : SORT_FORM_BIG;
+    if (tail.form) *tail.form = form;
+    if (small_max) c->sort_forms[form]++;
+    if (form == SORT_FORM_BIG) small_max = 0u;               // the multi-block kernels do not look for a small count
+    uint32_t* const kin0 = kin; uint32_t* const vin0 = vin;
     const bool one_group = grid <= OS_ONE_GROUP_TILES;          // `grid` = tiles expected (exact, or from the hint)
     const uint32_t group_tiles = one_group ? OS_ALL_TILES : OS_GROUP;
     const uint32_t hist_grid = min(ceil_div(grid, OS_HIST_TILES), 4096u);
     const uint32_t gcap = c->os_groups_cap;                     // tickets: [pass][group]
-    if (one_group) {                                            // every pass from one histogram of the input
+    if (form == SORT_FORM_SMALL) {                              // only the buffers take their turns
+        for (uint32_t p = 0; p < passes; p++) {
+            uint32_t* t;
+            t = kin; kin = kout; kout = t;
+            t = vin; vin = vout; vout = t;
+        }
+    }
+    if (one_group && form != SORT_FORM_SMALL) {                 // every pass from one histogram of the input
         hipLaunchKernelGGL(k_os_hist<BITS>, dim3(hist_grid), dim3(SORT_THREADS), 0, c->stream, kin, n, n_dev, 0u, passes,
                            group_tiles, c->os_hist, small_max);
         hipLaunchKernelGGL(k_os_scan<BITS>, dim3(RADIX / 4, passes), dim3(256), 0, c->stream, c->os_hist, c->os_base, c->os_tot,
                            n, n_dev, c->os_tickets, gcap, 0u, group_tiles, small_max);
         SPH_HIP(hipGetLastError());
     }
-    for (uint32_t p = 0; p < passes; p++) {
+    for (uint32_t p = 0; p < passes && form != SORT_FORM_SMALL; p++) {
         if (!one_group) {                                       // the groups' counts of the keys as this pass finds them
             hipLaunchKernelGGL(k_os_hist<BITS>, dim3(hist_grid), dim3(SORT_THREADS), 0, c->stream, kin, n, n_dev, p, 1u,
                                group_tiles, c->os_hist, small_max);
@@ -824,9 +940,10 @@ static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32
     }
     if (small_max) {
         // the one-block sort: from the ORIGINAL input into the buffers the passes above would have ended in (they left at
-        // once if this kernel takes the count, and this kernel leaves at once if it does not)
-        hipLaunchKernelGGL(k_os_small<BITS>, dim3(1), dim3(SMALL_THREADS), 0, c->stream, kin0, vin0, kin, vin, n_dev, n, passes,
-                           tail.A, tail.n_slots, tail.front, c->mm_tileL, c->mm_tileA);
+        // once if this kernel takes the count, and this kernel leaves at once if it does not -- unless it is alone)
+        uint32_t* const bk = (passes & 1u) ? kin : kout; uint32_t* const bv = (passes & 1u) ? vin : vout;    // the buffers that are not the input
+        hipLaunchKernelGGL(k_os_small<BITS>, dim3(1), dim3(SMALL_THREADS), 0, c->stream, kin0, vin0, bk, bv, n_dev, n, passes,
+                           form == SORT_FORM_SMALL, tail.A, tail.n_slots, tail.front, c->mm_tileL, c->mm_tileA);
         SPH_HIP(hipGetLastError());
     }
     return SPH_OK;
@@ -949,12 +1066,13 @@ constexpr uint32_t MM_RANK_TILE = 4096;
 __global__ __launch_bounds__(256) void k_mm_tile_rank(const uint32_t* __restrict__ A, uint32_t n,
                                                       const uint32_t* __restrict__ mk, const uint32_t* __restrict__ mi,
                                                       const uint32_t* __restrict__ m_dev, uint32_t* __restrict__ tileL,
-                                                      uint32_t* __restrict__ tileA, uint32_t small_max, Front front) {
+                                                      uint32_t* __restrict__ tileA, bool small_too, uint32_t small_max,
+                                                      Front front) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t ntiles = (n + MM_RANK_TILE - 1) / MM_RANK_TILE;
     if (t > ntiles) return;
     const uint32_t m = *m_dev;
-    if (m <= small_max) return;                              // k_os_small ranked the tiles from its LDS copy
+    if (small_too && m <= small_max) return;                 // k_os_small (launched beside the passes) ranked the tiles from its LDS copy
     const uint32_t slot = t * MM_RANK_TILE;
     const uint32_t a = t == ntiles ? 0xFFFFFFFFu : A[slot];
     tileA[t] = a;                      // first key of every tile: the coarse level of k_mm_place_movers' searches
@@ -1149,13 +1267,16 @@ static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_
                        c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr);
     SPH_HIP(hipGetLastError());
     SmallTail tail;
-    tail.A = A; tail.n_slots = n; tail.front = front;
+    int form = SORT_FORM_BOTH;
+    tail.A = A; tail.n_slots = n; tail.front = front; tail.hint = hint; tail.form = &form;
     int rc = radix_sort_pairs(c, n_tot, c->mm_count, merge_grid_for(hint, n_tot), false, mk, mi, mk2, mi2, tail);
     if (rc) return rc;
-    const uint32_t rank_tiles = ceil_div(n, MM_RANK_TILE) + 1u;
-    hipLaunchKernelGGL(k_mm_tile_rank, dim3(ceil_div(rank_tiles, 256u)), dim3(256), 0, c->stream, A, n, mk, mi, c->mm_count,
-                       c->mm_tileL, c->mm_tileA, SPH_OS_SMALL ? OS_SMALL_MAX : 0u, front);
-    SPH_HIP(hipGetLastError());
+    if (form != SORT_FORM_SMALL) {                              // (the one-block sort ranks the tile boundaries itself)
+        const uint32_t rank_tiles = ceil_div(n, MM_RANK_TILE) + 1u;
+        hipLaunchKernelGGL(k_mm_tile_rank, dim3(ceil_div(rank_tiles, 256u)), dim3(256), 0, c->stream, A, n, mk, mi, c->mm_count,
+                           c->mm_tileL, c->mm_tileA, SPH_OS_SMALL && form == SORT_FORM_BOTH, OS_SMALL_MAX, front);
+        SPH_HIP(hipGetLastError());
+    }
     uint32_t* perm = c->keep_perm ? c->v1 : (uint32_t*)nullptr;
     const float4* ps = c->posi + c->own_off; const float4* vs = c->velr + c->own_off;
     float4* po = c->posi2 + c->gcap; float4* vo = c->velr2 + c->gcap; uint32_t* ko = c->keyS2 + c->gcap;

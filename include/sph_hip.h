@@ -213,6 +213,10 @@ int sph_timing_reset(sph_ctx* c);
  * Any pointer may be NULL. */
 int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers,
                    uint64_t* movers_total);
+/* How the movers' sorts of the merge path were launched so far: out[0] both forms (the count lives on the device, each
+ * kernel looks at it and leaves if it is not its turn), out[1] the one-block sort alone, out[2] the multi-block passes
+ * alone -- the last two only in host-paced (slab) contexts, from the previous sort's count.  No synchronisation. */
+int sph_sort_forms(const sph_ctx* c, uint64_t out[3]);
 /* merge = 1 (default): the sort takes the merge path while few particles change cell (up to 1/8 of them, by
  * the count the device last reported); 0: the full radix sort every step (what SPH_SORT_MERGE=0 in the
  * environment selects at sph_create time); 2: the merge path whenever the previous order is intact, whatever

@@ -38,7 +38,7 @@ def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport=
             cuts0 = list(sim.cuts)
             sim.run(DT, steps, rebalance_every=rebalance_every)
             sim.sync()
-            results[r] = (sim.gather_state(), dict(sim.stats), sim.cuts, sim.engine.n, cuts0)
+            results[r] = (sim.gather_state(), dict(sim.stats, sort_forms=sim.engine.ctx.sort_forms()), sim.cuts, sim.engine.n, cuts0)
             sim.close()
         except BaseException as e:     # noqa: BLE001
             errors.append(e)
@@ -435,3 +435,44 @@ def test_slab_fuzz(seed):
     assert sum(r[3] for r in res) == pos.shape[0]
     assert all(r[1]["host_waits"] == steps + r[1]["far_steps"] for r in res)
     _same_bits(st, ref)
+
+
+@pytest.mark.parametrize("case", ["burst", "ramp"])
+def test_movers_sort_forms_in_a_slab(case):
+    """A slab's host knows the mover count of the PREVIOUS sort and launches only the sort form that count asks for
+    (csrc/sph_sort.hip: radix_sort_bits).  "burst": nothing moves for three steps, then half of all particles change
+    cell in ONE step (every other lattice plane in x crosses its cell face): 65,536 movers per slab reach a one-block
+    sort that was launched alone for "at most 8192" -- it sorts them all the same (tile by tile, `alone`).  "ramp": half
+    of the particles cross over four steps, 10,000 - 16,000 per slab and step: the multi-block passes launched alone.
+    Bit for bit the whole-domain result."""
+    cfg = ic.CONFIGS["C2"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=False)
+    if case == "burst":
+        vel[:, 0] = 8000.0                               # 0.004 per step: the planes 0.0156 below a face cross in step 4
+    else:
+        idx = np.arange(pos.shape[0])
+        ix, iz = idx % 64, idx // (64 * 64)
+        rng = np.random.default_rng(2)
+        sel = ix % 2 == 1
+        vel[sel, 0] = rng.uniform(3906.0, 8000.0, int(sel.sum())).astype(np.float32)
+    # (ramp: viscosity brakes them; measured on the device, the whole domain has 20,825 / 32,271 / 28,817 / 22,672 movers
+    # in steps 9 .. 12 -- per slab between 8192 and the 16,384 beyond which the next sort is a full radix sort)
+    steps = 8 if case == "burst" else 13
+    res = _run_slabs(2, cfg["box"], cfg["grid"], steps, particles=(pos, vel))
+    forms = [r[1]["sort_forms"] for r in res]
+    assert all(f[0] == 0 for f in forms), forms          # a slab never launches both forms
+    if case == "burst":
+        assert all(f[1] >= 3 for f in forms), forms
+    else:
+        assert all(f[1] >= 1 and f[2] >= 1 for f in forms), forms
+    with capi.Context(pos.shape[0], box=cfg["box"], grid=cfg["grid"]) as c:
+        c.upload(pos, vel)
+        c.step(DT, 3)
+        q0 = c.sort_stats()
+        c.step(DT, 2)
+        q1 = c.sort_stats()
+        c.step(DT, steps - 5)
+        ref = c.download()
+    if case == "burst":
+        assert q1["movers_total"] - q0["movers_total"] >= 100000, (q0, q1)      # the burst is what the docstring says
+    _same_bits(res[0][0], ref)
