@@ -71,6 +71,7 @@ static int derive(sph_ctx* c, const sph_params* p, uint32_t z_lo, uint32_t z_hi,
     ph.poly6_mass = p->mass * poly6;
     ph.spiky_half_mass = p->mass * spiky * 0.5f;
     ph.visc_coef = (p->viscosity * p->mass) * spiky;
+    ph.cp_scale = ph.spiky_half_mass / ph.visc_coef;
     ph.gravity_y = p->gravity_y;
     ph.wall_eps = p->wall_eps;
     ph.wall_damping = p->wall_damping;
@@ -100,7 +101,7 @@ static int dev_alloc(T** p, size_t count) {
 }
 
 static void free_all(sph_ctx* c) {
-    hipFree(c->posi); hipFree(c->velr); hipFree(c->posi2); hipFree(c->velr2); hipFree(c->keyS); hipFree(c->dp);
+    hipFree(c->posi); hipFree(c->velr); hipFree(c->posi2); hipFree(c->velr2); hipFree(c->keyS); hipFree(c->dp); hipFree(c->cw);
     hipFree(c->fpress); hipFree(c->fvisc); hipFree(c->dvel); hipFree(c->pos_out); hipFree(c->cells_base);
     hipFree(c->k0); hipFree(c->v0); hipFree(c->k1); hipFree(c->v1); hipFree(c->os_hist); hipFree(c->os_base); hipFree(c->os_tickets); hipFree(c->os_tot); hipFree(c->os_status); hipFree(c->os_status32); hipFree(c->keyS2); hipFree(c->mm_tileL); hipFree(c->mm_tileA);
     if (c->os_err_host) hipHostFree(c->os_err_host);
@@ -151,6 +152,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (!rc) rc = dev_alloc(&c->keyS, tot);
     if (!rc) rc = dev_alloc(&c->keyS2, tot);
     if (!rc) rc = dev_alloc(&c->dp, tot);
+    if (!rc) rc = dev_alloc(&c->cw, tot);
     if (!rc) rc = dev_alloc(&c->fpress, tot);
     if (!rc) rc = dev_alloc(&c->fvisc, tot);
     if (!rc) rc = dev_alloc(&c->dvel, tot);
@@ -236,6 +238,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
         rc = SPH_E_DEVICE;
     }
     if (!rc && (hipMemset(c->dp, 0, tot * sizeof(float2)) != hipSuccess ||
+                hipMemset(c->cw, 0, tot * sizeof(float2)) != hipSuccess ||
                 hipMemset(c->posi, 0, tot * sizeof(float4)) != hipSuccess ||
                 hipMemset(c->velr, 0, tot * sizeof(float4)) != hipSuccess ||
                 hipMemset(c->posi2, 0, tot * sizeof(float4)) != hipSuccess ||
@@ -487,6 +490,7 @@ int sph_upload(sph_ctx* c, uint32_t n, const float* pos, const float* vel, const
         SPH_HIP(hipMemcpyAsync(c->posi + c->own_off, hp.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         SPH_HIP(hipMemcpyAsync(c->velr + c->own_off, hv.data(), n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
         SPH_HIP(hipMemsetAsync(c->dp + c->own_off, 0, n * sizeof(float2), c->stream));
+        SPH_HIP(hipMemsetAsync(c->cw + c->own_off, 0, n * sizeof(float2), c->stream));
         if (!c->slab) {
             // gl_pos starts as the initial positions (initGrid writes m_hPos, particleSystem.cpp:865-868)
             std::vector<float4> ho(c->pos_out_cap, make_float4(0.f, 0.f, 0.f, 0.f));

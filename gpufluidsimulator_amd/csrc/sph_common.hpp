@@ -39,6 +39,7 @@ struct Phys {
     float poly6_mass;      // MASS * 315/(65*pi*h^9)        (particleSystem.cu:30,35)
     float spiky_half_mass; // MASS * 45/(pi*h^6) / 2         (particleSystem.cu:41,47; sign folded)
     float visc_coef;       // VISC * MASS * 45/(pi*h^6)      (particleSystem.cu:42,48)
+    float cp_scale;        // spiky_half_mass / visc_coef: the pressure coefficient relative to the viscous one (sph_pairs.hip)
     float gravity_y;
     float wall_eps, wall_damping;
     float coll_dist2;      // (COLLISION_PARAM * 2 * radius)^2 (particleSystem.cu:61)
@@ -78,6 +79,8 @@ struct sph_ctx {
     uint32_t* keyS = nullptr; // cell key per slot (same indexing as posi)
     uint32_t* keyS2 = nullptr;// ping-pong target of the sort
     float2* dp = nullptr;     // density, pressure
+    float2* cw = nullptr;     // what the force pass needs of a NEIGHBOUR: cp_j = cp_scale * p_j, w_j = visc_coef / rho_j (0 where
+                              // rho_j = 0: padding), written by the density pass next to dp (neighbour_terms, sph_device.hpp)
     float4* fpress = nullptr; // phase API outputs
     float4* fvisc = nullptr;
     float4* dvel = nullptr;   // delta_velocity xyz, collision count

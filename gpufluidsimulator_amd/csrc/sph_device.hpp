@@ -71,6 +71,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// ---- what the force pass needs of a neighbour j (sph_pairs.hip: k_force) --------------------------------------------
+// cp_j = (spiky/visc) * p_j and w_j = visc * 1/rho_j (v_rcp_f32), so that the pair loop needs w = w_j * (h - r) for the
+// viscosity and (cp_i + cp_j) * w * (h - r) / r for the pressure.  rho = 0 (padding entries) -> weight 0.  Computed ONCE
+// per particle, by whoever writes its (rho, p) -- the density pass, the unpacking of a ghost layer's densities --
+// instead of at every staging of every wave that has the particle among its candidates (9 x 2 per wave in k_force).
+__device__ __forceinline__ float2 neighbour_terms(const Phys& ph, float rho, float p) {
+    return make_float2(ph.cp_scale * p, rho > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(rho) : 0.f);
+}
+
 // ---- cell hashing -------------------------------------------------------------------------
 // get_Z_index of the reference (particleSystem.cu:93-103): subtract boxMin, DIVIDE by the box
 // dimension, THEN multiply by the grid size, floor.  IEEE division (hipcc default

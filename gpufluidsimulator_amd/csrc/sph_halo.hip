@@ -12,6 +12,15 @@
 
 namespace sph {
 
+__global__ __launch_bounds__(256) void k_unpack_dp(const float2* __restrict__ src, float2* __restrict__ dp, float2* __restrict__ cw,
+                                                   uint32_t n, Phys ph) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    const float2 v = src[t];
+    dp[t] = v;
+    cw[t] = neighbour_terms(ph, v.x, v.y);
+}
+
 __global__ void k_lower_bounds(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ targets,
                                uint32_t m, uint32_t* __restrict__ out) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,14 +231,14 @@ int sph_halo_pack_density(sph_ctx* c, void* buf_dev[2], uint32_t capacity) {
 int sph_halo_unpack_density(sph_ctx* c, const void* lo_dev, const void* hi_dev) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     SPH_HIP(hipSetDevice(c->device));
-    if (c->n_glo) {
-        SPH_REQUIRE(lo_dev, SPH_E_INVALID, "null buffer");
-        SPH_HIP(hipMemcpyAsync(c->dp + c->own_off - c->n_glo, lo_dev, c->n_glo * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+    SPH_REQUIRE((!c->n_glo || lo_dev) && (!c->n_ghi || hi_dev), SPH_E_INVALID, "null buffer");
+    for (int side = 0; side < 2; side++) {       // (rho, p) and the neighbour terms the force pass reads of a ghost
+        const uint32_t cnt = side == 0 ? c->n_glo : c->n_ghi, at = side == 0 ? c->own_off - c->n_glo : c->own_off + c->n;
+        if (cnt)
+            hipLaunchKernelGGL(k_unpack_dp, dim3(ceil_div(cnt, 256u)), dim3(256), 0, c->stream,
+                               (const float2*)(side == 0 ? lo_dev : hi_dev), c->dp + at, c->cw + at, cnt, c->phys);
     }
-    if (c->n_ghi) {
-        SPH_REQUIRE(hi_dev, SPH_E_INVALID, "null buffer");
-        SPH_HIP(hipMemcpyAsync(c->dp + c->own_off + c->n, hi_dev, c->n_ghi * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
-    }
+    SPH_HIP(hipGetLastError());
     return SPH_OK;
 }
 

@@ -390,8 +390,8 @@ __device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, ui
 __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const float4* __restrict__ posi,
                                                                         const uint32_t* __restrict__ keyS,
                                                                         const uint2* __restrict__ cells,
-                                                                        float2* __restrict__ dp, Targets tg,
-                                                                        GridDesc g, Phys ph) {
+                                                                        float2* __restrict__ dp, float2* __restrict__ cw,
+                                                                        Targets tg, GridDesc g, Phys ph) {
 #ifndef SPH_DENS_SKEW
 #define SPH_DENS_SKEW 0      // 1: one pad entry per 32 (entries 32 apart then sit on different banks); experiment, see DESIGN 5
 #endif
@@ -436,6 +436,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
             float rho = acc * ph.poly6_mass;
             float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
             dp[i] = make_float2(rho, p);
+            cw[i] = neighbour_terms(ph, rho, p);
         }
     };
     if (wave_has_long_hull(H, my_key, tg.direct_hull)) {          // a branch of its own, to its own end: the staged walk keeps its registers
@@ -538,8 +539,8 @@ __device__ __forceinline__ PairWalk pair_walk(uint32_t slice_pairs, uint32_t l0,
 __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const float4* __restrict__ posi,
                                                                           const uint32_t* __restrict__ keyS,
                                                                           const uint2* __restrict__ cells,
-                                                                          float2* __restrict__ dp, Targets tg,
-                                                                          GridDesc g, Phys ph) {
+                                                                          float2* __restrict__ dp, float2* __restrict__ cw,
+                                                                          Targets tg, GridDesc g, Phys ph) {
     struct XY { h2 x, y; };                                   // 8 bytes: one ds_read_b64 per pair
     __shared__ XY s_xy[2 * LDS_PAIRS];
     __shared__ h2 s_z[2 * LDS_PAIRS];
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
             float rho = acc * (ph.poly6_mass * (h2f * h2f * h2f));          // m POLY6 h^6 sum (1 - r'^2)^3
             float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
             dp[i] = make_float2(rho, p);
+            cw[i] = neighbour_terms(ph, rho, p);
         }
     };
     if (wave_has_long_hull(H, my_key, tg.direct_hull)) {
@@ -701,7 +703,7 @@ extern "C" void sph_debug_pair_stats(unsigned long long* out, int on) {     // r
 template <bool FORCE, bool COLL, bool INTEG>
 __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     const float4* __restrict__ posi, const float4* __restrict__ velr, const float2* __restrict__ dp,
-    const uint32_t* __restrict__ keyS, const uint2* __restrict__ cells, float4* __restrict__ fpress,
+    const float2* __restrict__ cw, const uint32_t* __restrict__ keyS, const uint2* __restrict__ cells, float4* __restrict__ fpress,
     float4* __restrict__ fvisc, float4* __restrict__ dvel, float4* __restrict__ posi_out,
     float4* __restrict__ velr_out, float4* __restrict__ pos_by_index, uint32_t* __restrict__ keys_out,
     uint64_t* __restrict__ mm_mask, uint32_t* __restrict__ mm_tile_cnt, Targets tg,
@@ -738,8 +740,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
 #endif
     float4 q0, q1, w0, w1;
     float2 e0, e1;
-    const float cps = ph.spiky_half_mass / ph.visc_coef;   // pressure coefficient relative to the viscous one
-    const float cpi = cps * dpi.y;
+    const float cpi = ph.cp_scale * dpi.y;                 // (the lane's own cp: as neighbour_terms computes it)
     const float h_v = in_vgpr(ph.h);
     // Collision range, two stages.  The candidate loop only needs a cheap SUPERSET: its r2 comes out of three
     // fused multiply-adds and differs from the reference's x*x + (y*y + z*z) by a few ulps, so the mask bit is
@@ -858,12 +859,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                 const uint32_t j = valid ? l0 + t : me;              // a lane out of range reads itself (finite values, masked)
                 const float4 q = posi[j], w = velr[j];
                 float2 e = make_float2(0.f, 0.f);
-                if (FORCE) e = dp[j];
-                // cp_j, w_j exactly as the staging computes them
-                // (through in_vgpr: the staged walk reads these two back from LDS as ROUNDED products; left in the open
-                // here, hipcc would fuse cps * p_j into the (cp_i + cp_j) of pair_math and round once less)
-                const float cpj = in_vgpr(cps * e.y), wj = in_vgpr(e.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e.x) : 0.f);
-                const float tt = pair_math(q.x, q.y, q.z, w.x, w.y, w.z, cpj, wj, valid);
+                if (FORCE) e = cw[j];                                // cp_j, w_j
+                const float tt = pair_math(q.x, q.y, q.z, w.x, w.y, w.z, e.x, e.y, valid);
                 if (COLL && __ballot(tt < 0.f) != 0ull) {            // candidate order, as the staged walk's work-off
                     if (tt < 0.f) collide_math(q.x, q.y, q.z, w.x, w.y, w.z);
                 }
@@ -877,7 +874,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
         [&](uint32_t a) {
             q0 = posi[a + lane]; q1 = posi[a + WAVE + lane];
             w0 = velr[a + lane]; w1 = velr[a + WAVE + lane];
-            if (FORCE) { e0 = dp[a + lane]; e1 = dp[a + WAVE + lane]; }
+            if (FORCE) { e0 = cw[a + lane]; e1 = cw[a + WAVE + lane]; }
         },
         [&]() {
             float2* e0p = &s_e[(slice + lane) * 5];
@@ -888,12 +885,9 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             e1p[0] = make_float2(q1.x, q1.y);
             e1p[1] = make_float2(q1.z, w1.x);
             e1p[2] = make_float2(w1.y, w1.z);
-            if (FORCE) {
-                // staged per candidate: cp_j = (spiky/visc) * p_j and w_j = visc * 1/rho_j (v_rcp_f32), so
-                // that the pair loop needs w = w_j*(h-r) for viscosity and (cp_i+cp_j)*w*(h-r)/r for pressure.
-                // Padding entries have rho = 0 -> weight 0.
-                e0p[3] = make_float2(cps * e0.y, e0.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e0.x) : 0.f);
-                e1p[3] = make_float2(cps * e1.y, e1.x > 0.f ? ph.visc_coef * __builtin_amdgcn_rcpf(e1.x) : 0.f);
+            if (FORCE) {            // {cp_j, w_j} as the density pass left them (neighbour_terms); padding entries hold 0: weight 0
+                e0p[3] = e0;
+                e1p[3] = e1;
             }
         },
         [&](int r, uint32_t a, uint32_t b) {
@@ -986,7 +980,7 @@ int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, ui
     if (threads == 0) return SPH_OK;
     dim3 grid(ceil_div(threads, PAIR_THREADS)), block(PAIR_THREADS);
 #define SPH_LAUNCH_FORCE(F, C, I)                                                                              \
-    hipLaunchKernelGGL((k_force<F, C, I>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->keyS, c->cells, \
+    hipLaunchKernelGGL((k_force<F, C, I>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->cw, c->keyS, c->cells, \
                        c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, c->k0,              \
                        mark ? c->mm_mask : nullptr, c->mm_tile_cnt, tg, c->own_off, dt, c->grid, c->phys)
     if (force && collide && integrate) SPH_LAUNCH_FORCE(true, true, true);
@@ -1037,10 +1031,10 @@ static int launch_density_targets(sph_ctx* c, const Targets& tg, uint32_t thread
     if (threads == 0) return SPH_OK;
     if (c->precision == SPH_PRECISION_MIXED_F16)
         hipLaunchKernelGGL(k_density_h, dim3(ceil_div(threads, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
-                           c->keyS, c->cells, c->dp, tg, c->grid, c->phys);
+                           c->keyS, c->cells, c->dp, c->cw, tg, c->grid, c->phys);
     else
         hipLaunchKernelGGL(k_density, dim3(ceil_div(threads, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
-                           c->keyS, c->cells, c->dp, tg, c->grid, c->phys);
+                           c->keyS, c->cells, c->dp, c->cw, tg, c->grid, c->phys);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
 }

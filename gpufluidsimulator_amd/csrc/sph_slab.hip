@@ -215,6 +215,15 @@ __global__ __launch_bounds__(256) void k_slab_copy_dp2(const float2* __restrict_
     else if (t - n_lo < n_hi) dst_hi[t - n_lo] = src_hi[t - n_lo];
 }
 
+// ghost (rho, p) of both sides <- messages, with the neighbour terms the force pass reads of them (cw)
+__global__ __launch_bounds__(256) void k_slab_unpack_dp2(const float2* __restrict__ src_lo, float2* __restrict__ dp_lo,
+                                                         float2* __restrict__ cw_lo, uint32_t n_lo, const float2* __restrict__ src_hi,
+                                                         float2* __restrict__ dp_hi, float2* __restrict__ cw_hi, uint32_t n_hi, Phys ph) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n_lo) { const float2 v = src_lo[t]; dp_lo[t] = v; cw_lo[t] = neighbour_terms(ph, v.x, v.y); }
+    else if (t - n_lo < n_hi) { const float2 v = src_hi[t - n_lo]; dp_hi[t - n_lo] = v; cw_hi[t - n_lo] = neighbour_terms(ph, v.x, v.y); }
+}
+
 // Ghost records of both sides -> the slots in front of / behind the owned range, with their cell keys, AND the cell
 // table entries of the two ghost layers, in one launch: a thread recomputes the keys of its two neighbours from
 // their records instead of reading them back (boundary flags as in k_cells_build; the records are in key order).
@@ -900,8 +909,9 @@ int slab_step_once(sph_slab* s, float dt) {
                        s->dens_send[1], h_hi * sizeof(float2), s->dens_recv[1], g_hi * sizeof(float2));
     if (rc) return rc;
     if (g_lo + g_hi)
-        hipLaunchKernelGGL(k_slab_copy_dp2, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->dens_recv[0],
-                           c->dp + c->own_off - g_lo, g_lo, s->dens_recv[1], c->dp + c->own_off + n, g_hi);
+        hipLaunchKernelGGL(k_slab_unpack_dp2, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->dens_recv[0],
+                           c->dp + c->own_off - g_lo, c->cw + c->own_off - g_lo, g_lo, s->dens_recv[1], c->dp + c->own_off + n,
+                           c->cw + c->own_off + n, g_hi, c->phys);
     SPH_HIP(hipGetLastError());
     // the boundary layers' force pass: on the comm stream, behind the ghosts' (rho, p) -- beside the interior launch
     // (it reads what that one reads and writes other slots of the ping-pong arrays), not behind it
