@@ -665,7 +665,10 @@ __device__ __forceinline__ void wall(float& x, float& v, float lo, float hi, flo
 __device__ __forceinline__ void integrate_one(const Phys& ph, float dt, float4& pi, float4& vi, float rho, float fx,
                                               float fy, float fz, float dvx, float dvy, float dvz) {
     fy += ph.gravity_y * rho;
-    float ax = fx / rho, ay = fy / rho, az = fz / rho;
+    // one v_rcp_f32 (1 ulp) and three multiplications instead of three IEEE divisions (~10 instructions each): the
+    // acceleration moves by <= 1.5 ulp, five orders below the stated tolerance
+    const float ir = __builtin_amdgcn_rcpf(rho);
+    float ax = fx * ir, ay = fy * ir, az = fz * ir;
     vi.x += dt * ax + dvx;
     vi.y += dt * ay + dvy;
     vi.z += dt * az + dvz;
@@ -820,8 +823,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
         if (active) {
             float dvx = 0.f, dvy = 0.f, dvz = 0.f;
             if (COLL) {
-                const float den = ph.mass * (float)(1u + ccount);
-                dvx = -cvx / den; dvy = -cvy / den; dvz = -cvz / den;
+                const float nid = -__builtin_amdgcn_rcpf(ph.mass * (float)(1u + ccount));       // one v_rcp_f32 for the three components
+                dvx = cvx * nid; dvy = cvy * nid; dvz = cvz * nid;
             }
             if (INTEG) {
                 integrate_one(ph, dt, pi, vi, dpi.x, fpx + fvx, fpy + fvy, fpz + fvz, dvx, dvy, dvz);
