@@ -29,7 +29,8 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, 
 
 class Transport(C.Structure):
     """`sph_transport` of include/sph_hip.h."""
-    _fields_ = [("self", C.c_void_p), ("exchange", EXCHANGE_FN), ("host_buffers", C.c_int)]
+    _fields_ = [("self", C.c_void_p), ("exchange", EXCHANGE_FN), ("host_buffers", C.c_int),
+                ("abort", C.CFUNCTYPE(None, C.c_void_p))]
 
 
 class Params(C.Structure):
@@ -114,6 +115,8 @@ SIGNATURES = {
     "sph_rccl_transport_destroy": (None, [C.POINTER(Transport)]),
     "sph_rccl_transport_selftest": (C.c_int, [C.POINTER(Transport), C.c_size_t]),
     "sph_slab_in_place_merges": (C.c_uint64, [C.c_void_p]),
+    "sph_slab_exchanges": (C.c_uint64, [C.c_void_p]),
+    "sph_slab_failed": (C.c_int, [C.c_void_p]),
     "sph_slab_create": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int, C.POINTER(Transport), _U32]),
     "sph_slab_destroy": (None, [_P]),
     "sph_slab_step": (C.c_int, [_P, C.c_float, _U32]),

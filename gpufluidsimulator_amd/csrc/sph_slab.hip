@@ -53,7 +53,7 @@ enum {
                       //        (zl-2)*layer, (zl-1)*layer
     HL_DEEP = 4,      // [4..5] the deep interior [first key >= 4*layer, first key >= (zl-4)*layer), ABSOLUTE slots
     HL_FAR = 6,       // [6..7] my leavers (down, up) that are NOT in the neighbour's adjacent layer (crossed > 1 layer)
-    HL_HDR_LO = 8,    // [8..11]  header received from the lower neighbour {#arrivals, #its boundary layer, #far, 0}
+    HL_HDR_LO = 8,    // [8..11]  header received from the lower neighbour {#arrivals, #its boundary layer, #far, abort}
     HL_HDR_HI = 12,   // [12..15] ... from the upper neighbour
     HL_SEQ = 16,      // written last: the step number
     HL_ERR = 17,      // [17..18] sticky error words set by device-side checks (plain stores of 1): SLAB_ERR_*
@@ -176,6 +176,12 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     dl[DL_NEAR] = own_off + s_lb[6]; dl[DL_NEAR + 1] = own_off + max(s_lb[7], s_lb[6]);
 }
 
+// A rank that failed tells its neighbours: the header of its NEXT migrant message says "abort" (word 3), nothing else
+__global__ void k_slab_abort_headers(float4* __restrict__ out_lo, float4* __restrict__ out_hi) {
+    if (threadIdx.x == 0) out_lo[0] = make_float4(0.f, 0.f, 0.f, __uint_as_float(1u));
+    if (threadIdx.x == 1) out_hi[0] = make_float4(0.f, 0.f, 0.f, __uint_as_float(1u));
+}
+
 // comm stream, right behind the migrant exchange: everything the host's one wait needs, in one mapped block, the
 // sequence word last (a system-scope fence in between: the host polls that word and then reads the rest)
 __global__ void k_slab_post_headers(const uint32_t* __restrict__ dl, const float4* __restrict__ hdr_lo,
@@ -187,7 +193,7 @@ __global__ void k_slab_post_headers(const uint32_t* __restrict__ dl, const float
         const float4* h = t < 12u ? hdr_lo : hdr_hi;
         const uint32_t w = (t - 8u) & 3u;
         const uint32_t* hw = reinterpret_cast<const uint32_t*>(h);
-        host[t] = (h && w < 3u) ? hw[w] : 0u;
+        host[t] = h ? hw[w] : 0u;                             // {#arrivals, #its boundary layer, #far, abort}
     }
     __threadfence_system();
     __builtin_amdgcn_wave_barrier();
@@ -354,6 +360,7 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id128 /* by value */, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;       // optional
     int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -375,6 +382,7 @@ int rccl_load() {
     SPH_SYM(GetUniqueId, "ncclGetUniqueId");
     SPH_SYM(CommInitRank, "ncclCommInitRank");
     SPH_SYM(CommDestroy, "ncclCommDestroy");
+    *(void**)(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
     SPH_SYM(Send, "ncclSend");
     SPH_SYM(Recv, "ncclRecv");
     SPH_SYM(GroupStart, "ncclGroupStart");
@@ -388,7 +396,18 @@ int rccl_load() {
 struct RcclLink {
     void* comm = nullptr;
     int rank = 0, world = 1;
+    bool aborted = false;
 };
+
+// A receive whose sender stopped never completes: it sits on the comm stream and blocks every later synchronisation
+// of that stream (sph_slab_destroy, sph_slab_sync).  ncclCommAbort takes the communicator's queued operations down.
+void rccl_abort(void* self) {
+    RcclLink* L = (RcclLink*)self;
+    if (!L || L->aborted || !L->comm) return;
+    L->aborted = true;
+    if (g_rccl.CommAbort) g_rccl.CommAbort(L->comm);
+    L->comm = nullptr;
+}
 
 #define SPH_NCCL(call)                                                                                   \
     do {                                                                                                 \
@@ -400,6 +419,7 @@ struct RcclLink {
 int rccl_exchange(void* self, int, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
                   const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes, void* stream) {
     RcclLink* L = (RcclLink*)self;
+    SPH_REQUIRE(L->comm && !L->aborted, SPH_E_DEVICE, "the RCCL communicator of rank %d was aborted", L->rank);
     hipStream_t s = (hipStream_t)stream;
     const int ncclChar = 0;
     SPH_NCCL(g_rccl.GroupStart());
@@ -537,6 +557,18 @@ struct sph_slab {
     char* stage_recv[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
     uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0, inserts = 0, far_steps = 0, rest_msgs = 0;
+    uint64_t exchanges = 0;              // transport calls so far (3 in a usual step: migrants, halo A, halo B)
+    // failure: the first error of this slab (sticky), its message, and whether the transport may still be used
+    int failed = 0;
+    char fail_msg[512] = {0};
+    bool transport_dead = false;
+    // what the step in flight has exchanged so far and what it still owes its neighbours (slab_fail)
+    struct Progress {
+        bool headers = false, rest = false, halo_a = false, halo_b = false;
+        bool peer_dead[2] = {false, false};          // that neighbour's header said "abort": nothing more to or from it
+        uint32_t rest_s[2] = {0, 0}, rest_r[2] = {0, 0};   // records of the second migrant message (send, receive) per side
+        uint32_t h[2] = {0, 0}, g[2] = {0, 0};       // boundary-layer records I send / ghost records I receive per side
+    } pg;
 };
 
 namespace {
@@ -562,12 +594,14 @@ void slab_free(sph_slab* s) {
 // ones get pinned host copies (the comm stream is drained first: a test transport, not the product path).
 int slab_exchange(sph_slab* s, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
                   const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes) {
-    if (!s->has_lo) send_lo_bytes = recv_lo_bytes = 0;
-    if (!s->has_hi) send_hi_bytes = recv_hi_bytes = 0;
+    if (!s->has_lo || s->pg.peer_dead[0]) send_lo_bytes = recv_lo_bytes = 0;
+    if (!s->has_hi || s->pg.peer_dead[1]) send_hi_bytes = recv_hi_bytes = 0;
+    s->exchanges++;
     if (!s->host_staged) {
         int rc = s->tr.exchange(s->tr.self, tag, send_lo, send_lo_bytes, recv_lo, recv_lo_bytes, send_hi, send_hi_bytes, recv_hi,
                                 recv_hi_bytes, (void*)s->comm);
         if (rc < 0 && sph_last_error()[0] == 0) set_error("slab transport failed (tag %d)", tag);
+        if (rc < 0) s->transport_dead = true;
         return rc;
     }
     SPH_REQUIRE(send_lo_bytes <= s->stage_bytes && send_hi_bytes <= s->stage_bytes && recv_lo_bytes <= s->stage_bytes &&
@@ -577,7 +611,7 @@ int slab_exchange(sph_slab* s, int tag, const void* send_lo, size_t send_lo_byte
     SPH_HIP(hipStreamSynchronize(s->comm));
     int rc = s->tr.exchange(s->tr.self, tag, s->stage_send[0], send_lo_bytes, s->stage_recv[0], recv_lo_bytes, s->stage_send[1],
                             send_hi_bytes, s->stage_recv[1], recv_hi_bytes, nullptr);
-    if (rc < 0) { if (sph_last_error()[0] == 0) set_error("slab transport failed (tag %d)", tag); return rc; }
+    if (rc < 0) { if (sph_last_error()[0] == 0) set_error("slab transport failed (tag %d)", tag); s->transport_dead = true; return rc; }
     if (recv_lo_bytes) SPH_HIP(hipMemcpyAsync(recv_lo, s->stage_recv[0], recv_lo_bytes, hipMemcpyHostToDevice, s->comm));
     if (recv_hi_bytes) SPH_HIP(hipMemcpyAsync(recv_hi, s->stage_recv[1], recv_hi_bytes, hipMemcpyHostToDevice, s->comm));
     return SPH_OK;
@@ -615,6 +649,7 @@ int slab_wait_headers(sph_slab* s) {
             if (dt > s->wait_timeout_s) {
                 set_error("rank %d: no migrant header after %.1f s (step %llu): a neighbour stopped, or the transport is stuck",
                           s->rank, dt, (unsigned long long)s->steps);
+                s->transport_dead = true;
                 return SPH_E_DEVICE;
             }
             hipError_t q = hipStreamQuery(s->comm);            // a device fault shows up here, not in the mapped word
@@ -635,9 +670,10 @@ int slab_check_device_flags(sph_slab* s) {
     return SPH_OK;
 }
 
-int slab_step_once(sph_slab* s, float dt) {
+int slab_step_body(sph_slab* s, float dt) {
     sph_ctx* c = s->c;
     int rc;
+    s->pg = sph_slab::Progress();
     rc = slab_check_device_flags(s); if (rc) return rc;
     // ---- hash + sort the owned particles (leavers end up at the two ends of the owned range) -----------------------
     rc = step_hash(c); if (rc) return rc;
@@ -671,6 +707,7 @@ int slab_step_once(sph_slab* s, float dt) {
     SPH_HIP(hipGetLastError());
     // ---- the one host wait of the step ---------------------------------------------------------------------------
     rc = slab_wait_headers(s); if (rc) return rc;
+    s->pg.headers = true;
     const uint32_t lb0 = s->h_lb[HL_LB], lb1 = s->h_lb[HL_LB + 1], lb2 = s->h_lb[HL_LB + 2], lb3 = s->h_lb[HL_LB + 3];
     const uint32_t deep_lo = s->h_lb[HL_DEEP], deep_hi = s->h_lb[HL_DEEP + 1];
     const uint32_t near_lo = s->h_lb[HL_NEAR], near_hi = s->h_lb[HL_NEAR + 1];     // first slot of layer 3 / of layer zl-3
@@ -680,6 +717,28 @@ int slab_step_once(sph_slab* s, float dt) {
     const uint32_t in_lo = s->has_lo ? s->h_lb[HL_HDR_LO] : 0u, peer_own_lo = s->has_lo ? s->h_lb[HL_HDR_LO + 1] : 0u;
     const uint32_t in_hi = s->has_hi ? s->h_lb[HL_HDR_HI] : 0u, peer_own_hi = s->has_hi ? s->h_lb[HL_HDR_HI + 1] : 0u;
     const uint32_t far_in_lo = s->has_lo ? s->h_lb[HL_HDR_LO + 2] : 0u, far_in_hi = s->has_hi ? s->h_lb[HL_HDR_HI + 2] : 0u;
+    {   // What this step still owes its neighbours -- the second migrant message, halo A, halo B -- in numbers BOTH ends of
+        // a link see (mine in my header, the neighbour's in its header), clamped to the buffers: if this rank fails from
+        // here on it still sends and takes exactly these (slab_fail), so that no neighbour is left waiting for a message.
+        sph_slab::Progress& g = s->pg;
+        auto umin = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
+        g.peer_dead[0] = s->has_lo && s->h_lb[HL_HDR_LO + 3] != 0u;
+        g.peer_dead[1] = s->has_hi && s->h_lb[HL_HDR_HI + 3] != 0u;
+        const uint32_t inl0 = umin(MIG_INLINE, s->mcap);
+        const uint32_t mm[2] = {umin(m_lo, s->mcap), umin(m_hi, s->mcap)}, ii[2] = {umin(in_lo, s->mcap), umin(in_hi, s->mcap)};
+        const uint32_t own[2] = {own_lo, own_hi}, peer[2] = {peer_own_lo, peer_own_hi}, fo[2] = {umin(far_lo, m_lo), umin(far_hi, m_hi)},
+                       fi[2] = {umin(far_in_lo, in_lo), umin(far_in_hi, in_hi)}, mraw[2] = {m_lo, m_hi}, iraw[2] = {in_lo, in_hi};
+        const bool any_rest = m_lo > inl0 || m_hi > inl0 || in_lo > inl0 || in_hi > inl0;
+        for (int k = 0; k < 2; k++) {
+            const bool has = k == 0 ? s->has_lo : s->has_hi;
+            g.rest_s[k] = any_rest && mm[k] > inl0 ? mm[k] - inl0 : 0u;
+            g.rest_r[k] = any_rest && ii[k] > inl0 ? ii[k] - inl0 : 0u;
+            g.h[k] = has ? umin(own[k] + iraw[k] - fi[k], s->gcap) : 0u;
+            g.g[k] = has ? umin(peer[k] + mraw[k] - fo[k], s->gcap) : 0u;
+        }
+        SPH_REQUIRE(!g.peer_dead[0] && !g.peer_dead[1], SPH_E_PEER, "rank %d: its %s neighbour reported a failure and stopped (step %llu)",
+                    s->rank, g.peer_dead[0] ? (g.peer_dead[1] ? "lower and upper" : "lower") : "upper", (unsigned long long)s->steps);
+    }
     SPH_REQUIRE(s->has_lo || m_lo == 0, SPH_E_STATE, "rank %d: %u particles below the lowest slab", s->rank, m_lo);
     SPH_REQUIRE(s->has_hi || m_hi == 0, SPH_E_STATE, "rank %d: %u particles above the highest slab", s->rank, m_hi);
     // both ends of a link see the same numbers (mine in my header, the neighbour's in its header): they fail together
@@ -688,6 +747,10 @@ int slab_step_once(sph_slab* s, float dt) {
                 in_lo, in_hi, s->mcap);
     SPH_REQUIRE(far_in_lo <= in_lo && far_in_hi <= in_hi && far_lo <= m_lo && far_hi <= m_hi, SPH_E_STATE,
                 "rank %d: inconsistent migrant headers", s->rank);
+    // capacity for what arrives, checked BEFORE anything is dropped or merged: on this error the owned range is still the
+    // sorted range of this step
+    SPH_REQUIRE(n0 - m_lo - m_hi + in_lo + in_hi <= c->cap && (uint64_t)off0 + n0 - m_hi + in_lo + in_hi <= c->tot, SPH_E_CAPACITY,
+                "rank %d: %u + %u arriving particles exceed the capacity %u", s->rank, n0 - m_lo - m_hi, in_lo + in_hi, c->cap);
     // ---- more leavers than ride in the fixed-size message: the rest, exact size (both ends know both counts) ----------
     if (m_lo > inl || m_hi > inl || in_lo > inl || in_hi > inl) {
         const size_t s_lo = m_lo > inl ? (size_t)(m_lo - inl) * rec : 0, s_hi = m_hi > inl ? (size_t)(m_hi - inl) * rec : 0;
@@ -697,6 +760,7 @@ int slab_step_once(sph_slab* s, float dt) {
         if (rc) return rc;
         s->rest_msgs++;
     }
+    s->pg.rest = true;
     // A step without arrivals (the usual one) hands the rest of the halo work to the COMM stream at once: the main
     // stream is busy with the deep density, and pack -> HALO A -> ghost unpack need nothing from it (the slices they
     // read have been final since the sort).  The ghosts are then in place when the deep density ends, and everything
@@ -859,6 +923,7 @@ int slab_step_once(sph_slab* s, float dt) {
     rc = slab_exchange(s, SPH_TAG_HALO_A, s->halo_send[0], h_lo * rec, s->halo_recv[0], g_lo * rec, s->halo_send[1], h_hi * rec,
                        s->halo_recv[1], g_hi * rec);
     if (rc) return rc;
+    s->pg.halo_a = true;
     // ghosts go directly in front of / behind the owned range, already in key order; their cells join the table of
     // the owned slots (comm stream, one kernel: none of it is touched by the interior passes)
     if (g_lo + g_hi)
@@ -908,6 +973,7 @@ int slab_step_once(sph_slab* s, float dt) {
     rc = slab_exchange(s, SPH_TAG_HALO_B, s->dens_send[0], h_lo * sizeof(float2), s->dens_recv[0], g_lo * sizeof(float2),
                        s->dens_send[1], h_hi * sizeof(float2), s->dens_recv[1], g_hi * sizeof(float2));
     if (rc) return rc;
+    s->pg.halo_b = true;
     if (g_lo + g_hi)
         hipLaunchKernelGGL(k_slab_unpack_dp2, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->dens_recv[0],
                            c->dp + c->own_off - g_lo, c->cw + c->own_off - g_lo, g_lo, s->dens_recv[1], c->dp + c->own_off + n,
@@ -930,6 +996,51 @@ int slab_step_once(sph_slab* s, float dt) {
     s->steps++;
     if (c->timing) { c->timed_steps++; if (c->events.size() > 3 * 4096) timing_collect(c); }
     return SPH_OK;
+}
+
+// A rank that fails does not simply return: its neighbours have sized this step's messages from the headers and are
+// about to post them, and with RCCL a receive whose sender never sends stays on the comm stream for ever.  So the rank
+// (1) still exchanges what the step owes -- the numbers of Progress, contents irrelevant: the run is over --, (2) puts
+// "abort" into the header of its NEXT migrant message and exchanges that too, (3) is marked failed: every later call
+// returns the first error.  A neighbour reads the abort word at its next wait, returns SPH_E_PEER and does the same
+// towards ITS other neighbour: the failure reaches rank r +- k after k steps, nobody waits for a timeout.  If the
+// transport itself failed (or a wait timed out: the neighbour is gone) nothing more is exchanged and the transport is
+// aborted (RCCL: ncclCommAbort), so that destroy / sync do not block on a receive that will never complete.
+int slab_fail(sph_slab* s, int rc) {
+    if (s->failed) return s->failed;
+    s->failed = rc;
+    snprintf(s->fail_msg, sizeof s->fail_msg, "%s", sph_last_error());
+    sph_slab::Progress& g = s->pg;
+    const size_t rec = 2 * sizeof(float4);
+    const uint32_t inl = min(MIG_INLINE, s->mcap);
+    int e = SPH_OK;
+    if (!s->transport_dead && g.headers && s->world > 1) {
+        if (!g.rest && (g.rest_s[0] | g.rest_s[1] | g.rest_r[0] | g.rest_r[1]))
+            e = slab_exchange(s, SPH_TAG_MIGRANTS_REST, s->mig_send[0] + 2 * (1 + inl), g.rest_s[0] * rec, s->mig_recv[0] + 2 * (1 + inl),
+                              g.rest_r[0] * rec, s->mig_send[1] + 2 * (1 + inl), g.rest_s[1] * rec, s->mig_recv[1] + 2 * (1 + inl),
+                              g.rest_r[1] * rec);
+        if (!e && !g.halo_a)
+            e = slab_exchange(s, SPH_TAG_HALO_A, s->halo_send[0], g.h[0] * rec, s->halo_recv[0], g.g[0] * rec, s->halo_send[1],
+                              g.h[1] * rec, s->halo_recv[1], g.g[1] * rec);
+        if (!e && !g.halo_b)
+            e = slab_exchange(s, SPH_TAG_HALO_B, s->dens_send[0], g.h[0] * sizeof(float2), s->dens_recv[0], g.g[0] * sizeof(float2),
+                              s->dens_send[1], g.h[1] * sizeof(float2), s->dens_recv[1], g.g[1] * sizeof(float2));
+        if (!e) {                                               // the next step's header: "abort"
+            hipLaunchKernelGGL(k_slab_abort_headers, dim3(1), dim3(64), 0, s->comm, s->mig_send[0], s->mig_send[1]);
+            const size_t mig_bytes = (size_t)(1 + inl) * rec;
+            e = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
+                              s->mig_recv[1], mig_bytes);
+        }
+    }
+    if ((s->transport_dead || e) && s->tr.abort) { s->tr.abort(s->tr.self); s->transport_dead = true; }
+    set_error("%s", s->fail_msg);
+    return rc;
+}
+
+int slab_step_once(sph_slab* s, float dt) {
+    if (s->failed) { set_error("%s", s->fail_msg); return s->failed; }
+    const int rc = slab_step_body(s, dt);
+    return rc ? slab_fail(s, rc) : SPH_OK;
 }
 
 }  // namespace
@@ -966,6 +1077,7 @@ int sph_rccl_transport_create(sph_transport** out, const uint8_t id[128], int ra
     t->self = L;
     t->exchange = rccl_exchange;
     t->host_buffers = 0;
+    t->abort = rccl_abort;
     *out = t;
     return SPH_OK;
 }
@@ -973,7 +1085,7 @@ int sph_rccl_transport_create(sph_transport** out, const uint8_t id[128], int ra
 void sph_rccl_transport_destroy(sph_transport* t) {
     if (!t) return;
     RcclLink* L = (RcclLink*)t->self;
-    if (L) { if (L->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(L->comm); delete L; }
+    if (L) { if (L->comm && !L->aborted && g_rccl.CommDestroy) g_rccl.CommDestroy(L->comm); delete L; }
     delete t;
 }
 
@@ -1070,6 +1182,7 @@ int sph_local_transport_create(sph_transport** out, sph_local_hub* hub, int rank
     t->self = E;
     t->exchange = local_exchange;
     t->host_buffers = 0;
+    t->abort = nullptr;               // (its waits are host-side and bounded: nothing stays queued on a stream)
     *out = t;
     return SPH_OK;
 }
@@ -1136,6 +1249,7 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
 void sph_slab_destroy(sph_slab* s) {
     if (!s) return;
     hipSetDevice(s->device);
+    if (s->transport_dead && s->tr.abort) s->tr.abort(s->tr.self);     // (idempotent) nothing of a dead link stays queued
     hipStreamSynchronize(s->comm);
     hipStreamSynchronize(s->c->stream);
     s->c->host_paced = false;
@@ -1174,6 +1288,12 @@ int sph_slab_counters(const sph_slab* s, uint64_t out[8]) {
     out[0] = s->steps; out[1] = s->migrants; out[2] = s->resorts; out[3] = s->ghosts; out[4] = s->host_waits;
     out[5] = s->inserts; out[6] = s->far_steps; out[7] = s->rest_msgs;
     return SPH_OK;
+}
+
+uint64_t sph_slab_exchanges(const sph_slab* s) { return s ? s->exchanges : 0; }
+
+int sph_slab_failed(const sph_slab* s) {
+    return s ? s->failed : SPH_E_INVALID;
 }
 
 int sph_slab_stats(const sph_slab* s, uint64_t out[5]) {

@@ -262,7 +262,7 @@ class HipEngine:
 # ------------------------------------------------------------------------------------------------
 class SlabSimulation:
     def __init__(self, comm, engine_factory, box, grid, lattice=None, jitter=True, jitter_dims=None,
-                 capacity_factor=1.5, ghost_factor=3.0, particles=None):
+                 capacity_factor=1.5, ghost_factor=3.0, particles=None, capacity_slack=4096):
         """comm: TorchDistComm | LocalComm.  engine_factory(capacity, ghost_capacity, params, z_lo, z_hi)
         builds this rank's engine.  Either `lattice` (dam break generated slab by slab) or
         `particles` = (pos, vel) of the WHOLE system (small tests)."""
@@ -324,7 +324,7 @@ class SlabSimulation:
         n_own = int(pos.shape[0])
         per_layer = max(int(hist.max()), 1)
         self.ghost_capacity = int(ghost_factor * per_layer) + 1024
-        self.capacity = int(capacity_factor * max(n_own, self.total // self.world)) + 4096
+        self.capacity = int(capacity_factor * max(n_own, self.total // self.world)) + int(capacity_slack)
         self._factory = engine_factory
         self.engine = engine_factory(self.capacity, self.ghost_capacity, self.params, z_lo, z_hi)
         self.engine.upload(pos, vel, index)
@@ -617,6 +617,7 @@ class NativeSlabSimulation(SlabSimulation):
         base = getattr(self, "_stats_base", {})
         names = ("steps", "migrants", "resorts", "ghosts", "host_waits", "in_place_merges", "far_steps", "rest_messages")
         self.stats.update({k: base.get(k, 0) + int(out[i]) for i, k in enumerate(names)})
+        self.stats["exchanges"] = base.get("exchanges", 0) + int(capi.load().sph_slab_exchanges(self._slab))
 
     def sync(self):
         capi._check(capi.load().sph_slab_sync(self._slab))
@@ -629,7 +630,7 @@ class NativeSlabSimulation(SlabSimulation):
             return False                                   # balanced: the slab object and its buffers stay as they are
         self._pull_stats()
         self._stats_base = {k: self.stats.get(k, 0) for k in ("migrants", "resorts", "ghosts", "host_waits", "steps",
-                                                              "in_place_merges", "far_steps", "rest_messages")}
+                                                              "in_place_merges", "far_steps", "rest_messages", "exchanges")}
         self._unbind()                 # the engine (context) is replaced when the cuts move
         moved = super().rebalance(tolerance, cuts=cuts)
         self._bind()
@@ -741,9 +742,10 @@ def bench_rank(comm, local, args, transport, log=None):
                                    f"{cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} = {total} particles "
                                    f"({total // world} per GPU), grid {list(cfg['grid'])}, dt 5e-7, "
                                    f"{'FLOWING' if flow_ok else 'NOT a flowing state'}: timed after {runup} run-up steps; z-slabs, "
-                                   f"ghost layers and migrants over "
-                                   + {"rccl": "RCCL send/recv (library comm stream)", "host": "host-staged messages",
-                                      "local": "device-to-device copies between the streams of one process"}[transport],
+                                   + ("ONE slab, NO neighbours: nothing is exchanged (no halo pack / unpack, no boundary launches)"
+                                      if world == 1 else "ghost layers and migrants over "
+                                      + {"rccl": "RCCL send/recv (library comm stream)", "host": "host-staged messages",
+                                         "local": "device-to-device copies between the streams of one process"}[transport]),
                        "particles": total, "grid": list(cfg["grid"]), "cuts": sim.cuts, "layers_per_slab": layers,
                        "state": "flow" if flow_ok else "not-flowing", "runup_steps": runup,
                        "runup_last_1000_steps": {"steps": tail, "movers_per_step": movers_tail, "rebalances": rebalances,
@@ -782,7 +784,9 @@ def bench_main(args):
         args.ranks_as = "threads of one process"
         torch.cuda.set_device(0)
         hub = LocalComm.Hub(args.gpus)
-        hub_tr = capi.LocalHub(args.gpus) if transport == "local" else None
+        # a rehearsal: a rank that fails must not leave the others in 120 s waits (the library's defaults)
+        os.environ.setdefault("SPH_SLAB_TIMEOUT_S", "20")
+        hub_tr = capi.LocalHub(args.gpus, timeout_s=20) if transport == "local" else None
         res, errors = [None] * args.gpus, []
 
         def rank_main(r):
@@ -797,11 +801,16 @@ def bench_main(args):
                 hub.bar.abort()
 
         threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(args.gpus)]
-        for t in threads: t.start()
-        for t in threads: t.join()
+        try:
+            for t in threads: t.start()
+            for t in threads: t.join()
+        finally:
+            if hub_tr is not None:
+                hub_tr.close()
         if errors:
             sys.exit(f"bench: a rank failed: {errors[0]!r}")
-        out, bad = res[0]
+        out = res[0][0]
+        bad = any(r is not None and r[1] for r in res)          # any rank may have seen a non-flowing window
         print(json.dumps(out), flush=True)
         if bad:
             sys.exit("bench: the timed window was not a flowing state (sort skipped or too few particles changed cell)")

@@ -39,7 +39,8 @@ enum {
     SPH_E_DEVICE = -2,    /* HIP runtime error, no device, wrong architecture */
     SPH_E_NOMEM = -3,     /* device or host allocation failed */
     SPH_E_CAPACITY = -4,  /* more particles / ghosts than the context was created for */
-    SPH_E_STATE = -5      /* phase called out of order */
+    SPH_E_STATE = -5,     /* phase called out of order */
+    SPH_E_PEER = -6       /* slab step: a neighbouring rank reported a failure and stopped (its own error says why) */
 };
 
 typedef struct sph_ctx sph_ctx;
@@ -275,6 +276,9 @@ typedef struct sph_transport {
     int (*exchange)(void* self, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
                     const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes, void* hip_stream);
     int host_buffers;
+    /* optional (may be NULL): take down everything the transport still has queued on a stream -- called when an exchange
+     * failed or a neighbour stopped answering, so that no receive without a sender blocks a later synchronisation */
+    void (*abort)(void* self);
 } sph_transport;
 
 /* RCCL transport over the direct xGMI links (librccl is loaded on first use): rank 0 makes the id, every rank gets
@@ -323,6 +327,13 @@ int sph_slab_counters(const sph_slab* s, uint64_t out[8]);
 /* of the steps with arrivals, those that merged them into the two boundary layers in place (the rest ran a pass over
  * all particles: more than 2048 arrivals on a side, or no valid cell table) */
 uint64_t sph_slab_in_place_merges(const sph_slab* s);
+/* transport calls so far: 3 in a usual step (migrants, halo A, halo B), 4 when a side has more leavers than ride in the
+ * fixed-size migrant message */
+uint64_t sph_slab_exchanges(const sph_slab* s);
+/* 0, or the first error of this slab: a slab that failed stays failed -- it has told its neighbours (they return
+ * SPH_E_PEER at their next step), every later sph_slab_step returns the same error, and the state of its context is that
+ * of a half-done step: download / destroy only */
+int sph_slab_failed(const sph_slab* s);
 
 #ifdef __cplusplus
 }

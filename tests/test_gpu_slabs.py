@@ -84,6 +84,8 @@ def test_slabs_with_migration_match_whole_domain(case, world, transport):
     assert sum(r[1]["migrants"] for r in res) > 0
     assert sum(r[3] for r in res) == pos.shape[0]
     assert all(r[1]["host_waits"] == steps for r in res), "one host wait per step and rank"
+    # three transport calls per step (migrants, halo A, halo B), a fourth only when a side has > 255 leavers
+    assert all(r[1]["exchanges"] == 3 * steps + r[1]["rest_messages"] for r in res), [r[1] for r in res]
     arrivals, in_place = sum(r[1]["resorts"] for r in res), sum(r[1]["in_place_merges"] for r in res)
     assert arrivals > 0 and in_place == arrivals, "arrivals join their boundary layer in place (k_slab_insert)"
     _same_bits(st, ref)
@@ -476,3 +478,46 @@ def test_movers_sort_forms_in_a_slab(case):
     if case == "burst":
         assert q1["movers_total"] - q0["movers_total"] >= 100000, (q0, q1)      # the burst is what the docstring says
     _same_bits(res[0][0], ref)
+
+
+def test_a_failure_on_one_rank_reaches_every_rank_within_steps_not_timeouts():
+    """The top rank of three has room for exactly the particles it starts with; the fluid moves up, so the first lattice
+    layer that arrives overflows it: SPH_E_CAPACITY there -- and only there, its neighbours cannot know.  The failing rank
+    still exchanges what the step owes (so nobody is left waiting for a halo), then sends "abort" in its next migrant
+    header: the middle rank returns SPH_E_PEER one step later, the bottom rank the step after that.  All timeouts are 60 s;
+    the three ranks are done in a fraction of that, and every slab closes (nothing stays queued on a stream)."""
+    import time
+    pos, vel, box, grid = make_case("up")
+    world = 3
+    hub = slab.LocalComm.Hub(world)
+    dev_hub = capi.LocalHub(world, timeout_s=60)
+    errors, steps_done, t_end = [None] * world, [0] * world, [0.0] * world
+    t0 = time.perf_counter()
+
+    def rank_main(r):
+        sim = None
+        try:
+            sim = slab.NativeSlabSimulation(_comm(hub, dev_hub, r), box, grid, device_index=0, transport="local", particles=(pos, vel),
+                                            capacity_factor=1.0 if r == world - 1 else 1.5, capacity_slack=0 if r == world - 1 else 4096)
+            for k in range(60):
+                sim.run(DT, 1)
+                steps_done[r] = k + 1
+        except BaseException as e:     # noqa: BLE001
+            errors[r] = e
+        finally:
+            t_end[r] = time.perf_counter() - t0
+            if sim is not None:
+                failed = capi.load().sph_slab_failed(sim._slab)
+                errors[r] = (errors[r], failed)
+                sim.close()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=300)
+    dev_hub.close()
+    assert all(isinstance(e, tuple) and isinstance(e[0], capi.SphError) for e in errors), errors
+    assert errors[2][1] == -4 and "exceed the capacity" in str(errors[2][0]), errors           # SPH_E_CAPACITY, the cause
+    assert errors[1][1] == -6 and "upper neighbour reported a failure" in str(errors[1][0]), errors
+    assert errors[0][1] == -6 and "upper neighbour reported a failure" in str(errors[0][0]), errors
+    assert steps_done[1] == steps_done[2] + 1 and steps_done[0] == steps_done[2] + 2, steps_done
+    assert max(t_end) < 30.0, t_end                                                          # nobody sat out a 60 s timeout
