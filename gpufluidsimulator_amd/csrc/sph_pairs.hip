@@ -378,7 +378,11 @@ __device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, ui
     uint32_t lo = T.lo;
     hi = T.hi;
     if (T.dev) { lo = T.dev[0]; hi = T.dev[1]; }          // wave-uniform (scalar loads)
-    first = lo + (xcd_block(blockIdx.x, gridDim.x) * PAIR_WAVES + wave) * WAVE;
+#ifndef SPH_PAIR_REVERSE
+#define SPH_PAIR_REVERSE 0           // 1: the LAST slots are dispatched first (experiment, DESIGN 5: where the direct-walk waves sit)
+#endif
+    const uint32_t blk = SPH_PAIR_REVERSE ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    first = lo + (xcd_block(blk, gridDim.x) * PAIR_WAVES + wave) * WAVE;
     if (first >= T.gap_lo) first += T.gap_len;
     i = first + lane;
     return first < hi;

@@ -4,7 +4,7 @@
 
 Writes profiles/pmc_traffic.json (HBM-side traffic per launch: FETCH_SIZE x 2 per the gfx950 correction of
 MI355X_MICROARCH.md section HBM -- FETCH_SIZE tallies 128-byte requests at 64 bytes for wide coalesced reads -- plus
-WRITE_SIZE, both reported in KB) and profiles/r03_c3_flow_sq_counters.json.
+WRITE_SIZE, both reported in KB) and profiles/<tag>_c3_flow_sq_counters.json.
 
     python profiles/pmc_summarize.py <dir with fetch/ write/ sq1/ sq2/> <runup> <warmup> <steps>
 """
@@ -12,6 +12,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 root, runup, warm, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+tag = sys.argv[5] if len(sys.argv) > 5 else "r04"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -50,7 +51,7 @@ N = 16777216
 force = next((v for k, v in res.items() if k.startswith("k_force<")), {})
 dens = res.get("k_density", {})
 traffic = {
-    "workload": "C3", "state": "flow", "round": 3, "collected": __import__("time").strftime("%Y-%m-%d"),
+    "workload": "C3", "state": "flow", "round": int(tag.lstrip("r") or 0), "collected": __import__("time").strftime("%Y-%m-%d"),
     "method": f"profiles/collect_pmc.sh: rocprofv3 --pmc, one pass per counter group, over `python bench.py --runup {runup} "
               f"--steps {steps} --warmup {warm} --no-cpu`; means over the dispatches of the timed window; FETCH_SIZE and WRITE_SIZE in "
               "KB; reads = FETCH_SIZE x 2 (gfx950: wide coalesced reads are tallied at half their bytes, MI355X_MICROARCH.md HBM); "
@@ -70,6 +71,6 @@ for k, v in sq.items():                         # per-wave instruction counts (w
         for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
             if c in v:
                 v[c + "_per_wave"] = v[c] / v["SQ_WAVES"]
-json.dump(sq, open(os.path.join(HERE, "r03_c3_flow_sq_counters.json"), "w"), indent=1)
+json.dump(sq, open(os.path.join(HERE, tag + "_c3_flow_sq_counters.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1)[:3000])
 print(json.dumps({k: sq[k] for k in sq if k.startswith("k_force<") or k == "k_density"}, indent=1))
