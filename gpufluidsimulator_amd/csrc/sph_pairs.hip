@@ -694,13 +694,15 @@ __device__ __forceinline__ void integrate_one(const Phys& ph, float dt, float4& 
 // The reference runs three separate traversals plus an integrate pass; FORCE, COLL and INTEG select
 // what this instantiation does so that the phase API can still run them one at a time.
 #ifdef SPH_PAIR_STATS
-__device__ unsigned long long g_pair_stats[8];   // debug build only (-DSPH_PAIR_STATS): waves, pieces, walk length, chunks, collision rounds
+__device__ unsigned long long g_pair_stats[12];  // debug build only (-DSPH_PAIR_STATS): waves, pieces, walk length, chunks, collision rounds,
+                                                 // waves with a hull > 256 / 512 / 2048 slots, [8] sum over waves of the busiest LANE's collision
+                                                 // candidates (what a per-particle queue would have to work off), [9] sum over all lanes of them
 __device__ int g_pair_stats_on;
 #define PAIR_STAT(k, v) do { if (lane == 0 && g_pair_stats_on) atomicAdd(&g_pair_stats[k], (unsigned long long)(v)); } while (0)
 extern "C" void sph_debug_pair_stats(unsigned long long* out, int on) {     // read + clear the counters, then count or not
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stats), sizeof(g_pair_stats));
-    unsigned long long z[8] = {};
+    unsigned long long z[12] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stats), z, sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stats_on), &on, sizeof(on));
 }
@@ -764,6 +766,9 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     float fpx = 0.f, fpy = 0.f, fpz = 0.f, fvx = 0.f, fvy = 0.f, fvz = 0.f, sw = 0.f;
     float cvx = 0.f, cvy = 0.f, cvz = 0.f;
     uint32_t ccount = 0;
+#ifdef SPH_PAIR_STATS
+    uint32_t stat_near = 0;
+#endif
     // One candidate (position q, velocity u, cp_j, w_j): the pressure / viscosity sums; returns r2 - (collision range + 8
     // ulps), whose sign is the candidate's bit of the collision SUPERSET.  Shared by the staged walk and the direct walk
     // (traverse), so a row gives the same bits either way.
@@ -822,6 +827,15 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
         ccount += hit ? 1u : 0u;
     };
     auto finish = [&]() {
+#ifdef SPH_PAIR_STATS
+        if (COLL) {
+            const uint32_t busiest = wave_max_u32(stat_near);          // (all lanes: the macro's body runs in lane 0 only)
+            PAIR_STAT(8, busiest);
+            uint32_t sum = stat_near;
+            for (int off = 32; off; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off);
+            PAIR_STAT(9, sum);
+        }
+#endif
         if (FORCE && SPH_VISC_SPLIT) { fvx = fmaf(-vi.x, sw, fvx); fvy = fmaf(-vi.y, sw, fvy); fvz = fmaf(-vi.z, sw, fvz); }
         bool moved = false;
         if (active) {
@@ -938,6 +952,9 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                     idx += SPH_FORCE_UNROLL;
                     done += SPH_FORCE_UNROLL;
                 }
+#ifdef SPH_PAIR_STATS
+                if (COLL) stat_near += (uint32_t)__popc(near);
+#endif
                 if (COLL) {
                     // bit (done-1-k) of `near` belongs to the k-th candidate of this chunk; highest bit first
                     // keeps the candidate order of the sums

@@ -37,7 +37,7 @@ def analyse(label, pos, vel):
         ms_d = (time.perf_counter() - t0) / 50 * 1e3
         stats = None
         if hasattr(lib, "sph_debug_pair_stats"):
-            out = (ctypes.c_ulonglong * 8)()
+            out = (ctypes.c_ulonglong * 12)()
             lib.sph_debug_pair_stats(out, 1)
             c.force(); c.sync()
             lib.sph_debug_pair_stats(out, 0)
