@@ -407,6 +407,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
     constexpr int DENS_ENT = SPH_DENS_SKEW ? LDS_ENT + LDS_ENT / 32 + 2 : LDS_ENT;
     __shared__ float2 s_xy[DENS_ENT];
     __shared__ float s_z[DENS_ENT];
+    // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
+    if (tg.dev && tg.dev[0] + blockIdx.x * (uint32_t)PAIR_THREADS >= tg.dev[1]) return;
     for (uint32_t k = threadIdx.x; k < DENS_ENT; k += PAIR_THREADS) {   // see LDS_ENT: keep over-reads finite
         s_xy[k] = make_float2(0.f, 0.f);
         s_z[k] = 0.f;

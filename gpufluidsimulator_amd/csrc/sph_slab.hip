@@ -170,8 +170,13 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     out_hi[0] = make_float4(__uint_as_float(m_hi), __uint_as_float(lb3 - s_lb[2]), __uint_as_float(far_hi), 0.f);
     out_hi[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = 0; t < 4; t++) dl[t] = s_lb[t];
-    dl[DL_DEEP] = own_off + s_lb[4];
-    dl[DL_DEEP + 1] = own_off + max(s_lb[5], s_lb[4]);
+    // the deep range starts on a 64-slot chunk of what will be the owned range once the lower leavers are gone (the usual
+    // step: no arrivals): the launch over "everything that is not deep" cuts its hole on whole waves from there
+    // (targets_with_hole rounds the hole's start UP), so the two launches -- on two streams -- cover disjoint slots
+    // instead of both writing the up to 63 slots in front of the first whole chunk (the same values: benign, but unordered)
+    const uint32_t deep0 = lb0 + ((s_lb[4] - lb0 + 63u) & ~63u);
+    dl[DL_DEEP] = own_off + deep0;
+    dl[DL_DEEP + 1] = own_off + max(s_lb[5], deep0);
     dl[DL_FAR] = far_lo; dl[DL_FAR + 1] = far_hi;
     dl[DL_NEAR] = own_off + s_lb[6]; dl[DL_NEAR + 1] = own_off + max(s_lb[7], s_lb[6]);
 }
