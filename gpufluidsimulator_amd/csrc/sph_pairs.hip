@@ -373,16 +373,34 @@ struct Targets {
     uint32_t direct_hull;       // rows whose hull is longer are read straight from global memory (see traverse)
 };
 
+// Which 256 slots a block takes.  The waves that take the direct walk (sparse particles next to a dense layer, see
+// traverse) run 2-3x as long as the others and sit where the fluid's free z faces are: at the END of the slot range
+// (the last blocks, which start last and then ARE the kernel's tail) or at its beginning.  So the last 1/64 of the
+// blocks are dispatched first, then the others in order: on the thin slab whose outer layer is sparse `k_force` 0.302
+// -> 0.276 ms and `k_density` 0.135 -> 0.130 (the times of the state without sparse layers), C3 unchanged
+// (profiles/r04_rotate_dispatch_experiment.txt).  Dispatching everything backwards does the same for the tail but costs
+// C3 3.5 % of wall clock (-DSPH_PAIR_REVERSE=1, profiles/r04_reverse_dispatch_experiment.txt).
+#ifndef SPH_PAIR_REVERSE
+#define SPH_PAIR_REVERSE 0
+#endif
+#ifndef SPH_PAIR_ROTATE
+#define SPH_PAIR_ROTATE 1
+#endif
+__device__ __forceinline__ uint32_t pair_block() {
+    if (SPH_PAIR_REVERSE) return gridDim.x - 1u - blockIdx.x;
+    if (SPH_PAIR_ROTATE) {
+        const uint32_t rot = max(gridDim.x >> 6, 1u);
+        return blockIdx.x < rot ? gridDim.x - rot + blockIdx.x : blockIdx.x - rot;
+    }
+    return blockIdx.x;
+}
+
 __device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, uint32_t lane, uint32_t& i, uint32_t& hi,
                                              uint32_t& first) {
     uint32_t lo = T.lo;
     hi = T.hi;
     if (T.dev) { lo = T.dev[0]; hi = T.dev[1]; }          // wave-uniform (scalar loads)
-#ifndef SPH_PAIR_REVERSE
-#define SPH_PAIR_REVERSE 0           // 1: the LAST slots are dispatched first (experiment, DESIGN 5: where the direct-walk waves sit)
-#endif
-    const uint32_t blk = SPH_PAIR_REVERSE ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-    first = lo + (xcd_block(blk, gridDim.x) * PAIR_WAVES + wave) * WAVE;
+    first = lo + (xcd_block(pair_block(), gridDim.x) * PAIR_WAVES + wave) * WAVE;
     if (first >= T.gap_lo) first += T.gap_len;
     i = first + lane;
     return first < hi;
@@ -408,7 +426,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
     __shared__ float2 s_xy[DENS_ENT];
     __shared__ float s_z[DENS_ENT];
     // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
-    if (tg.dev && tg.dev[0] + blockIdx.x * (uint32_t)PAIR_THREADS >= tg.dev[1]) return;
+    if (tg.dev && tg.dev[0] + pair_block() * (uint32_t)PAIR_THREADS >= tg.dev[1]) return;
     for (uint32_t k = threadIdx.x; k < DENS_ENT; k += PAIR_THREADS) {   // see LDS_ENT: keep over-reads finite
         s_xy[k] = make_float2(0.f, 0.f);
         s_z[k] = 0.f;
