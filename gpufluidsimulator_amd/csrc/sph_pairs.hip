@@ -23,6 +23,15 @@ namespace sph {
 #endif
 constexpr int PAIR_THREADS = SPH_PAIR_THREADS;   // 4 independent waves
 constexpr int PAIR_WAVES = PAIR_THREADS / WAVE;
+// block of the fp32 density pass (A/B knob).  Round 4 tried 128 for it alone: +1.0 % SQ cycles, wall clock in the noise
+// (profiles/r04_block_size_and_xcd_pmc_ab.txt: with 128 threads for BOTH kernels the density pass reads -2.2 % and k_force
+// +5.4 %, with 512 both are worse; an XCD-contiguous block order gives k_force -1.2 % and the density pass +1.7 %: all
+// within what the clock ratio of a power-capped chip moves these counters)
+#ifndef SPH_DENS_THREADS
+#define SPH_DENS_THREADS SPH_PAIR_THREADS
+#endif
+constexpr int DENS_THREADS = SPH_DENS_THREADS;
+constexpr int DENS_WAVES = DENS_THREADS / WAVE;
 constexpr int PIECE = 128;          // staged candidates per piece (2 coalesced loads per lane)
 
 // The candidate walks read LDS through volatile LDS-address-space pointers: each read then stays ONE
@@ -400,7 +409,7 @@ __device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, ui
     uint32_t lo = T.lo;
     hi = T.hi;
     if (T.dev) { lo = T.dev[0]; hi = T.dev[1]; }          // wave-uniform (scalar loads)
-    first = lo + (xcd_block(pair_block(), gridDim.x) * PAIR_WAVES + wave) * WAVE;
+    first = lo + (xcd_block(pair_block(), gridDim.x) * (blockDim.x >> 6) + wave) * WAVE;
     if (first >= T.gap_lo) first += T.gap_len;
     i = first + lane;
     return first < hi;
@@ -409,7 +418,7 @@ __device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, ui
 // ---- density + pressure (kernelComputeDensities, particleSystem.cu:132-187) ---------------------------
 // rho_i = sum_{j in 27 cells, r2 < h2} m * POLY6 * (h2 - r2)^3   (self included)   (.cu:28-37)
 // p_i   = max(0, k * (rho_i - rho0))                                              (.cu:15-17)
-__global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const float4* __restrict__ posi,
+__global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const float4* __restrict__ posi,
                                                                         const uint32_t* __restrict__ keyS,
                                                                         const uint2* __restrict__ cells,
                                                                         float2* __restrict__ dp, float2* __restrict__ cw,
@@ -422,12 +431,13 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density(const fl
 #else
 #define DSK(j) (j)
 #endif
-    constexpr int DENS_ENT = SPH_DENS_SKEW ? LDS_ENT + LDS_ENT / 32 + 2 : LDS_ENT;
+    constexpr int DENS_LDS = (DENS_WAVES + 1) * PIECE + 8;          // as LDS_ENT, for this kernel's block
+    constexpr int DENS_ENT = SPH_DENS_SKEW ? DENS_LDS + DENS_LDS / 32 + 2 : DENS_LDS;
     __shared__ float2 s_xy[DENS_ENT];
     __shared__ float s_z[DENS_ENT];
     // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
-    if (tg.dev && tg.dev[0] + pair_block() * (uint32_t)PAIR_THREADS >= tg.dev[1]) return;
-    for (uint32_t k = threadIdx.x; k < DENS_ENT; k += PAIR_THREADS) {   // see LDS_ENT: keep over-reads finite
+    if (tg.dev && tg.dev[0] + pair_block() * (uint32_t)DENS_THREADS >= tg.dev[1]) return;
+    for (uint32_t k = threadIdx.x; k < DENS_ENT; k += DENS_THREADS) {   // see LDS_ENT: keep over-reads finite
         s_xy[k] = make_float2(0.f, 0.f);
         s_z[k] = 0.f;
     }
@@ -1077,7 +1087,7 @@ static int launch_density_targets(sph_ctx* c, const Targets& tg, uint32_t thread
         hipLaunchKernelGGL(k_density_h, dim3(ceil_div(threads, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
                            c->keyS, c->cells, c->dp, c->cw, tg, c->grid, c->phys);
     else
-        hipLaunchKernelGGL(k_density, dim3(ceil_div(threads, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
+        hipLaunchKernelGGL(k_density, dim3(ceil_div(threads, DENS_THREADS)), dim3(DENS_THREADS), 0, c->stream, c->posi,
                            c->keyS, c->cells, c->dp, c->cw, tg, c->grid, c->phys);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
