@@ -521,3 +521,23 @@ def test_a_failure_on_one_rank_reaches_every_rank_within_steps_not_timeouts():
     assert errors[0][1] == -6 and "upper neighbour reported a failure" in str(errors[0][0]), errors
     assert steps_done[1] == steps_done[2] + 1 and steps_done[0] == steps_done[2] + 2, steps_done
     assert max(t_end) < 30.0, t_end                                                          # nobody sat out a 60 s timeout
+
+
+def test_long_flowing_run_in_four_slabs_bit_for_bit():
+    """BASELINE config 2's dam (262,144 particles) for 3,100 steps -- from rest through the first lattice planes crossing cell
+    faces into a flow with bursts of movers, leavers and arrivals at every cut, re-balancing checks every 500 steps -- in
+    four slabs against one context: the same bits after thousands of steps, not just after the few dozen of the fuzz."""
+    cfg = ic.CONFIGS["C2"]
+    steps = 3100
+    res = _run_slabs(4, cfg["box"], cfg["grid"], steps, lattice=cfg["lattice"], rebalance_every=500)
+    st = res[0][0]
+    stats = [r[1] for r in res]
+    assert sum(s["migrants"] for s in stats) > 0 and all(s["host_waits"] == s["steps"] + s["far_steps"] for s in stats), stats
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=True)
+    with capi.Context(pos.shape[0], box=cfg["box"], grid=cfg["grid"]) as c:
+        c.upload(pos, vel)
+        c.step(DT, steps)
+        ref = c.download()
+        movers = c.sort_stats()["movers_total"]
+    assert movers > 100 * pos.shape[0] // 100, movers            # a flowing state: every particle changed cell on average
+    _same_bits(st, ref)
