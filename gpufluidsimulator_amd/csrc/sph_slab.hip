@@ -28,6 +28,11 @@
 //   step through the pass over all particles instead) ; pack boundary layers -> HALO A ; density interior-minus-deep
 //   while it travels ; (event) density boundary ; pack (rho, p) -> HALO B ; force interior ; force boundary on comm
 //
+// Equal keys at a cut keep the order of the whole-domain stable sort (what came up from below in front of the residents
+// of its cell, what came down from above behind them): an N-slab run has the bits of the one-context run.
+// A rank that fails still exchanges what the step owes, then sends "abort" in its next migrant header (slab_fail): its
+// neighbours return SPH_E_PEER one step later instead of waiting for a timeout; a dead transport is aborted.
+//
 // The interior layers (all but the first and last owned layer) never look at a ghost, so their passes run while
 // the halos travel.  Messages go point to point to the two z-neighbours only: RCCL ncclSend/ncclRecv in one group
 // on the comm stream (sph_rccl_transport_create; over the direct xGMI link), or through a caller-supplied
