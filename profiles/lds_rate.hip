@@ -196,9 +196,17 @@ static std::vector<int> cells(const std::vector<int>& lanes_per_cell, const std:
     return e;
 }
 
-int main() {
+int main(int argc, char** argv) {
     const std::vector<int> eight(8, 8);
     const auto rest = cells(eight, eight);                                         // 8 lanes per cell, cells 8 entries apart
+    if (argc > 1 && std::string(argv[1]) == "two") {
+        // round 4: what would two targets per lane buy k_force?  The candidate's four reads feed 48 VALU instead of 24.
+        runmix<4, 24>("4 ds_read_b64 + 24 VALU (one target)", rest);
+        runmix<4, 48>("4 ds_read_b64 + 48 VALU (two targets: per PAIR)", rest);
+        runmix<0, 24>("24 VALU, no LDS", rest);
+        runmix<0, 48>("48 VALU, no LDS", rest);
+        return 0;
+    }
     runmix<0, 24>("24 VALU, no LDS", rest);
     runmix<4, 0>("4 ds_read_b64, no VALU", rest);
     runmix<4, 24>("4 ds_read_b64 + 24 VALU (force-like)", rest);
