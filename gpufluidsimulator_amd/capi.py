@@ -96,6 +96,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_uint64)]),
     "sph_set_sort_mode": (C.c_int, [_P, C.c_int]),
     "sph_set_direct_hull": (C.c_int, [_P, C.c_uint32]),
+    "sph_set_block_order": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint32]),
     "sph_sort_forms": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "sph_set_precision": (C.c_int, [_P, C.c_int]),
     "sph_get_precision": (C.c_int, [_P]),
@@ -404,6 +405,10 @@ class Context:
         out = (C.c_uint64 * 3)()
         _check(self.L.sph_sort_forms(self.h, out))
         return tuple(int(v) for v in out)
+
+    def set_block_order(self, xcd=True, ztile=True, strip_blocks_log2=4):
+        """Order in which the pair kernels' workgroups take the slots (performance only; see sph_set_block_order)."""
+        _check(self.L.sph_set_block_order(self.h, int(bool(xcd)), int(bool(ztile)), int(strip_blocks_log2)))
 
     def set_direct_hull(self, slots=512):
         """Rows of the neighbour passes whose staged hull would exceed `slots` are read straight from global memory

@@ -196,6 +196,10 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
         set_error("hipHostMalloc failed");
         rc = SPH_E_NOMEM;
     }
+    if (const char* env = getenv("SPH_BLOCK_ORDER")) {          // "xcd,ztile,strip_log2" at create time: A/B runs (sph_set_block_order)
+        int x = 1, z = 1, sh = 4;
+        if (sscanf(env, "%d,%d,%d", &x, &z, &sh) >= 1) { c->order_xcd = x != 0; c->order_ztile = z != 0; if (sh >= 1 && sh <= 10) c->order_strip_sh = (uint32_t)sh; }
+    }
     {   // merge sort scratch
         const char* env = getenv("SPH_SORT_MERGE");
         c->sort_merge = !(env && env[0] == '0');
@@ -213,7 +217,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
             set_error("hipEventCreate failed");
             rc = SPH_E_DEVICE;
         }
-        if (!rc && (hipHostMalloc((void**)&c->mm_count_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        if (!rc && (hipHostMalloc((void**)&c->mm_count_host, 4 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
                     hipHostGetDevicePointer((void**)&c->mm_count_host_dev, c->mm_count_host, 0) != hipSuccess)) {
             set_error("hipHostMalloc(mapped) failed");
             rc = SPH_E_NOMEM;
@@ -224,7 +228,9 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
                 rc = SPH_E_DEVICE;
             }
         if (!rc) {
-            *c->mm_count_host = 0;
+            c->mm_count_host[0] = 0;
+            c->mm_count_host[1] = 1; c->mm_count_host[2] = 0;          // "no estimate yet" (first key > last key)
+            c->mm_count_host[3] = 0;
             if (hipMemset(c->mm_tile_cnt, 0, ntiles * sizeof(uint32_t)) != hipSuccess ||
                 hipMemset(c->mm_count, 0, sizeof(uint32_t)) != hipSuccess ||
                 hipMemset(c->mm_total, 0, sizeof(unsigned long long)) != hipSuccess) {
@@ -961,6 +967,15 @@ int sph_set_sort_mode(sph_ctx* c, int merge) {
 int sph_sort_forms(const sph_ctx* c, uint64_t out[3]) {
     SPH_REQUIRE(c && out, SPH_E_INVALID, "null argument");
     for (int k = 0; k < 3; k++) out[k] = c->sort_forms[k];
+    return SPH_OK;
+}
+
+int sph_set_block_order(sph_ctx* c, int xcd, int ztile, uint32_t strip_blocks_log2) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    SPH_REQUIRE(strip_blocks_log2 >= 1u && strip_blocks_log2 <= 10u, SPH_E_INVALID, "strip of 2^%u blocks", strip_blocks_log2);
+    c->order_xcd = xcd != 0;
+    c->order_ztile = ztile != 0;
+    c->order_strip_sh = strip_blocks_log2;
     return SPH_OK;
 }
 

@@ -90,6 +90,10 @@ struct sph_ctx {
     // pair kernels: a (dz, dy) row whose staged hull would exceed this many slots is read straight from global memory
     // by every lane instead (sph_pairs.hip: traverse; sph_set_direct_hull)
     uint32_t direct_hull = 512;
+    // block order of the pair kernels (sph_device.hpp: BlockOrder; sph_set_block_order): every XCD walks a contiguous eighth
+    // of the slots; the fused force pass also walks strips of 2^order_strip_sh blocks through the z layers of that eighth
+    bool order_xcd = true, order_ztile = true;
+    uint32_t order_strip_sh = 4;
 
     // cell table: {start, end} per local cell, zero = empty
     uint2* cells = nullptr;        // = cells_base + 1
@@ -134,7 +138,8 @@ struct sph_ctx {
     uint32_t* mm_tile_cnt = nullptr; uint32_t* mm_tile_off = nullptr;
     uint32_t* mm_k0 = nullptr; uint32_t* mm_k1 = nullptr; uint32_t* mm_v1 = nullptr;   // mover (key, slot) ping-pong (+ v0)
     uint32_t* mm_count = nullptr;           // movers of the current sort (device)
-    uint32_t* mm_count_host = nullptr;      // pinned, written by the device: last known count (a hint)
+    uint32_t* mm_count_host = nullptr;      // pinned, written by the device: [0] last known count (a hint), [1], [2] the keys of
+                                            // the first / last owned slot after the last table build (block_order's estimate)
     uint32_t* mm_count_host_dev = nullptr;  // device view of the same word
     unsigned long long* mm_total = nullptr; // movers of all sorts so far (device; sph_sort_stats)
     hipEvent_t mm_done[4] = {nullptr, nullptr, nullptr, nullptr};   // end of the last four sorts: bounds the host's run-ahead

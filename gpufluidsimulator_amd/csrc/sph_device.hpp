@@ -7,23 +7,39 @@ namespace sph {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-// Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2.
-// Map the hardware block id to a logical one so that every XCD walks ONE contiguous eighth of the
-// sorted particles: neighbouring rows are then re-used out of that XCD's L2 instead of being
-// fetched through the fabric by all eight.  A bijection on [0, nb) for any nb.
-// Measured at C3 (round 1): no gain -- k_force 2.67 vs 2.63 ms, FETCH_SIZE 2.9 vs 2.6 GB; the three
-// z-layers a sweep re-uses (9.8 MB) exceed one XCD's 4 MB L2 either way, and the kernel is VALU-bound.
-// Off by default; -DSPH_XCD_SWIZZLE=1 to re-measure after a layout change.
-#ifndef SPH_XCD_SWIZZLE
-#define SPH_XCD_SWIZZLE 0
-#endif
-__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
-#if SPH_XCD_SWIZZLE
+// ---- which slots a workgroup of the pair kernels takes ---------------------------------------------------------------
+// Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own 4 MB L2, and an XCD
+// starts its blocks in the order of their ids.  A block stages rows of three z layers; with blocks walking the sorted
+// particles front to back on all XCDs at once, a row is fetched through the fabric again for every layer that uses it and
+// by every XCD: 3.1x the algorithmic bytes for k_force at C3 (profiles/pmc_traffic.json, rounds 2-4).  Two remappings of
+// the block id, both bijections on [0, nb), so that only the ORDER of the work changes (results do not depend on it):
+//   xcd   every XCD walks ONE contiguous eighth of the slots: FETCH_SIZE of k_force -24 %, of k_density -19 %, SQ cycles
+//         -1.2 % / +0.3 % (round 1 had measured "no gain" in time; the traffic it had not looked at);
+//   zt    inside that eighth, strips of 2^s_sh blocks are walked through all 2^nl_sh z layers of the eighth (2^lb_sh
+//         blocks per layer, from the host's estimate) before the next strip: the rows of layers z-1, z, z+1 of a strip
+//         are still in the XCD's L2 when the next layer's blocks of the same strip come by.  k_force FETCH_SIZE -51 %
+//         against the plain order (1.8x algorithmic traffic instead of 3.1x) and -3.6 % wall clock; k_density fetches
+//         -63 % but runs 2.8 % SLOWER (its blocks are short: the 2 MB jumps between layers cost it more than the fabric
+//         reads did), so it takes `xcd` only.  profiles/r04_block_order_traffic.txt, r04_block_order_wallclock_ab.txt.
+// Powers of two only (shifts, no divisions per wave): the estimate need not be exact, a tile that straddles two layers
+// only loses some of the reuse.
+struct BlockOrder {
+    uint32_t xcd;                   // 1: contiguous eighth per XCD
+    uint32_t lb_sh, s_sh, nl_sh;    // zt: log2 of blocks per layer, per strip, layers per XCD range; nl_sh = 0: off
+};
+
+__device__ __forceinline__ uint32_t ordered_block(uint32_t b, uint32_t nb, const BlockOrder& o) {
+    if (!o.xcd) return b;
     const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u;
-    return xcd * q + (xcd < r ? xcd : r) + (b >> 3);
-#else
-    return b;
-#endif
+    const uint32_t base = xcd * q + (xcd < r ? xcd : r);
+    uint32_t j = b >> 3;
+    if (o.nl_sh && j < (1u << (o.lb_sh + o.nl_sh))) {               // inside the whole layers of this XCD's range
+        const uint32_t per_sh = o.s_sh + o.nl_sh;                    // blocks per strip over all layers
+        const uint32_t st = j >> per_sh, rr = j & ((1u << per_sh) - 1u);
+        const uint32_t l = rr >> o.s_sh, col = (st << o.s_sh) + (rr & ((1u << o.s_sh) - 1u));
+        j = (l << o.lb_sh) + col;
+    }
+    return base + j;
 }
 
 // ---- wave64 reductions over DPP (no LDS): row reductions by quad_perm / mirrors, then

@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) void k_cells_clear(const uint32_t* __restrict_
 // (one slot per thread took 51 us for 16.7 M slots: far from any bandwidth)
 constexpr uint32_t CELLS_SPT = 4;
 __global__ __launch_bounds__(256) void k_cells_build(const uint32_t* __restrict__ key, uint32_t lo, uint32_t hi,
-                                                     uint2* __restrict__ cells) {
+                                                     uint2* __restrict__ cells, volatile uint32_t* __restrict__ ends_host) {
     const uint32_t s0 = lo + (blockIdx.x * 256u + threadIdx.x) * CELLS_SPT;
     if (s0 >= hi) return;
+    if (ends_host && s0 == lo) { ends_host[0] = key[lo]; ends_host[1] = key[hi - 1u]; }    // for the host's block order (block_order)
     uint32_t kk[CELLS_SPT + 2];                          // key[s0 - 1 .. s0 + 4]
     kk[1] = key[s0];
     kk[0] = s0 > lo ? key[s0 - 1] : ~kk[1];
@@ -137,7 +138,9 @@ int launch_cells_clear_range(sph_ctx* c, uint32_t lo, uint32_t hi) {
 
 int launch_cells_build_range(sph_ctx* c, uint32_t lo, uint32_t hi) {
     if (hi <= lo) return SPH_OK;
-    hipLaunchKernelGGL(k_cells_build, dim3(ceil_div(hi - lo, 256u * CELLS_SPT)), dim3(256), 0, c->stream, c->keyS, lo, hi, c->cells);
+    // (the whole owned range: the sort's table build -- also tells the host the first and the last key)
+    uint32_t* ends = (lo == c->own_off && hi == c->own_off + c->n) ? c->mm_count_host_dev + 1 : (uint32_t*)nullptr;
+    hipLaunchKernelGGL(k_cells_build, dim3(ceil_div(hi - lo, 256u * CELLS_SPT)), dim3(256), 0, c->stream, c->keyS, lo, hi, c->cells, ends);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
 }
@@ -380,6 +383,7 @@ struct Targets {
     uint32_t lo, hi, gap_lo, gap_len;
     const uint32_t* dev;
     uint32_t direct_hull;       // rows whose hull is longer are read straight from global memory (see traverse)
+    BlockOrder order;           // which block takes which slots (sph_device.hpp)
 };
 
 // Which 256 slots a block takes.  The waves that take the direct walk (sparse particles next to a dense layer, see
@@ -409,7 +413,7 @@ __device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, ui
     uint32_t lo = T.lo;
     hi = T.hi;
     if (T.dev) { lo = T.dev[0]; hi = T.dev[1]; }          // wave-uniform (scalar loads)
-    first = lo + (xcd_block(pair_block(), gridDim.x) * (blockDim.x >> 6) + wave) * WAVE;
+    first = lo + (ordered_block(pair_block(), gridDim.x, T.order) * (blockDim.x >> 6) + wave) * WAVE;
     if (first >= T.gap_lo) first += T.gap_len;
     i = first + lane;
     return first < hi;
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
     __shared__ float2 s_xy[DENS_ENT];
     __shared__ float s_z[DENS_ENT];
     // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
-    if (tg.dev && tg.dev[0] + pair_block() * (uint32_t)DENS_THREADS >= tg.dev[1]) return;
+    if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)DENS_THREADS >= tg.dev[1]) return;
     for (uint32_t k = threadIdx.x; k < DENS_ENT; k += DENS_THREADS) {   // see LDS_ENT: keep over-reads finite
         s_xy[k] = make_float2(0.f, 0.f);
         s_z[k] = 0.f;
@@ -1005,10 +1009,30 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     finish();
 }
 
+// The block order of a launch over `nblocks` blocks (BlockOrder, sph_device.hpp).  The z tiling needs the blocks per cell
+// layer: estimated from the keys of the first and the last owned slot, which k_cells_build leaves in mapped host memory
+// after every sort (a few steps old when the host runs ahead: an estimate is all that is needed).
+static BlockOrder block_order(const sph_ctx* c, uint32_t nblocks, bool ztile) {
+    BlockOrder o{c->order_xcd ? 1u : 0u, 0u, 0u, 0u};
+    if (!o.xcd || !ztile || !c->order_ztile || nblocks < 1024u) return o;
+    const uint32_t k0 = c->mm_count_host[1], k1 = c->mm_count_host[2], layer = c->grid.g[0] * c->grid.g[1];
+    if (k1 < k0 || layer == 0u) return o;
+    const uint32_t nz = k1 / layer - k0 / layer + 1u;                    // occupied cell layers
+    const uint32_t per_layer = nblocks / nz;                             // blocks per layer, about
+    if (per_layer < 32u) return o;
+    uint32_t lb_sh = 31u - (uint32_t)__builtin_clz(per_layer);
+    if ((per_layer >> lb_sh) && (per_layer - (1u << lb_sh)) > (1u << lb_sh) / 2u) lb_sh++;      // nearest power of two
+    const uint32_t q = nblocks >> 3, nl = q >> lb_sh;
+    if (nl < 2u) return o;
+    o.lb_sh = lb_sh; o.s_sh = c->order_strip_sh; o.nl_sh = 31u - (uint32_t)__builtin_clz(nl);
+    if (o.s_sh >= o.lb_sh) o.nl_sh = 0u;
+    return o;
+}
+
 // [lo, hi) minus the hole [hole_lo, hole_hi): the hole's start is rounded UP to a whole wave from lo (see Targets),
 // what is cut off the hole that way is simply computed by this launch as well.
 static Targets targets_with_hole(uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi, uint32_t& threads) {
-    Targets t{lo, hi, hi, 0u, nullptr, 0u};
+    Targets t{lo, hi, hi, 0u, nullptr, 0u, BlockOrder{0u, 0u, 0u, 0u}};
     threads = hi - lo;
     if (hole_lo < lo) hole_lo = lo;
     if (hole_hi > hi) hole_hi = hi;
@@ -1029,6 +1053,7 @@ int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, ui
     uint32_t threads;
     Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
     tg.direct_hull = c->direct_hull;
+    tg.order = block_order(c, ceil_div(threads, (uint32_t)PAIR_THREADS), integrate && force);      // (the fused launch: see BlockOrder)
     SPH_REQUIRE(tg.gap_len == 0u || (((tg.gap_lo - lo) | tg.gap_len) & 63u) == 0u || tg.gap_lo + tg.gap_len == hi, SPH_E_INVALID,
                 "force hole is not made of whole 64-slot chunks");
     if (threads == 0) return SPH_OK;
@@ -1099,6 +1124,7 @@ int launch_density_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, 
     uint32_t threads;
     Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
     tg.direct_hull = c->direct_hull;
+    tg.order = block_order(c, ceil_div(threads, (uint32_t)(c->precision == SPH_PRECISION_MIXED_F16 ? PAIR_THREADS : DENS_THREADS)), false);
     return launch_density_targets(c, tg, threads);
 }
 
@@ -1107,7 +1133,7 @@ int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi) { return launch_d
 // density over the slots [range_dev[0], range_dev[1]) -- two words of DEVICE memory written by an earlier kernel of
 // the stream; at most max_count slots (sizes the grid; waves beyond the range leave at once)
 int launch_density_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count) {
-    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev, c->direct_hull};
+    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev, c->direct_hull, block_order(c, ceil_div(max_count, (uint32_t)DENS_THREADS), false)};
     return launch_density_targets(c, tg, max_count);
 }
 

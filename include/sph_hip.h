@@ -229,6 +229,12 @@ int sph_set_sort_mode(sph_ctx* c, int merge);
  * and become the tail of the whole launch.  Both ways give the same bits.  0: every row direct; 0xFFFFFFFF: never
  * (for tests and A/B runs).  Takes effect at the next launch. */
 int sph_set_direct_hull(sph_ctx* c, uint32_t slots);
+/* The ORDER in which the neighbour passes' workgroups take the sorted slots (results do not depend on it).  xcd = 1
+ * (default): each of the 8 XCDs walks one contiguous eighth of the slots; ztile = 1 (default): the fused force pass also
+ * walks strips of 2^strip_blocks_log2 workgroups (default 4: 16 workgroups = 4096 slots) through the cell layers of that
+ * eighth before the next strip, so that the rows of neighbouring layers are re-used out of the XCD's L2: half the HBM-side
+ * reads of the plain order.  0 / 0 restores the plain front-to-back order (A/B runs). */
+int sph_set_block_order(sph_ctx* c, int xcd, int ztile, uint32_t strip_blocks_log2);
 /* 1 if the last sph_sort found that no particle had changed cell and left everything as it was (then
  * every count derived from the sorted order -- sph_slab_counts, sph_halo_count -- is that of the step
  * before), else 0.  No synchronisation. */

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the pair kernels for several library variants on ONE flowing C3 snapshot (GPU box, repo root):
-#   bash profiles/collect_pmc_ab.sh out_tag lib1.so lib2.so ...
+#   [PMC_COUNTERS="FETCH_SIZE"] bash profiles/collect_pmc_ab.sh out_tag lib1.so lib2.so ...
 # Clock-independent A/B: wall-clock A/B runs of one box differ by +-3 % (the chip sits at its power cap and the kernels
 # of a step share one thermal budget), SQ_BUSY_CYCLES / SQ_WAVE_CYCLES / SQ_INSTS_* per launch do not.
 set -e
@@ -9,10 +9,12 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export KB_SNAP=/tmp/c3_flow.snap
 [ -f $KB_SNAP ] || python profiles/scripts/kbench_flow.py --one prepare
 OUT=gpurun_out/pmc_ab; rm -rf $OUT; mkdir -p $OUT
-for LIB in "$@"; do
-  N=$(basename $LIB .so)
+for SPEC in "$@"; do                       # lib.so or lib.so@SPH_BLOCK_ORDER=0,0,4 (an environment setting for that run)
+  LIB=${SPEC%%@*}; SET=${SPEC#*@}; [ "$SET" = "$SPEC" ] && SET=""
+  N=$(basename $LIB .so)${SET:+_$(echo $SET | tr -c 'A-Za-z0-9' '_')}
   export SPH_HIP_LIB=$(realpath $LIB)
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex 'k_force|k_density' \
+  unset SPH_BLOCK_ORDER; [ -n "$SET" ] && export "$SET"
+  rocprofv3 --pmc ${PMC_COUNTERS:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE} --kernel-include-regex 'k_force|k_density' \
       --output-format csv -d $OUT/$N -o p -- python profiles/scripts/kbench_flow.py --one run > $OUT/$N.log 2>&1
   python - "$OUT/$N" "$N" <<'PY' >> gpurun_out/${TAG}_pmc_ab.txt
 import csv, glob, sys

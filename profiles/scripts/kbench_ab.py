@@ -17,9 +17,16 @@ snap = os.environ.get("KB_SNAP", "/tmp/c3_flow.snap")
 if not os.path.exists(snap):
     subprocess.run([sys.executable, os.path.join(HERE, "kbench_flow.py"), "--one", "prepare"], check=True, timeout=900)
 res = {l: [] for l in libs}
+# a "library" may carry environment settings: path.so@SPH_BLOCK_ORDER=0,0,4@OTHER=1
+def split(spec):
+    parts = spec.split("@")
+    return parts[0], dict(p.split("=", 1) for p in parts[1:])
+
+
 for rep in range(R):
     for lib in libs:
-        env = dict(os.environ, SPH_HIP_LIB=os.path.abspath(lib))
+        path, extra = split(lib)
+        env = dict(os.environ, SPH_HIP_LIB=os.path.abspath(path), **extra)
         r = subprocess.run([sys.executable, os.path.join(HERE, "kbench_flow.py"), "--one", "run"], env=env, capture_output=True,
                            text=True, timeout=600)
         line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
