@@ -1133,7 +1133,9 @@ int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi) { return launch_d
 // density over the slots [range_dev[0], range_dev[1]) -- two words of DEVICE memory written by an earlier kernel of
 // the stream; at most max_count slots (sizes the grid; waves beyond the range leave at once)
 int launch_density_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count) {
-    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev, c->direct_hull, block_order(c, ceil_div(max_count, (uint32_t)DENS_THREADS), false)};
+    // plain block order: the grid is only an upper bound, and with a contiguous eighth per XCD the blocks beyond the range
+    // would all belong to the last XCDs -- the first ones would do all the work
+    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev, c->direct_hull, BlockOrder{0u, 0u, 0u, 0u}};
     return launch_density_targets(c, tg, max_count);
 }
 
