@@ -197,8 +197,11 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
         rc = SPH_E_NOMEM;
     }
     if (const char* env = getenv("SPH_BLOCK_ORDER")) {          // "xcd,ztile,strip_log2" at create time: A/B runs (sph_set_block_order)
-        int x = 1, z = 1, sh = 4;
-        if (sscanf(env, "%d,%d,%d", &x, &z, &sh) >= 1) { c->order_xcd = x != 0; c->order_ztile = z != 0; if (sh >= 1 && sh <= 10) c->order_strip_sh = (uint32_t)sh; }
+        int x = 1, z = 1, sh = 4, zd = 1, xr = 1;
+        if (sscanf(env, "%d,%d,%d,%d,%d", &x, &z, &sh, &zd, &xr) >= 1) {
+            c->order_xcd = x != 0; c->order_ztile = z != 0; if (sh >= 1 && sh <= 10) c->order_strip_sh = (uint32_t)sh;
+            c->order_ztile_dens = zd != 0; c->order_xrot = xr != 0;
+        }
     }
     {   // merge sort scratch
         const char* env = getenv("SPH_SORT_MERGE");
@@ -974,7 +977,7 @@ int sph_set_block_order(sph_ctx* c, int xcd, int ztile, uint32_t strip_blocks_lo
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     SPH_REQUIRE(strip_blocks_log2 >= 1u && strip_blocks_log2 <= 10u, SPH_E_INVALID, "strip of 2^%u blocks", strip_blocks_log2);
     c->order_xcd = xcd != 0;
-    c->order_ztile = ztile != 0;
+    c->order_ztile = c->order_ztile_dens = ztile != 0;
     c->order_strip_sh = strip_blocks_log2;
     return SPH_OK;
 }

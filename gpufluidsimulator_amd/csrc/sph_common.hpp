@@ -93,6 +93,7 @@ struct sph_ctx {
     // block order of the pair kernels (sph_device.hpp: BlockOrder; sph_set_block_order): every XCD walks a contiguous eighth
     // of the slots; the fused force pass also walks strips of 2^order_strip_sh blocks through the z layers of that eighth
     bool order_xcd = true, order_ztile = true;
+    bool order_ztile_dens = true, order_xrot = true;        // (SPH_BLOCK_ORDER fields 4 and 5: the strips for the density pass too; XCD x starts at strip x * strips / 8)
     uint32_t order_strip_sh = 4;
 
     // cell table: {start, end} per local cell, zero = empty

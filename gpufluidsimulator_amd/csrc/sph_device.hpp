@@ -19,13 +19,16 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 //         blocks per layer, from the host's estimate) before the next strip: the rows of layers z-1, z, z+1 of a strip
 //         are still in the XCD's L2 when the next layer's blocks of the same strip come by.  k_force FETCH_SIZE -51 %
 //         against the plain order (1.8x algorithmic traffic instead of 3.1x) and -3.6 % wall clock; k_density fetches
-//         -63 % but runs 2.8 % SLOWER (its blocks are short: the 2 MB jumps between layers cost it more than the fabric
-//         reads did), so it takes `xcd` only.  profiles/r04_block_order_traffic.txt, r04_block_order_wallclock_ab.txt.
+//         -55..63 % but ran 2.8 % SLOWER until the XCDs stopped walking the SAME strip at the same time (`xrot`: XCD x
+//         starts at strip x * strips / 8 -- eight XCDs x sixteen layers at one offset modulo the 2 MB layer stride had
+//         been hitting the same memory channels): with it the time is that of the plain order.
+//         profiles/r04_block_order_traffic.txt, r04_block_order_wallclock_ab.txt.
 // Powers of two only (shifts, no divisions per wave): the estimate need not be exact, a tile that straddles two layers
 // only loses some of the reuse.
 struct BlockOrder {
     uint32_t xcd;                   // 1: contiguous eighth per XCD
     uint32_t lb_sh, s_sh, nl_sh;    // zt: log2 of blocks per layer, per strip, layers per XCD range; nl_sh = 0: off
+    uint32_t xrot;                  // zt: XCD x starts at strip x * (strips / 8) instead of strip 0
 };
 
 __device__ __forceinline__ uint32_t ordered_block(uint32_t b, uint32_t nb, const BlockOrder& o) {
@@ -35,7 +38,9 @@ __device__ __forceinline__ uint32_t ordered_block(uint32_t b, uint32_t nb, const
     uint32_t j = b >> 3;
     if (o.nl_sh && j < (1u << (o.lb_sh + o.nl_sh))) {               // inside the whole layers of this XCD's range
         const uint32_t per_sh = o.s_sh + o.nl_sh;                    // blocks per strip over all layers
-        const uint32_t st = j >> per_sh, rr = j & ((1u << per_sh) - 1u);
+        uint32_t st = j >> per_sh;
+        const uint32_t rr = j & ((1u << per_sh) - 1u);
+        if (o.xrot) { const uint32_t ns_sh = o.lb_sh - o.s_sh; st = (st + ((xcd << ns_sh) >> 3)) & ((1u << ns_sh) - 1u); }
         const uint32_t l = rr >> o.s_sh, col = (st << o.s_sh) + (rr & ((1u << o.s_sh) - 1u));
         j = (l << o.lb_sh) + col;
     }

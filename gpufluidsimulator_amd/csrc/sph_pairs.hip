@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
 // layer: estimated from the keys of the first and the last owned slot, which k_cells_build leaves in mapped host memory
 // after every sort (a few steps old when the host runs ahead: an estimate is all that is needed).
 static BlockOrder block_order(const sph_ctx* c, uint32_t nblocks, bool ztile) {
-    BlockOrder o{c->order_xcd ? 1u : 0u, 0u, 0u, 0u};
+    BlockOrder o{c->order_xcd ? 1u : 0u, 0u, 0u, 0u, c->order_xrot ? 1u : 0u};
     if (!o.xcd || !ztile || !c->order_ztile || nblocks < 1024u) return o;
     const uint32_t k0 = c->mm_count_host[1], k1 = c->mm_count_host[2], layer = c->grid.g[0] * c->grid.g[1];
     if (k1 < k0 || layer == 0u) return o;
@@ -1032,7 +1032,7 @@ static BlockOrder block_order(const sph_ctx* c, uint32_t nblocks, bool ztile) {
 // [lo, hi) minus the hole [hole_lo, hole_hi): the hole's start is rounded UP to a whole wave from lo (see Targets),
 // what is cut off the hole that way is simply computed by this launch as well.
 static Targets targets_with_hole(uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi, uint32_t& threads) {
-    Targets t{lo, hi, hi, 0u, nullptr, 0u, BlockOrder{0u, 0u, 0u, 0u}};
+    Targets t{lo, hi, hi, 0u, nullptr, 0u, BlockOrder{0u, 0u, 0u, 0u, 0u}};
     threads = hi - lo;
     if (hole_lo < lo) hole_lo = lo;
     if (hole_hi > hi) hole_hi = hi;
@@ -1124,7 +1124,7 @@ int launch_density_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, 
     uint32_t threads;
     Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
     tg.direct_hull = c->direct_hull;
-    tg.order = block_order(c, ceil_div(threads, (uint32_t)(c->precision == SPH_PRECISION_MIXED_F16 ? PAIR_THREADS : DENS_THREADS)), false);
+    tg.order = block_order(c, ceil_div(threads, (uint32_t)(c->precision == SPH_PRECISION_MIXED_F16 ? PAIR_THREADS : DENS_THREADS)), c->order_ztile_dens);
     return launch_density_targets(c, tg, threads);
 }
 
@@ -1135,7 +1135,7 @@ int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi) { return launch_d
 int launch_density_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count) {
     // plain block order: the grid is only an upper bound, and with a contiguous eighth per XCD the blocks beyond the range
     // would all belong to the last XCDs -- the first ones would do all the work
-    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev, c->direct_hull, BlockOrder{0u, 0u, 0u, 0u}};
+    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev, c->direct_hull, BlockOrder{0u, 0u, 0u, 0u, 0u}};
     return launch_density_targets(c, tg, max_count);
 }
 

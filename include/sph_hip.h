@@ -230,8 +230,8 @@ int sph_set_sort_mode(sph_ctx* c, int merge);
  * (for tests and A/B runs).  Takes effect at the next launch. */
 int sph_set_direct_hull(sph_ctx* c, uint32_t slots);
 /* The ORDER in which the neighbour passes' workgroups take the sorted slots (results do not depend on it).  xcd = 1
- * (default): each of the 8 XCDs walks one contiguous eighth of the slots; ztile = 1 (default): the fused force pass also
- * walks strips of 2^strip_blocks_log2 workgroups (default 4: 16 workgroups = 4096 slots) through the cell layers of that
+ * (default): each of the 8 XCDs walks one contiguous eighth of the slots; ztile = 1 (default): inside its eighth an XCD
+ * walks strips of 2^strip_blocks_log2 workgroups (default 4: 16 workgroups = 4096 slots) through all cell layers of the
  * eighth before the next strip, so that the rows of neighbouring layers are re-used out of the XCD's L2: half the HBM-side
  * reads of the plain order.  0 / 0 restores the plain front-to-back order (A/B runs). */
 int sph_set_block_order(sph_ctx* c, int xcd, int ztile, uint32_t strip_blocks_log2);
