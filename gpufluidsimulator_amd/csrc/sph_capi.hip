@@ -45,6 +45,11 @@ static int derive(sph_ctx* c, const sph_params* p, uint32_t z_lo, uint32_t z_hi,
     for (int a = 0; a < 3; a++) {
         g.box_min[a] = p->box_min[a];
         g.box_dims[a] = p->box_max[a] - p->box_min[a];
+        {   // a power-of-two edge (every BASELINE config: 4, 8, 32, 64): x / edge == x * (1 / edge) in every bit
+            int e = 0;
+            const float m = frexpf(g.box_dims[a], &e);
+            g.inv_dims[a] = (m == 0.5f && e > -100 && e < 100) ? 1.0f / g.box_dims[a] : 0.0f;
+        }
         g.g[a] = p->grid[a];
         g.gf[a] = (float)p->grid[a];
     }

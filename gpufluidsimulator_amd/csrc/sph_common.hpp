@@ -25,6 +25,7 @@ constexpr uint32_t MM_TILE_CHUNKS = 256;   // merge sort: 64-slot chunks per sca
 struct GridDesc {
     float box_min[3];
     float box_dims[3];     // box_max - box_min
+    float inv_dims[3];     // 1 / box_dims where that is a power of two (the division is then an exact scaling), else 0
     uint32_t g[3];         // global cells per axis
     float gf[3];           // (float)g
     int32_t z_off;         // local z layer = global z layer - z_off (slab: z_lo - 1; whole domain: 0)

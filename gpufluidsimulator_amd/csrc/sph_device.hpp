@@ -116,13 +116,25 @@ __device__ __forceinline__ uint32_t cell_coord(float p, float bmin, float bdim, 
     return (uint32_t)c;
 }
 
+// The same with the division replaced by an exact scaling where the box edge is a power of two (inv != 0: GridDesc::
+// inv_dims): x / 2^k and x * 2^-k are the same float, and an IEEE division is ~10 instructions (three of them in the
+// integrate epilogue of every particle).  Other edges keep the division.
+__device__ __forceinline__ uint32_t cell_coord(float p, float bmin, float bdim, float inv, float gf, uint32_t g) {
+    const float rel = p - bmin;
+    const float q = (inv != 0.f ? rel * inv : rel / bdim) * gf;              // (wave-uniform choice)
+    int c = (int)floorf(q);
+    c = c < 0 ? 0 : c;
+    c = c >= (int)g ? (int)g - 1 : c;
+    return (uint32_t)c;
+}
+
 // Local cell key: x fastest, then y, then the local z layer (global z - z_off; in a slab context
 // layer 0 and layer zl-1 are the ghost layers, a whole-domain context has none).  The reference numbers cells in Morton order
 // (particleSystem.cu:68-91); the numbering is internal: results are reported by creation index.
 __device__ __forceinline__ uint32_t cell_key(const GridDesc& g, float x, float y, float z) {
-    uint32_t cx = cell_coord(x, g.box_min[0], g.box_dims[0], g.gf[0], g.g[0]);
-    uint32_t cy = cell_coord(y, g.box_min[1], g.box_dims[1], g.gf[1], g.g[1]);
-    uint32_t cz = cell_coord(z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]);
+    uint32_t cx = cell_coord(x, g.box_min[0], g.box_dims[0], g.inv_dims[0], g.gf[0], g.g[0]);
+    uint32_t cy = cell_coord(y, g.box_min[1], g.box_dims[1], g.inv_dims[1], g.gf[1], g.g[1]);
+    uint32_t cz = cell_coord(z, g.box_min[2], g.box_dims[2], g.inv_dims[2], g.gf[2], g.g[2]);
     // particles outside the local layers cannot be represented: clamp into the outermost ones
     int lz = (int)cz - g.z_off;
     lz = lz < 0 ? 0 : lz;

@@ -713,9 +713,15 @@ __device__ __forceinline__ void integrate_one(const Phys& ph, float dt, float4& 
     pi.x += dt * vi.x;
     pi.y += dt * vi.y;
     pi.z += dt * vi.z;
-    wall(pi.x, vi.x, ph.box_min[0], ph.box_max[0], ph.wall_eps, ph.wall_damping);
-    wall(pi.y, vi.y, ph.box_min[1], ph.box_max[1], ph.wall_eps, ph.wall_damping);
-    wall(pi.z, vi.z, ph.box_min[2], ph.box_max[2], ph.wall_eps, ph.wall_damping);
+    // (a wave whose 64 particles are all clear of the walls -- nearly every wave -- skips the six tests' selects)
+    const float e = ph.wall_eps;
+    const bool near_wall = pi.x - e < ph.box_min[0] || pi.x + e > ph.box_max[0] || pi.y - e < ph.box_min[1] || pi.y + e > ph.box_max[1] ||
+                           pi.z - e < ph.box_min[2] || pi.z + e > ph.box_max[2];
+    if (__ballot(near_wall) != 0ull) {
+        wall(pi.x, vi.x, ph.box_min[0], ph.box_max[0], ph.wall_eps, ph.wall_damping);
+        wall(pi.y, vi.y, ph.box_min[1], ph.box_max[1], ph.wall_eps, ph.wall_damping);
+        wall(pi.z, vi.z, ph.box_min[2], ph.box_max[2], ph.wall_eps, ph.wall_damping);
+    }
 }
 
 // ---- force / collision / integrate in ONE neighbour traversal ------------------------------------------
