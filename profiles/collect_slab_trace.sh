@@ -2,7 +2,7 @@
 # Kernel trace of ONE rank's share of the metric's 8-GPU point (run on the GPU box from the repo root):
 #   bash profiles/collect_slab_trace.sh [tag]
 # C3 cut into 8 z-slabs gives every rank a 256 x 256 x 32 lattice (2,097,152 particles); this traces that slab alone
-# (bench.py --force-slab --lattice 256,256,32: the slab step with no neighbours -- every kernel, event hop and the
+# (bench.py --force-slab --lattice 256,256,32: the slab step of ONE slab with no neighbours -- sort chain, bounds, split density, force, the
 # host wait of the real step, no transfers) and summarises the timed window with profiles/step_trace_summary.py.
 set -e
 TAG=${1:-r03}
