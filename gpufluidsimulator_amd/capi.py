@@ -115,6 +115,12 @@ SIGNATURES = {
     "sph_rccl_transport_create": (C.c_int, [C.POINTER(C.POINTER(Transport)), C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "sph_rccl_transport_destroy": (None, [C.POINTER(Transport)]),
     "sph_rccl_transport_selftest": (C.c_int, [C.POINTER(Transport), C.c_size_t]),
+    "sph_rccl_transport_info": (C.c_int, [C.POINTER(Transport), C.POINTER(C.c_int)]),
+    "sph_slab_ping": (C.c_int, [_P, C.c_size_t, _U32, C.POINTER(C.c_double)]),
+    "sph_slab_timing_enable": (C.c_int, [_P, C.c_int]),
+    "sph_slab_timing_reset": (C.c_int, [_P]),
+    "sph_slab_timing_get": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "sph_slab_test_raise_flag": (C.c_int, [_P, C.c_int]),
     "sph_slab_in_place_merges": (C.c_uint64, [C.c_void_p]),
     "sph_slab_exchanges": (C.c_uint64, [C.c_void_p]),
     "sph_slab_failed": (C.c_int, [C.c_void_p]),

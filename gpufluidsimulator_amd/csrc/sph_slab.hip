@@ -47,6 +47,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <cstring>
 #include <new>
 
@@ -68,7 +69,7 @@ enum {
 enum { SLAB_ERR_INSERT_LAYER = 0, SLAB_ERR_ARRIVAL_OUTSIDE = 1 };
 // device words (sph_slab::d_lb): [0..3] bounds, [4..5] deep range (absolute), [6..7] far counts, [8..10] the
 // fused kernel's block counters {far down, far up, blocks done}
-enum { DL_DEEP = 4, DL_FAR = 6, DL_CTR = 8, DL_NEAR = 12, DL_WORDS = 16 };
+enum { DL_DEEP = 4, DL_FAR = 6, DL_CTR = 8, DL_NEAR = 12, DL_PING = 14, DL_WORDS = 16 };
 
 constexpr uint32_t MIG_INLINE = 255;   // leavers per side that ride in the first (fixed-size, 8 KB) migrant message
 
@@ -355,6 +356,30 @@ __global__ __launch_bounds__(256) void k_slab_copy_back(const float4* __restrict
     k_dst[first + t] = k_src[first + t];
 }
 
+// ---- neighbour ping (sph_slab_ping): a message whose every word says who sent it, towards which side, in which round --
+__device__ __forceinline__ uint32_t ping_word(uint32_t rank, uint32_t side, uint32_t rep, uint32_t i) {
+    uint32_t x = (rank * 2u + side) * 0x9E3779B9u + rep * 0x85EBCA6Bu + i;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_slab_ping_fill(uint32_t* __restrict__ lo, uint32_t* __restrict__ hi, uint32_t words,
+                                                        uint32_t rank, uint32_t rep) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) {
+        if (lo) lo[i] = ping_word(rank, 0u, rep, i);
+        if (hi) hi[i] = ping_word(rank, 1u, rep, i);
+    }
+}
+// what came from below was sent UP by rank - 1 (its side 1), what came from above was sent DOWN by rank + 1 (its side 0)
+__global__ __launch_bounds__(256) void k_slab_ping_check(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
+                                                         uint32_t words, uint32_t rank, uint32_t rep, uint32_t* __restrict__ bad) {
+    uint32_t wrong = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) {
+        if (lo) wrong += lo[i] != ping_word(rank - 1u, 1u, rep, i) ? 1u : 0u;
+        if (hi) wrong += hi[i] != ping_word(rank + 1u, 0u, rep, i) ? 1u : 0u;
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
 }  // namespace sph
 
 using namespace sph;
@@ -376,6 +401,10 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;            // optional: what the communicator itself says it is
+    int (*CommUserRank)(void*, int*) = nullptr;
+    int (*CommCuDevice)(void*, int*) = nullptr;
+    int (*CommGetAsyncError)(void*, int*) = nullptr;
 };
 Rccl g_rccl;
 
@@ -399,6 +428,10 @@ int rccl_load() {
     SPH_SYM(GroupEnd, "ncclGroupEnd");
     SPH_SYM(GetErrorString, "ncclGetErrorString");
 #undef SPH_SYM
+    *(void**)(&g_rccl.CommCount) = dlsym(h, "ncclCommCount");
+    *(void**)(&g_rccl.CommUserRank) = dlsym(h, "ncclCommUserRank");
+    *(void**)(&g_rccl.CommCuDevice) = dlsym(h, "ncclCommCuDevice");
+    *(void**)(&g_rccl.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
     g_rccl.lib = h;
     return SPH_OK;
 }
@@ -573,7 +606,20 @@ struct sph_slab {
     char fail_msg[512] = {0};
     bool transport_dead = false;
     // what the step in flight has exchanged so far and what it still owes its neighbours (slab_fail)
+    // ---- where a step's time goes (sph_slab_timing_get).  Host side, always on (three clock reads per step): the one
+    //      wait, the host time in front of it (hash / sort / bounds / migrant exchange queued) and the whole call.
+    //      Device side, only while sph_slab_timing_enable(1): an event pair around every transport call on the comm
+    //      stream (an event recorded on a stream costs the device ~5 us at its next dispatch: not in timed runs).
+    struct Acc { uint64_t n = 0; double sum = 0.0, max = 0.0; void add(double v) { n++; sum += v; if (v > max) max = v; } };
+    Acc t_wait, t_pre, t_post, t_host;
+    uint64_t waits_ready = 0;            // waits whose sequence word was there at the first look: the HOST is behind the device
+    Acc t_group[5];                      // by tag - 1: MIGRANTS, HALO_A, HALO_B, MIGRANTS_REST, PING
+    bool time_groups = false;
+    struct Pending { int tag; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_free;
     struct Progress {
+        bool mig_posted = false;                     // this step's SPH_TAG_MIGRANTS exchange has been handed to the transport
         bool headers = false, rest = false, halo_a = false, halo_b = false;
         bool peer_dead[2] = {false, false};          // that neighbour's header said "abort": nothing more to or from it
         uint32_t rest_s[2] = {0, 0}, rest_r[2] = {0, 0};   // records of the second migrant message (send, receive) per side
@@ -596,14 +642,43 @@ void slab_free(sph_slab* s) {
     if (s->ev_main) hipEventDestroy(s->ev_main);
     if (s->ev_comm) hipEventDestroy(s->ev_comm);
     if (s->ev_deep) hipEventDestroy(s->ev_deep);
+    for (auto& pd : s->pending) { hipEventDestroy(pd.a); hipEventDestroy(pd.b); }
+    for (hipEvent_t e : s->ev_free) hipEventDestroy(e);
     if (s->comm) hipStreamDestroy(s->comm);
     delete s;
 }
 
 // hand the four buffers to the transport.  Device transports get device pointers and the comm stream; host-staged
 // ones get pinned host copies (the comm stream is drained first: a test transport, not the product path).
+hipEvent_t slab_timing_event(sph_slab* s) {
+    hipEvent_t e = nullptr;
+    if (!s->ev_free.empty()) { e = s->ev_free.back(); s->ev_free.pop_back(); return e; }
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+
+int slab_exchange_raw(sph_slab* s, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
+                      const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes);
+
+// the transport call of one message group; with sph_slab_timing_enable an event pair brackets it on the comm stream: the
+// time between the two is the group as the DEVICE sees it -- waiting for the neighbour's half included, which is the point
 int slab_exchange(sph_slab* s, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
                   const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (s->time_groups && tag >= 1 && tag <= 5) {
+        a = slab_timing_event(s); b = slab_timing_event(s);
+        if (a && b) SPH_HIP(hipEventRecord(a, s->comm));
+    }
+    const int rc = slab_exchange_raw(s, tag, send_lo, send_lo_bytes, recv_lo, recv_lo_bytes, send_hi, send_hi_bytes, recv_hi,
+                                     recv_hi_bytes);
+    if (a && b) {
+        if (rc == SPH_OK && hipEventRecord(b, s->comm) == hipSuccess) s->pending.push_back({tag, a, b});
+        else { s->ev_free.push_back(a); s->ev_free.push_back(b); }
+    }
+    return rc;
+}
+
+int slab_exchange_raw(sph_slab* s, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
+                      const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes) {
     if (!s->has_lo || s->pg.peer_dead[0]) send_lo_bytes = recv_lo_bytes = 0;
     if (!s->has_hi || s->pg.peer_dead[1]) send_hi_bytes = recv_hi_bytes = 0;
     s->exchanges++;
@@ -652,6 +727,7 @@ struct OnComm {
 int slab_wait_headers(sph_slab* s) {
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t spins = 0;
+    if (s->h_lb[HL_SEQ] == s->seq) s->waits_ready++;          // the device got here first: this step is paced by the host
     while (s->h_lb[HL_SEQ] != s->seq) {
         __builtin_ia32_pause();
         if ((++spins & 0x3FFFu) == 0u) {
@@ -668,6 +744,7 @@ int slab_wait_headers(sph_slab* s) {
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     s->host_waits++;
+    s->t_wait.add(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     return SPH_OK;
 }
 
@@ -680,9 +757,23 @@ int slab_check_device_flags(sph_slab* s) {
     return SPH_OK;
 }
 
+// elapsed times of the bracketed transport calls so far (drains the comm stream)
+int slab_timing_collect(sph_slab* s) {
+    if (s->pending.empty()) return SPH_OK;
+    SPH_HIP(hipStreamSynchronize(s->comm));
+    for (auto& pd : s->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pd.a, pd.b) == hipSuccess) s->t_group[pd.tag - 1].add((double)ms * 1e3);
+        s->ev_free.push_back(pd.a); s->ev_free.push_back(pd.b);
+    }
+    s->pending.clear();
+    return SPH_OK;
+}
+
 int slab_step_body(sph_slab* s, float dt) {
     sph_ctx* c = s->c;
     int rc;
+    const auto t_begin = std::chrono::steady_clock::now();
     s->pg = sph_slab::Progress();
     rc = slab_check_device_flags(s); if (rc) return rc;
     // ---- hash + sort the owned particles (leavers end up at the two ends of the owned range) -----------------------
@@ -709,6 +800,7 @@ int slab_step_body(sph_slab* s, float dt) {
     }
     const uint32_t inl = min(MIG_INLINE, s->mcap);
     const size_t mig_bytes = (size_t)(1 + inl) * rec;
+    s->pg.mig_posted = true;                                    // (also when the call fails: the transport is dead then)
     rc = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
                        s->mig_recv[1], mig_bytes);
     if (rc) return rc;
@@ -716,7 +808,9 @@ int slab_step_body(sph_slab* s, float dt) {
                        s->has_hi ? s->mig_recv[1] : (float4*)nullptr, s->h_lb_dev, s->seq);
     SPH_HIP(hipGetLastError());
     // ---- the one host wait of the step ---------------------------------------------------------------------------
+    s->t_pre.add(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     rc = slab_wait_headers(s); if (rc) return rc;
+    const auto t_waited = std::chrono::steady_clock::now();
     s->pg.headers = true;
     const uint32_t lb0 = s->h_lb[HL_LB], lb1 = s->h_lb[HL_LB + 1], lb2 = s->h_lb[HL_LB + 2], lb3 = s->h_lb[HL_LB + 3];
     const uint32_t deep_lo = s->h_lb[HL_DEEP], deep_hi = s->h_lb[HL_DEEP + 1];
@@ -1005,6 +1099,12 @@ int slab_step_body(sph_slab* s, float dt) {
     // k_slab_bounds_pack, i.e. behind everything queued above)
     s->steps++;
     if (c->timing) { c->timed_steps++; if (c->events.size() > 3 * 4096) timing_collect(c); }
+    {
+        const auto t_end = std::chrono::steady_clock::now();
+        s->t_post.add(std::chrono::duration<double, std::micro>(t_end - t_waited).count());
+        s->t_host.add(std::chrono::duration<double, std::micro>(t_end - t_begin).count());
+    }
+    if (s->pending.size() > 4096) { rc = slab_timing_collect(s); if (rc) return rc; }
     return SPH_OK;
 }
 
@@ -1013,7 +1113,8 @@ int slab_step_body(sph_slab* s, float dt) {
 // (1) still exchanges what the step owes -- the numbers of Progress, contents irrelevant: the run is over --, (2) puts
 // "abort" into the header of its NEXT migrant message and exchanges that too, (3) is marked failed: every later call
 // returns the first error.  A neighbour reads the abort word at its next wait, returns SPH_E_PEER and does the same
-// towards ITS other neighbour: the failure reaches rank r +- k after k steps, nobody waits for a timeout.  If the
+// towards ITS other neighbour: the failure reaches rank r +- k after k steps, nobody waits for a timeout.  A step that
+// fails before its own migrant message was posted sends the abort header AS that message (same step).  If the
 // transport itself failed (or a wait timed out: the neighbour is gone) nothing more is exchanged and the transport is
 // aborted (RCCL: ncclCommAbort), so that destroy / sync do not block on a receive that will never complete.
 int slab_fail(sph_slab* s, int rc) {
@@ -1024,7 +1125,16 @@ int slab_fail(sph_slab* s, int rc) {
     const size_t rec = 2 * sizeof(float4);
     const uint32_t inl = min(MIG_INLINE, s->mcap);
     int e = SPH_OK;
-    if (!s->transport_dead && g.headers && s->world > 1) {
+    if (!s->transport_dead && !g.mig_posted && s->world > 1) {
+        // the step failed BEFORE its migrant message went out (a device-side flag of the last step, the sort, a launch):
+        // the neighbours are about to post theirs, so the abort header travels as THIS step's migrant message -- they
+        // read it at this step's wait and stop; nothing else is owed (no header of this rank promised anything)
+        g.mig_posted = true;
+        hipLaunchKernelGGL(k_slab_abort_headers, dim3(1), dim3(64), 0, s->comm, s->mig_send[0], s->mig_send[1]);
+        const size_t mig_bytes = (size_t)(1 + inl) * rec;
+        e = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
+                          s->mig_recv[1], mig_bytes);
+    } else if (!s->transport_dead && g.headers && s->world > 1) {
         if (!g.rest && (g.rest_s[0] | g.rest_s[1] | g.rest_r[0] | g.rest_r[1]))
             e = slab_exchange(s, SPH_TAG_MIGRANTS_REST, s->mig_send[0] + 2 * (1 + inl), g.rest_s[0] * rec, s->mig_recv[0] + 2 * (1 + inl),
                               g.rest_r[0] * rec, s->mig_send[1] + 2 * (1 + inl), g.rest_s[1] * rec, s->mig_recv[1] + 2 * (1 + inl),
@@ -1255,12 +1365,32 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
     return SPH_OK;
 }
 
+// Draining the comm stream of a slab that FAILED must not wait for ever: its last act was to queue an "abort" migrant
+// message for the neighbours' next step, and if they never take another step (the failure came on the run's last step, or
+// they failed themselves) that send / receive pair is never matched.  Poll, bounded by the step's wait time-out, then take
+// the transport down (RCCL: ncclCommAbort) and only then synchronise.
+static void slab_drain_comm(sph_slab* s) {
+    if (s->transport_dead && s->tr.abort) s->tr.abort(s->tr.self);     // (idempotent) nothing of a dead link stays queued
+    if (s->failed && !s->transport_dead) {
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t q;
+        while ((q = hipStreamQuery(s->comm)) == hipErrorNotReady) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > s->wait_timeout_s) {
+                s->transport_dead = true;
+                if (s->tr.abort) s->tr.abort(s->tr.self);
+                break;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    hipStreamSynchronize(s->comm);
+}
+
 // must run BEFORE sph_destroy of its context (it drains the context's stream, on which its kernels run)
 void sph_slab_destroy(sph_slab* s) {
     if (!s) return;
     hipSetDevice(s->device);
-    if (s->transport_dead && s->tr.abort) s->tr.abort(s->tr.self);     // (idempotent) nothing of a dead link stays queued
-    hipStreamSynchronize(s->comm);
+    slab_drain_comm(s);
     hipStreamSynchronize(s->c->stream);
     s->c->host_paced = false;
     slab_free(s);
@@ -1285,10 +1415,133 @@ int sph_slab_step(sph_slab* s, float dt, uint32_t n_steps) {
 int sph_slab_sync(sph_slab* s) {
     SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
     SPH_HIP(hipSetDevice(s->c->device));
-    SPH_HIP(hipStreamSynchronize(s->comm));
+    slab_drain_comm(s);
+    SPH_HIP(hipStreamQuery(s->comm));
     int rc = sph_sync(s->c);
     if (rc) return rc;
     return slab_check_device_flags(s);
+}
+
+int sph_slab_timing_enable(sph_slab* s, int on) {
+    SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
+    s->time_groups = on != 0;
+    return SPH_OK;
+}
+
+int sph_slab_timing_reset(sph_slab* s) {
+    SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
+    SPH_HIP(hipSetDevice(s->c->device));
+    int rc = slab_timing_collect(s);
+    if (rc) return rc;
+    s->t_wait = s->t_pre = s->t_post = s->t_host = sph_slab::Acc();
+    for (auto& g : s->t_group) g = sph_slab::Acc();
+    s->waits_ready = 0;
+    return SPH_OK;
+}
+
+int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]) {
+    SPH_REQUIRE(s && out, SPH_E_INVALID, "null argument");
+    SPH_HIP(hipSetDevice(s->c->device));
+    int rc = slab_timing_collect(s);
+    if (rc) return rc;
+    for (int k = 0; k < SPH_SLAB_T_WORDS; k++) out[k] = 0.0;
+    out[SPH_SLAB_T_STEPS] = (double)s->t_host.n;
+    out[SPH_SLAB_T_WAITS_READY] = (double)s->waits_ready;
+    const sph_slab::Acc* host[4] = {&s->t_wait, &s->t_pre, &s->t_post, &s->t_host};
+    for (int k = 0; k < 4; k++) { out[SPH_SLAB_T_WAIT + 2 * k] = host[k]->sum; out[SPH_SLAB_T_WAIT + 2 * k + 1] = host[k]->max; }
+    for (int g = 0; g < 4; g++) {
+        out[SPH_SLAB_T_GROUPS + 3 * g] = (double)s->t_group[g].n;
+        out[SPH_SLAB_T_GROUPS + 3 * g + 1] = s->t_group[g].sum;
+        out[SPH_SLAB_T_GROUPS + 3 * g + 2] = s->t_group[g].max;
+    }
+    return SPH_OK;
+}
+
+// One slab_exchange-shaped group of `bytes` per direction to rank - 1 and rank + 1, `reps` times (+ one untimed round
+// first: RCCL connects to a new peer on first use), on the comm stream, through the slab's own transport and buffers.
+// Every word of a message names its sender, direction and round and is checked on arrival, so a ring wired the wrong
+// way round fails here and not as wrong physics.  COLLECTIVE: every rank of the chain calls it with the same arguments.
+int sph_slab_ping(sph_slab* s, size_t bytes, uint32_t reps, double out[3]) {
+    SPH_REQUIRE(s && out && reps >= 1, SPH_E_INVALID, "bad argument");
+    SPH_REQUIRE(!s->failed, s->failed, "%s", s->fail_msg);
+    const size_t cap = (size_t)(s->gcap + 1) * 2 * sizeof(float4);
+    SPH_REQUIRE(bytes >= 4 && bytes % 4 == 0 && bytes <= cap, SPH_E_INVALID, "ping of %zu bytes: must be a multiple of 4 up to the halo "
+                "buffer's %zu", bytes, cap);
+    SPH_HIP(hipSetDevice(s->c->device));
+    out[0] = out[1] = out[2] = 0.0;
+    if (s->world < 2) return SPH_OK;
+    const uint32_t words = (uint32_t)(bytes / 4), grid = min(ceil_div(words, 256u), 1024u);
+    uint32_t* bad = s->d_lb + DL_PING;
+    SPH_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), s->comm));
+    const uint64_t exchanges0 = s->exchanges;
+    const bool timed0 = s->time_groups;
+    const sph_slab::Acc acc0 = s->t_group[4];
+    int rc = slab_timing_collect(s);
+    s->t_group[4] = sph_slab::Acc();
+    for (uint32_t rep = 0; rep <= reps && !rc; rep++) {
+        s->time_groups = rep > 0;                             // round 0 is the connection set-up
+        hipLaunchKernelGGL(k_slab_ping_fill, dim3(grid), dim3(256), 0, s->comm, s->has_lo ? (uint32_t*)s->halo_send[0] : nullptr,
+                           s->has_hi ? (uint32_t*)s->halo_send[1] : nullptr, words, (uint32_t)s->rank, rep);
+        rc = slab_exchange(s, SPH_TAG_PING, s->halo_send[0], bytes, s->halo_recv[0], bytes, s->halo_send[1], bytes, s->halo_recv[1], bytes);
+        if (rc) break;
+        hipLaunchKernelGGL(k_slab_ping_check, dim3(grid), dim3(256), 0, s->comm, s->has_lo ? (const uint32_t*)s->halo_recv[0] : nullptr,
+                           s->has_hi ? (const uint32_t*)s->halo_recv[1] : nullptr, words, (uint32_t)s->rank, rep, bad);
+        if (hipGetLastError() != hipSuccess) { set_error("ping: kernel launch failed"); rc = SPH_E_DEVICE; }
+    }
+    s->time_groups = timed0;
+    s->exchanges = exchanges0;                                // (the step counters keep counting steps' messages only)
+    if (!rc) {
+        // bounded: a neighbour that never answers must be an error message, not a hang
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t q;
+        while ((q = hipStreamQuery(s->comm)) == hipErrorNotReady) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > s->wait_timeout_s) {
+                set_error("rank %d: ping of %zu bytes: no answer from a neighbour after %.0f s", s->rank, bytes, s->wait_timeout_s);
+                s->transport_dead = true;
+                if (s->tr.abort) s->tr.abort(s->tr.self);
+                rc = SPH_E_DEVICE;
+                break;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        if (!rc && q != hipSuccess) { set_error("ping: %s", hipGetErrorString(q)); rc = SPH_E_DEVICE; }
+    }
+    uint32_t wrong = 0;
+    if (!rc && hipMemcpy(&wrong, bad, sizeof wrong, hipMemcpyDeviceToHost) != hipSuccess) { set_error("ping: read back failed"); rc = SPH_E_DEVICE; }
+    if (!rc) rc = slab_timing_collect(s);
+    if (!rc) {
+        out[0] = s->t_group[4].n ? s->t_group[4].sum / (double)s->t_group[4].n : 0.0;
+        out[1] = s->t_group[4].max;
+        out[2] = (double)wrong;
+        if (wrong) {
+            set_error("rank %d: ping of %zu bytes: %u words did not come from the neighbour and direction they should have come from",
+                      s->rank, bytes, wrong);
+            rc = SPH_E_STATE;
+        }
+    }
+    s->t_group[4] = acc0;
+    if (rc) { s->failed = rc; snprintf(s->fail_msg, sizeof s->fail_msg, "%s", sph_last_error()); }
+    return rc;
+}
+
+// test hook: raise one of the sticky device-side error words by hand (what k_slab_insert / k_slab_unpack do when an
+// arrival is where it cannot be), so that the failure path of a step that has not sent anything yet can be exercised
+int sph_slab_test_raise_flag(sph_slab* s, int flag) {
+    SPH_REQUIRE(s && flag >= 0 && flag < 2, SPH_E_INVALID, "bad argument");
+    s->h_lb[HL_ERR + flag] = 1u;
+    return SPH_OK;
+}
+
+int sph_rccl_transport_info(const sph_transport* t, int out[4]) {
+    SPH_REQUIRE(t && t->self && t->exchange == rccl_exchange && out, SPH_E_INVALID, "not an RCCL transport");
+    const RcclLink* L = (const RcclLink*)t->self;
+    out[0] = out[1] = out[2] = -1; out[3] = 0;
+    SPH_REQUIRE(L->comm && !L->aborted, SPH_E_DEVICE, "the RCCL communicator of rank %d was aborted", L->rank);
+    if (g_rccl.CommCount) SPH_NCCL(g_rccl.CommCount(L->comm, &out[0]));
+    if (g_rccl.CommUserRank) SPH_NCCL(g_rccl.CommUserRank(L->comm, &out[1]));
+    if (g_rccl.CommCuDevice) SPH_NCCL(g_rccl.CommCuDevice(L->comm, &out[2]));
+    if (g_rccl.CommGetAsyncError) SPH_NCCL(g_rccl.CommGetAsyncError(L->comm, &out[3]));
+    return SPH_OK;
 }
 
 uint64_t sph_slab_in_place_merges(const sph_slab* s) { return s ? s->inserts : 0; }

@@ -228,6 +228,8 @@ class HipEngine:
     @property
     def n(self): return self.ctx.n
     def upload(self, pos, vel, index): self.ctx.upload(pos, vel, index)
+    def reset_lattice(self, lattice, jitter, jitter_dims, start, count):
+        self.ctx.reset_lattice(lattice, jitter=jitter, jitter_dims=jitter_dims, start=start, count=count)
     def hash(self): self.ctx.hash()
     def sort(self): self.ctx.sort()
     def sort_skipped(self): return self.ctx.sort_skipped()
@@ -262,7 +264,7 @@ class HipEngine:
 # ------------------------------------------------------------------------------------------------
 class SlabSimulation:
     def __init__(self, comm, engine_factory, box, grid, lattice=None, jitter=True, jitter_dims=None,
-                 capacity_factor=1.5, ghost_factor=3.0, particles=None, capacity_slack=4096):
+                 capacity_factor=1.5, ghost_factor=3.0, particles=None, capacity_slack=4096, device_lattice=None):
         """comm: TorchDistComm | LocalComm.  engine_factory(capacity, ghost_capacity, params, z_lo, z_hi)
         builds this rank's engine.  Either `lattice` (dam break generated slab by slab) or
         `particles` = (pos, vel) of the WHOLE system (small tests)."""
@@ -276,6 +278,9 @@ class SlabSimulation:
         self.grid = tuple(int(g) for g in grid)
         self.params = capi.default_params(self.box, self.grid)
         gz = self.grid[2]
+        if device_lattice is None:         # the product engine generates its lattice layers on the device when it can
+            device_lattice = getattr(engine_factory, "device_lattice", False)
+        device_run = None                  # (first creation index, count) when the engine makes the particles itself
 
         if particles is not None:
             pos_all, vel_all = particles
@@ -309,6 +314,14 @@ class SlabSimulation:
             lo_l = cell_layer_of(zc - amp - 1e-4, self.box[2], gz)
             hi_l = cell_layer_of(zc + amp + 1e-4, self.box[2], gz)
             cand = np.nonzero((hi_l >= z_lo) & (lo_l < z_hi))[0]
+            # Whole lattice layers, none of them straddling a cut (every BASELINE config: the lattice planes sit a quarter
+            # of a cell from the faces, the jitter is 0.08 of a cell): the slab's particles are ONE run of creation
+            # indices, which the product engine generates in HBM itself (sph_reset_lattice, bit-identical to ic.py) --
+            # no host arrays, no PCIe; 8.4 M particles per rank at config 4 otherwise take numpy tens of seconds.
+            if (device_lattice and cand.size and np.all(np.diff(cand) == 1) and np.all(lo_l[cand] >= z_lo)
+                    and np.all(hi_l[cand] < z_hi)):
+                device_run = (int(cand[0]) * nx * ny, int(cand.size) * nx * ny)
+                cand = cand[:0]
             chunks_p, chunks_i = [], []
             for iz in cand:
                 start = int(iz) * nx * ny
@@ -321,13 +334,17 @@ class SlabSimulation:
             index = np.concatenate(chunks_i) if chunks_i else np.zeros((0,), np.uint32)
             vel = np.zeros_like(pos)
         self.z_lo, self.z_hi = z_lo, z_hi
-        n_own = int(pos.shape[0])
+        n_own = int(pos.shape[0]) if device_run is None else device_run[1]
         per_layer = max(int(hist.max()), 1)
+        self.per_layer = per_layer       # particles of the fullest cell layer: the size of a halo message (same on every rank)
         self.ghost_capacity = int(ghost_factor * per_layer) + 1024
         self.capacity = int(capacity_factor * max(n_own, self.total // self.world)) + int(capacity_slack)
         self._factory = engine_factory
         self.engine = engine_factory(self.capacity, self.ghost_capacity, self.params, z_lo, z_hi)
-        self.engine.upload(pos, vel, index)
+        if device_run is None:
+            self.engine.upload(pos, vel, index)
+        else:
+            self.engine.reset_lattice((nx, ny, nz), jitter, jd, device_run[0], device_run[1])
         self._alloc_buffers()
         self.lo_peer = self.rank - 1 if self.rank > 0 else None
         self.hi_peer = self.rank + 1 if self.rank + 1 < self.world else None
@@ -557,13 +574,19 @@ class NativeSlabSimulation(SlabSimulation):
     call into libsph_hip.so per rank: sph_slab_step queues sort, migrants, halo A, density, halo B and the fused
     force pass on two HIP streams and waits for the device once (csrc/sph_slab.hip)."""
 
-    def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, **kw):
+    def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, ping_reps=3, **kw):
         self._device_index = device_index
         self._transport_kind = transport
         self._migrant_capacity = migrant_capacity
         self._slab = None
         self._tr = None
-        super().__init__(comm, lambda cap, gcap, p, z0, z1: HipEngine(cap, gcap, p, z0, z1, device_index), box, grid, **kw)
+        self._ping_reps = int(ping_reps)
+        self.ping = None               # {bytes: {"mean_us", "max_us"}} of the preflight, per message size of a step
+        self.rccl = None               # what the RCCL communicator says about itself (sph_rccl_transport_info)
+        def factory(cap, gcap, p, z0, z1):
+            return HipEngine(cap, gcap, p, z0, z1, device_index)
+        factory.device_lattice = True
+        super().__init__(comm, factory, box, grid, **kw)
         self._bind()
 
     def _alloc_buffers(self):          # the library owns the message buffers
@@ -590,6 +613,62 @@ class NativeSlabSimulation(SlabSimulation):
         h = C.c_void_p()
         capi._check(L.sph_slab_create(C.byref(h), self.engine.ctx.h, self.rank, self.world, tr, int(self._migrant_capacity)))
         self._slab = h
+        if self._transport_kind == "rccl" and self.rccl is None:
+            info = (C.c_int * 4)()
+            capi._check(L.sph_rccl_transport_info(self._tr, info))
+            self.rccl = {"world_seen": int(info[0]), "rank_seen": int(info[1]), "device_seen": int(info[2]),
+                         "async_error": int(info[3]), "device": int(self._device_index)}
+            if self.rccl["world_seen"] not in (-1, self.world) or self.rccl["rank_seen"] not in (-1, self.rank):
+                raise capi.SphError(f"rank {self.rank}/{self.world}: the RCCL communicator says it is rank "
+                                    f"{self.rccl['rank_seen']} of {self.rccl['world_seen']}")
+        if self.ping is None and self.world > 1 and self._ping_reps > 0:
+            self.ping = self._preflight()
+
+    def message_sizes(self):
+        """Bytes per direction of the three message groups of a usual step: the fixed migrant message (header + 255
+        records), halo A (32 B per particle of a boundary layer) and halo B (8 B per particle) -- for the fullest cell
+        layer, clamped to the library's buffers.  The same on every rank (the histogram is global)."""
+        cap = (self.ghost_capacity + 1) * 32
+        return {"migrants": 8192, "halo_a": min(max(self.per_layer, 1) * 32, cap), "halo_b": min(max(self.per_layer, 1) * 8, cap)}
+
+    def _preflight(self):
+        """Neighbour ping before the first step (collective): one exchange-shaped group to rank +- 1 at each of the
+        step's three message sizes through the product path (sph_slab_ping: the slab's transport, comm stream and
+        buffers; every word checked for sender and direction).  An RCCL error, a neighbour that does not answer or a
+        wrong word raises here with the library's message -- there is no fall-back to another transport."""
+        import ctypes as C
+        L = capi.load()
+        out = {}
+        for name, nbytes in self.message_sizes().items():
+            res = (C.c_double * 3)()
+            capi._check(L.sph_slab_ping(self._slab, int(nbytes), self._ping_reps, res))
+            out[name] = {"bytes": int(nbytes), "mean_us": float(res[0]), "max_us": float(res[1])}
+        return out
+
+    def slab_timing(self, reset=False):
+        """sph_slab_timing_get as a dict (microseconds): host_wait / host_pre / host_post / host_step {mean, max} over
+        the steps since the last reset, waits_ready (the header was there before the host looked: host-paced steps),
+        and per message group {calls, mean, max} of the event pairs on the comm stream (only while enabled)."""
+        import ctypes as C
+        L = capi.load()
+        w = (C.c_double * 22)()
+        capi._check(L.sph_slab_timing_get(self._slab, w))
+        n = max(w[0], 1.0)
+        out = {"steps": int(w[0]), "waits_ready": int(w[1])}
+        for k, name in enumerate(("host_wait_us", "host_pre_us", "host_post_us", "host_step_us")):
+            out[name] = {"mean": w[2 + 2 * k] / n, "max": w[3 + 2 * k]}
+        for g, name in enumerate(("migrants", "halo_a", "halo_b", "migrants_rest")):
+            c = w[10 + 3 * g]
+            out["exchange_us_" + name] = {"calls": int(c), "mean": w[11 + 3 * g] / c if c else None, "max": w[12 + 3 * g]}
+        if reset:
+            capi._check(L.sph_slab_timing_reset(self._slab))
+        return out
+
+    def slab_timing_enable(self, on=True):
+        capi._check(capi.load().sph_slab_timing_enable(self._slab, 1 if on else 0))
+
+    def slab_timing_reset(self):
+        capi._check(capi.load().sph_slab_timing_reset(self._slab))
 
     def _unbind(self):
         if self._slab:
@@ -668,6 +747,86 @@ def bench_config(args, world):
     return cfg, strong, label
 
 
+def gather_rows(comm, row):
+    """Every rank's vector of floats on every rank: a world x K matrix (one small all-reduce; NaN stands for 'none')."""
+    row = np.asarray(row, dtype=np.float64)
+    m = np.zeros((comm.world, row.shape[0]), np.float64)
+    m[comm.rank] = np.where(np.isnan(row), -1e300, row)
+    m = np.asarray(comm.allreduce_sum(m), dtype=np.float64)
+    return np.where(m <= -1e299, np.nan, m)
+
+
+_GROUPS = ("migrants", "halo_a", "halo_b", "migrants_rest")
+_HOST = ("host_wait_us", "host_pre_us", "host_post_us", "host_step_us")
+
+
+def bench_diagnostics(sim, comm, phases_ms, host_t, probe_t, n_own):
+    """What makes an N-rank bench line self-diagnosing: EVERY rank's phase times, host-side step timing of the timed
+    window, event-timed message groups of the probe pass, the preflight pings and what RCCL says about its communicator
+    -- gathered with one small all-reduce, laid out per rank and summarised (mean over ranks, max over ranks)."""
+    nan = float("nan")
+    row = [float(n_own)] + [float(phases_ms.get(k, 0.0)) for k in capi.PHASES]
+    for k in _HOST:
+        row += [host_t[k]["mean"], host_t[k]["max"]]
+    row += [float(host_t["waits_ready"]), float(host_t["steps"])]
+    for g in _GROUPS:
+        e = probe_t["exchange_us_" + g]
+        row += [float(e["calls"]), nan if e["mean"] is None else e["mean"], e["max"]]
+    ping = sim.ping or {}
+    for g in _GROUPS[:3]:
+        e = ping.get(g)
+        row += [nan, nan, nan] if e is None else [float(e["bytes"]), e["mean_us"], e["max_us"]]
+    r = sim.rccl or {}
+    row += [float(r.get(k, -1)) for k in ("world_seen", "rank_seen", "device_seen", "async_error", "device")]
+    m = gather_rows(comm, row)
+    none = lambda v: None if np.isnan(v) else float(v)          # noqa: E731
+    ranks, col = [], 0
+    for q in range(comm.world):
+        v, col = m[q], 0
+        d = {"rank": q, "owned": int(v[0])}
+        col = 1
+        d["phases_ms"] = {k: float(v[col + i]) for i, k in enumerate(capi.PHASES)}; col += len(capi.PHASES)
+        for k in _HOST:
+            d[k] = {"mean": float(v[col]), "max": float(v[col + 1])}; col += 2
+        d["waits_ready"], d["steps_timed"] = int(v[col]), int(v[col + 1]); col += 2
+        d["exchange_us"] = {}
+        for g in _GROUPS:
+            d["exchange_us"][g] = {"calls": int(v[col]), "mean": none(v[col + 1]), "max": float(v[col + 2])}; col += 3
+        d["ping_us"] = {}
+        for g in _GROUPS[:3]:
+            if not np.isnan(v[col]):
+                d["ping_us"][g] = {"bytes": int(v[col]), "mean": float(v[col + 1]), "max": float(v[col + 2])}
+            col += 3
+        d["rccl"] = {k: int(v[col + i]) for i, k in enumerate(("world_seen", "rank_seen", "device_seen", "async_error", "device"))}
+        ranks.append(d)
+
+    def over_ranks(get):
+        vals = [get(d) for d in ranks]
+        vals = [x for x in vals if x is not None]
+        return {"mean": float(np.mean(vals)), "max": float(np.max(vals))} if vals else None
+
+    out = {"ranks": ranks}
+    # per message group: mean over ranks of the per-rank mean, and the worst single group seen on any rank
+    out["exchange_us"] = {g: {"mean": (over_ranks(lambda d, g=g: d["exchange_us"][g]["mean"]) or {}).get("mean"),
+                              "max": max(d["exchange_us"][g]["max"] for d in ranks),
+                              "calls_per_rank": ranks[0]["exchange_us"][g]["calls"]} for g in _GROUPS}
+    out["host_wait_us"] = {"mean": float(np.mean([d["host_wait_us"]["mean"] for d in ranks])),
+                           "max": float(max(d["host_wait_us"]["max"] for d in ranks)),
+                           "waits_ready_frac": float(sum(d["waits_ready"] for d in ranks)) / max(sum(d["steps_timed"] for d in ranks), 1)}
+    out["host_step_us"] = {k: {"mean": float(np.mean([d[k]["mean"] for d in ranks])), "max": float(max(d[k]["max"] for d in ranks))}
+                           for k in _HOST[1:]}
+    out["ping_us"] = {g: {"bytes": ranks[0]["ping_us"][g]["bytes"],
+                          "mean": float(np.mean([d["ping_us"][g]["mean"] for d in ranks if g in d["ping_us"]])),
+                          "max": float(max(d["ping_us"][g]["max"] for d in ranks if g in d["ping_us"]))}
+                      for g in _GROUPS[:3] if g in ranks[0]["ping_us"]}
+    out["rccl"] = ({"world_seen": [d["rccl"]["world_seen"] for d in ranks], "rank_seen": [d["rccl"]["rank_seen"] for d in ranks],
+                    "devices": [d["rccl"]["device_seen"] for d in ranks],
+                    "async_error": [d["rccl"]["async_error"] for d in ranks], "ping_us": out["ping_us"]}
+                   if sim.rccl is not None else None)
+    out["phases_ms_max_over_ranks"] = {k: float(max(d["phases_ms"][k] for d in ranks)) for k in capi.PHASES}
+    return out
+
+
 def bench_rank(comm, local, args, transport, log=None):
     """One rank of the multi-GPU bench (a process under torch.distributed.run, or a thread of the one-GPU rehearsal).
     Returns the JSON record on rank 0, None elsewhere."""
@@ -705,24 +864,32 @@ def bench_rank(comm, local, args, transport, log=None):
     sim.run(dt, args.warmup)
     sim.sync(); torch.cuda.synchronize(); comm.barrier()
     s0 = sim.engine.ctx.sort_stats()
+    sim.slab_timing_reset()                              # host-side step timing of the timed window (three clock reads a step)
     t0 = time.perf_counter()
     sim.run(dt, args.steps)
     sim.sync(); torch.cuda.synchronize(); comm.barrier()
     wall = comm.allreduce_max(time.perf_counter() - t0)
+    host_t = sim.slab_timing()
     s1 = sim.engine.ctx.sort_stats()
     n_own = sim.engine.n
     counts = comm.allreduce_sum(np.array([n_own, s1["movers_total"] - s0["movers_total"], s1["skips"] - s0["skips"],
                                           tail_movers], dtype=np.int64))
     n_max = comm.allreduce_max(n_own)
     # per-phase device times of this rank's kernels (HIP events on the library's stream), outside the timed region
+    # -- and event pairs around every message group on the comm stream (sph_slab_timing_enable): the probe pass pays the
+    #    events' dispatch cost, the timed window above does not
     ctx = sim.engine.ctx
     ctx.timing(True); ctx.timing_reset()
-    probe = max(2, min(args.steps, 5))
+    sim.slab_timing_reset(); sim.slab_timing_enable(True)
+    probe = max(2, min(args.steps, 20))
     sim.run(dt, probe)
     sim.sync(); comm.barrier()
     ph, _ = ctx.timing_get()
     ctx.timing(False)
+    probe_t = sim.slab_timing()
+    sim.slab_timing_enable(False)
     phases_ms = {k: v / probe for k, v in ph.items()}
+    diag = bench_diagnostics(sim, comm, phases_ms, host_t, probe_t, n_own)      # collective: every rank
     out = None
     if rank == 0:
         total = sim.total
@@ -762,6 +929,15 @@ def bench_rank(comm, local, args, transport, log=None):
                          "algorithmic_bytes_per_particle": 84, "avg_launch_ms": t_force * 1e3,
                          "particles_rank0": int(n_own)},
             "cpu_baseline": None,      # timed at N = 1 only (bench.py without --gpus)
+            # ---- where the time of an N-rank step goes (DESIGN.md section 6 names the row each field confirms or refutes) ----
+            "rccl": diag["rccl"],                       # None unless --transport rccl: {world_seen, devices, ping_us}
+            "ping_us": diag["ping_us"],                 # preflight: one exchange-shaped group at the step's three message sizes
+            "exchange_us": diag["exchange_us"],         # event pairs around each group, probe pass of `probe_steps` steps
+            "host_wait_us": diag["host_wait_us"],       # the step's one host wait, timed window
+            "host_step_us": diag["host_step_us"],       # host time in front of / behind the wait, whole call
+            "probe_steps": probe,
+            "phases_ms": diag["ranks"],                 # EVERY rank: phases, host timing, groups, pings
+            "phases_ms_max_over_ranks": diag["phases_ms_max_over_ranks"],
             "phases_ms_rank0": phases_ms, "slab_stats_rank0": sim.stats, "owned_sum": int(counts[0]),
             "owned_max": int(n_max), "imbalance": float(n_max) * world / max(total, 1),
             "movers_per_step": movers_win, "sort_skips": int(counts[2]), "flowing": flow_ok,

@@ -226,8 +226,13 @@ int sph_set_sort_mode(sph_ctx* c, int merge);
 /* The neighbour passes stage, per (dz, dy) row, the hull of a wave's candidate ranges through LDS.  A row whose hull
  * is longer than `slots` (default 512; usual hulls are ~80) is read straight from global memory by every lane instead
  * -- sparse particles next to a dense layer would otherwise stage thousands of slots for a handful of candidates each
- * and become the tail of the whole launch.  Both ways give the same bits.  0: every row direct; 0xFFFFFFFF: never
- * (for tests and A/B runs).  Takes effect at the next launch. */
+ * and become the tail of the whole launch.  In SPH_PRECISION_F32 both ways give the same bits (same candidates, same order,
+ * same arithmetic).  In SPH_PRECISION_MIXED_F16 they do NOT: the staged walk pairs fp16 candidates per 128-slot piece, the
+ * direct walk per row, so the fp16 row sums differ within the mixed tolerance -- and since the way a wave goes depends on
+ * its 63 wave-mates, mixed-mode results depend on this setting and on how a domain is cut into slabs.  The test in front
+ * of the exact one is a heuristic (key span of the wave <= 64 cells: taken as "no hull beyond `slots`", which cells of
+ * more than slots / 66 particles can break -- such a wave stages a long hull, slowly but correctly).
+ * 0: every row direct; 0xFFFFFFFF: never (for tests and A/B runs).  Takes effect at the next launch. */
 int sph_set_direct_hull(sph_ctx* c, uint32_t slots);
 /* The ORDER in which the neighbour passes' workgroups take the sorted slots (results do not depend on it).  xcd = 1
  * (default): each of the 8 XCDs walks one contiguous eighth of the slots; ztile = 1 (default): inside its eighth an XCD
@@ -276,7 +281,10 @@ int sph_layer_histogram(sph_ctx* c, uint32_t* hist, uint32_t n_layers);
  *   host_buffers = 1 (tests): the pointers are pinned HOST buffers the library staged, the call blocks until its
  *                    receives are complete (several slabs of one GPU in one process; processes over gloo).
  * Return 0 or a negative SPH_E* code. */
-enum { SPH_TAG_MIGRANTS = 1, SPH_TAG_HALO_A = 2, SPH_TAG_HALO_B = 3, SPH_TAG_MIGRANTS_REST = 4 };
+enum { SPH_TAG_MIGRANTS = 1, SPH_TAG_HALO_A = 2, SPH_TAG_HALO_B = 3, SPH_TAG_MIGRANTS_REST = 4, SPH_TAG_PING = 5 };
+/* ZERO-INITIALISE the struct before filling it in (`sph_transport t = {0};`): sph_slab_create copies it by value, and
+ * members added at its end (so far: `abort`, ABI v2 of round 4) must read as NULL in a caller built against an older
+ * header -- there is no size field, a garbage `abort` pointer would be called on the first failure. */
 typedef struct sph_transport {
     void* self;
     int (*exchange)(void* self, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
@@ -295,6 +303,10 @@ void sph_rccl_transport_destroy(sph_transport* t);
 /* two messages of `bytes` and `bytes`/2 bytes from this rank to ITSELF through the transport's communicator (one
  * ncclGroup), compared on the host: checks the dlopen binding of librccl with real traffic on a one-GPU box */
 int sph_rccl_transport_selftest(sph_transport* t, size_t bytes);
+/* What the communicator says about itself: {ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclCommGetAsyncError}
+ * (-1 where librccl lacks the call).  The multi-GPU bench prints them: a communicator of the wrong size, or one that sits on
+ * another device than the slab's context, explains a hang or a slow run before any step is taken. */
+int sph_rccl_transport_info(const sph_transport* t, int out[4]);
 
 /* Device-to-device transport between the slabs of ONE process that share a GPU (one thread per rank): the buffers are
  * device pointers, the copies are queued on the caller's comm stream behind the sender's event, nothing blocks on the
@@ -336,6 +348,33 @@ uint64_t sph_slab_in_place_merges(const sph_slab* s);
 /* transport calls so far: 3 in a usual step (migrants, halo A, halo B), 4 when a side has more leavers than ride in the
  * fixed-size migrant message */
 uint64_t sph_slab_exchanges(const sph_slab* s);
+/* Neighbour ping: `reps` timed rounds (+ one untimed round first) of ONE exchange-shaped group -- `bytes` to and from
+ * rank - 1 and rank + 1, through this slab's transport, comm stream and halo buffers -- every word checked on arrival for
+ * sender, direction and round.  out = {mean us per group, max us, wrong words}; event times on the comm stream, i.e. what a
+ * step's group of that size costs the device (waiting for the neighbour included).  bytes: a multiple of 4, at most the halo
+ * buffer ((ghost capacity + 1) * 32).  COLLECTIVE over the chain.  A neighbour that does not answer within the wait
+ * time-out, an RCCL error or a wrong word is an error (the slab is failed); there is no fall-back to another transport. */
+int sph_slab_ping(sph_slab* s, size_t bytes, uint32_t reps, double out[3]);
+/* Where a step's time goes.  Host side, always measured: the step's one wait (WAIT), the host time in front of it (PRE:
+ * hash, sort, bounds kernel and the migrant exchange being queued), behind it (POST: everything else being queued) and the
+ * whole call (HOST), each {sum us, max us} over the steps since the last reset; WAITS_READY counts the waits that found the
+ * header already there -- the host, not the device, paced those steps.  Device side, only between sph_slab_timing_enable(1)
+ * and (0): an event pair around every transport call on the comm stream, per message group {calls, sum us, max us} -- the
+ * time the group occupies the comm stream, the neighbour's lateness included.  (An event recorded on a stream costs the
+ * device ~5 us at its next dispatch: switch it on for a probe pass, not for a timed one.)  _get drains the comm stream. */
+enum {
+    SPH_SLAB_T_STEPS = 0, SPH_SLAB_T_WAITS_READY = 1,
+    SPH_SLAB_T_WAIT = 2,   /* [2] sum, [3] max */
+    SPH_SLAB_T_PRE = 4, SPH_SLAB_T_POST = 6, SPH_SLAB_T_HOST = 8,
+    SPH_SLAB_T_GROUPS = 10, /* + 3 * (tag - 1): {calls, sum us, max us} for SPH_TAG_MIGRANTS, _HALO_A, _HALO_B, _MIGRANTS_REST */
+    SPH_SLAB_T_WORDS = 22
+};
+int sph_slab_timing_enable(sph_slab* s, int on);
+int sph_slab_timing_reset(sph_slab* s);
+int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]);
+/* TEST HOOK: raise sticky device-side error word `flag` (0: an arrival outside its boundary layer, 1: an arrival outside
+ * the slab) as the insert / unpack kernels would; the next sph_slab_step then fails before it has sent anything. */
+int sph_slab_test_raise_flag(sph_slab* s, int flag);
 /* 0, or the first error of this slab: a slab that failed stays failed -- it has told its neighbours (they return
  * SPH_E_PEER at their next step), every later sph_slab_step returns the same error, and the state of its context is that
  * of a half-done step: download / destroy only */

@@ -235,3 +235,116 @@ def test_c5_particle_count_mixed_precision_on_one_gpu():
     for k in ("pos", "vel", "density"):
         assert np.array_equal(sa[k], sb[k]), k
     assert np.isfinite(sa["vel"]).all() and (sa["density"] > 0).all()
+
+
+def test_c4_corner_block_matches_oracle():
+    """BASELINE config 4 at its stated size against the oracle: the 28^3 lattice corner of the 67,108,864-particle dam (one
+    context, 1024^3 cells) after two steps against the oracle run on that block alone, at the full fp32 bar."""
+    cfg = ic.CONFIGS["C4"]
+    nx, ny, nz = cfg["lattice"]
+    n = nx * ny * nz
+    steps = 2
+    ii = np.arange(28, dtype=np.int64)
+    sub = (ii[None, None, :] + nx * (ii[None, :, None] + ny * ii[:, None, None])).ravel()     # ix, iy, iz < 28
+    with capi.Context(n, box=cfg["box"], grid=cfg["grid"]) as c:
+        c.reset_lattice(cfg["lattice"], jitter=True)
+        p0 = c.download(want=("pos",))["pos"][sub]
+        c.step(DT, steps)
+        st = c.download()
+    o = oracle.Oracle(p0, np.zeros_like(p0), cfg["box"], cfg["grid"], oracle.CELL_LINEAR)
+    o.step(DT, steps)
+    so = o.state()
+    o.close()
+    ix, iy, iz = sub % nx, (sub // nx) % ny, sub // (nx * ny)
+    inner = (ix < 22) & (iy < 22) & (iz < 22)                      # >= 2 cells inside the cut faces
+    g = sub[inner]
+    assert np.abs(st["pos"][g] - so["pos"][inner]).max() <= 1e-6 * cfg["box"][0]
+    assert np.abs(st["vel"][g] - so["vel"][inner]).max() <= 1e-5 * max(np.abs(so["vel"][inner]).max(), 1e-30)
+    assert np.abs(st["density"][g] / so["density"][inner] - 1).max() <= 1e-5
+    assert np.isfinite(st["pos"]).all() and np.isfinite(st["vel"]).all() and st["density"].min() > 0
+
+
+def _eight_slabs_against_one_context(name, mixed, steps, dt, kick_seed):
+    """`name`'s dam at its stated size, kicked with random velocities (particles cross cell faces and slab cuts on the way),
+    in EIGHT z-slab contexts on this one GPU -- eight threads, sph_slab_step over the device-to-device transport: the
+    product branch of the exchange, the stream / event edges of an 8-GPU run -- against ONE whole-domain context.
+    Every rank generates its lattice layers in HBM and downloads its particles into the SAME host arrays (rows by
+    creation index; sph_download writes the rows it owns)."""
+    import threading
+    from gpufluidsimulator_amd import slab
+    cfg = ic.CONFIGS[name]
+    nx, ny, nz = cfg["lattice"]
+    n = nx * ny * nz
+    world = 8
+    rng = np.random.default_rng(kick_seed)
+    kick = rng.uniform(-80.0, 80.0, (n, 3)).astype(np.float32)
+    got = {k: np.full((n, 3) if k in ("pos", "vel") else (n,), np.nan, np.float32) for k in ("pos", "vel", "density", "pressure")}
+    hub, dev_hub = slab.LocalComm.Hub(world), capi.LocalHub(world, timeout_s=120)
+    stats, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            comm = slab.LocalComm(hub, r)
+            comm.local_hub = dev_hub
+            sim = slab.NativeSlabSimulation(comm, cfg["box"], cfg["grid"], device_index=0, transport="local",
+                                            lattice=cfg["lattice"], jitter=True)
+            ctx = sim.engine.ctx
+            ctx.set_precision(mixed)
+            first = sim.engine.n                                     # a run of creation indices (device-made lattice layers)
+            idx = ctx.order()
+            lo, hi = int(idx.min()), int(idx.max()) + 1
+            assert hi - lo == first
+            ctx.set_by_index(lo, vel=kick[lo:hi])
+            sim.run(dt, steps)
+            sim.sync()
+            import ctypes as C
+            capi._check(ctx.L.sph_download(ctx.h, 0, n, got["pos"].ctypes.data, got["vel"].ctypes.data,
+                                           got["density"].ctypes.data, got["pressure"].ctypes.data))
+            stats[r] = dict(sim.stats, owned=sim.engine.n, cuts=list(sim.cuts), ping=sim.ping)
+            sim.close()
+        except BaseException as e:     # noqa: BLE001
+            errors.append(e)
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=1500)
+    dev_hub.close()
+    assert not errors, errors
+    with capi.Context(n, box=cfg["box"], grid=cfg["grid"]) as c:
+        c.set_precision(mixed)
+        c.reset_lattice(cfg["lattice"], jitter=True)
+        c.set_by_index(0, vel=kick)
+        c.step(dt, steps)
+        ref = c.download()
+        movers = c.sort_stats()["movers_total"]
+    return got, ref, stats, movers, n
+
+
+def test_c4_in_eight_slabs_on_one_gpu_bit_for_bit():
+    """BASELINE config 4 (67,108,864 particles, 1024^3 cells) THROUGH the slab decomposition at its stated size: eight slab
+    contexts of 8.4 M particles, twelve steps with particles changing cell and crossing the cuts, positions, velocities,
+    densities and pressures `array_equal` to the one-context run."""
+    got, ref, stats, movers, n = _eight_slabs_against_one_context("C4", False, 12, 2e-5, 41)
+    assert sum(s["owned"] for s in stats) == n and movers > 100000
+    assert sum(s["migrants"] for s in stats) > 1000, stats             # particles changed rank
+    assert all(s["host_waits"] == s["steps"] + s["far_steps"] for s in stats), stats
+    assert max(s["owned"] for s in stats) <= 1.05 * n / 8, [s["owned"] for s in stats]
+    for k in ("pos", "vel", "density", "pressure"):
+        assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
+
+
+def test_c5_mixed_precision_in_eight_slabs_on_one_gpu():
+    """BASELINE config 5 as stated -- 2^27 particles, fp32 state with packed-fp16 neighbour accumulators -- through the same
+    eight-slab path.  The integer work and everything fp32 is bit for bit the one-context run's; the fp16 row sums of the
+    density pass pair their candidates per staged piece, which depends on a wave's 63 other particles and so on the cuts
+    (include/sph_hip.h, sph_set_direct_hull): densities agree within the mixed tolerance of DESIGN.md section 4."""
+    got, ref, stats, movers, n = _eight_slabs_against_one_context("C5", True, 12, 2e-5, 43)
+    assert n == 134217728 and sum(s["owned"] for s in stats) == n and movers > 100000
+    assert sum(s["migrants"] for s in stats) > 1000, stats
+    rel = got["density"] / ref["density"] - 1
+    assert np.isfinite(rel).all() and np.abs(rel).max() <= 2e-2 and np.sqrt(np.mean(rel.astype(np.float64) ** 2)) <= 4e-3
+    assert np.abs(got["vel"] - ref["vel"]).max() <= 5e-3 * np.abs(ref["vel"]).max()
+    assert np.abs(got["pos"] - ref["pos"]).max() <= 2e-6 * 64.0
+    same = float(np.mean(got["density"].view(np.uint32) == ref["density"].view(np.uint32)))
+    print(f"C5 mixed, 8 slabs vs 1 context: {same:.6f} of the densities bit-identical, max rel {np.abs(rel).max():.2e}")

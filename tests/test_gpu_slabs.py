@@ -541,3 +541,185 @@ def test_long_flowing_run_in_four_slabs_bit_for_bit():
         movers = c.sort_stats()["movers_total"]
     assert movers > 100 * pos.shape[0] // 100, movers            # a flowing state: every particle changed cell on average
     _same_bits(st, ref)
+
+
+def _with_ranks(world, body, timeout_s=60, hub_timeout=60):
+    """`body(sim_factory, r)` on `world` threads sharing one GPU over the device-to-device transport."""
+    hub = slab.LocalComm.Hub(world)
+    dev_hub = capi.LocalHub(world, timeout_s=hub_timeout)
+    out, errors = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            out[r] = body(lambda **kw: slab.NativeSlabSimulation(_comm(hub, dev_hub, r), device_index=0, transport="local", **kw), r)
+        except BaseException as e:     # noqa: BLE001
+            errors[r] = e
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=timeout_s)
+    dev_hub.close()
+    return out, errors
+
+
+def test_neighbour_ping_checks_sender_direction_and_size():
+    """The preflight of a multi-rank run (sph_slab_ping, called by NativeSlabSimulation._bind before the first step): one
+    exchange-shaped group to rank - 1 and rank + 1 at the step's three message sizes through the slab's own transport,
+    comm stream and buffers; every word is checked for its sender, direction and round.  Here over the device-to-device
+    transport (RCCL refuses two ranks on one device); the RCCL transport takes the same code path on an N-GPU node.  The
+    step counters do not count the ping, a size beyond the halo buffer is SPH_E_INVALID, and a rank whose neighbour does
+    not take part gets an error that names the ping, not a hang."""
+    import ctypes as C
+    pos, vel, box, grid = make_case("up")
+
+    def body(make, r):
+        sim = make(box=box, grid=grid, particles=(pos, vel))
+        try:
+            L = capi.load()
+            ping = dict(sim.ping)
+            ex0 = int(L.sph_slab_exchanges(sim._slab))
+            res = (C.c_double * 3)()
+            capi._check(L.sph_slab_ping(sim._slab, 4096, 4, res))
+            bad = L.sph_slab_ping(sim._slab, (sim.ghost_capacity + 2) * 32, 1, res)
+            sim.run(DT, 2)
+            sim.sync()
+            return ping, ex0, tuple(res), bad, int(L.sph_slab_exchanges(sim._slab)), sim.message_sizes()
+        finally:
+            sim.close()
+
+    out, errors = _with_ranks(3, body)
+    assert errors == [None] * 3, errors
+    for r, (ping, ex0, res, bad, ex1, sizes) in enumerate(out):
+        assert set(ping) == {"migrants", "halo_a", "halo_b"} and ping["migrants"]["bytes"] == 8192
+        assert {k: v["bytes"] for k, v in ping.items()} == sizes
+        assert all(v["mean_us"] > 0.0 and v["max_us"] >= v["mean_us"] for v in ping.values()), ping
+        assert ex0 == 0 and ex1 == 6, (ex0, ex1)               # two steps, three groups each: the pings are not counted
+        assert res[0] > 0.0 and res[2] == 0.0
+        assert bad == -1                                       # SPH_E_INVALID
+
+    # a neighbour that never pings: bounded, and the error says what was being waited for
+    def lonely(make, r):
+        sim = make(box=box, grid=grid, particles=(pos, vel), ping_reps=0)
+        try:
+            capi._check(capi.load().sph_slab_set_wait_timeout(sim._slab, 2.0))
+            if r == 0:
+                res = (C.c_double * 3)()
+                capi._check(capi.load().sph_slab_ping(sim._slab, 4096, 1, res))
+        finally:
+            if r == 1:
+                gone.wait(timeout=30)
+            else:
+                gone.set()
+            sim.close()
+
+    gone = threading.Event()
+    out, errors = _with_ranks(2, lonely, hub_timeout=2.0)
+    assert errors[1] is None and isinstance(errors[0], capi.SphError), errors
+    assert "never sent" in str(errors[0]) or "ping" in str(errors[0]), errors
+
+
+def test_slab_timing_reports_every_message_group():
+    """sph_slab_timing_*: host-side step timing is always on; with timing enabled every transport call of a step is
+    bracketed by an event pair on the comm stream -- three groups per step (+ the rest message on a burst)."""
+    pos, vel, box, grid = make_case("up")
+    steps = 12
+
+    def body(make, r):
+        sim = make(box=box, grid=grid, particles=(pos, vel))
+        try:
+            sim.run(DT, 3)
+            sim.slab_timing_reset(); sim.slab_timing_enable(True)
+            sim.run(DT, steps); sim.sync()
+            t = sim.slab_timing()
+            sim.slab_timing_enable(False); sim.slab_timing_reset()
+            sim.run(DT, 2); sim.sync()
+            return t, sim.slab_timing(), dict(sim.stats)
+        finally:
+            sim.close()
+
+    out, errors = _with_ranks(3, body)
+    assert errors == [None] * 3, errors
+    for t, t_off, stats in out:
+        assert t["steps"] == steps and 0 <= t["waits_ready"] <= steps
+        for k in ("host_wait_us", "host_pre_us", "host_post_us", "host_step_us"):
+            assert 0.0 < t[k]["mean"] <= t[k]["max"], (k, t[k])
+        assert t["host_step_us"]["mean"] >= t["host_wait_us"]["mean"]
+        for g in ("migrants", "halo_a", "halo_b"):
+            e = t["exchange_us_" + g]
+            assert e["calls"] == steps and 0.0 < e["mean"] <= e["max"], (g, e)
+        assert t["exchange_us_migrants_rest"]["calls"] == 0
+        assert t_off["steps"] == 2 and all(t_off["exchange_us_" + g]["calls"] == 0 for g in ("migrants", "halo_a", "halo_b"))
+
+
+def test_a_failure_before_the_migrant_message_reaches_the_neighbours_in_the_same_step():
+    """a step that fails BEFORE it has posted its migrant message (a device-side flag of the previous step's
+    insert kernel, the sort, a launch) used to send nothing -- the neighbours then sat out the whole wait time-out.  Now the
+    abort header travels as that step's migrant message: the middle rank of three raises the sticky 'arrival outside its
+    boundary layer' flag by hand after 5 steps (sph_slab_test_raise_flag), fails at its next step with SPH_E_STATE, and BOTH
+    neighbours return SPH_E_PEER from that same step -- with 60 s time-outs everybody is done in seconds and every slab closes."""
+    import time
+    pos, vel, box, grid = make_case("up")
+    t0 = time.perf_counter()
+
+    def body(make, r):
+        sim = make(box=box, grid=grid, particles=(pos, vel))
+        done, err = 0, None
+        try:
+            for k in range(20):
+                if r == 1 and k == 5:
+                    capi._check(capi.load().sph_slab_test_raise_flag(sim._slab, 0))
+                sim.run(DT, 1)
+                done = k + 1
+        except capi.SphError as e:
+            err = e
+        finally:
+            failed = capi.load().sph_slab_failed(sim._slab)
+            sim.close()
+        return done, failed, str(err), time.perf_counter() - t0
+
+    out, errors = _with_ranks(3, body, timeout_s=200)
+    assert errors == [None] * 3, errors
+    assert [o[0] for o in out] == [5, 5, 5], out                      # the same step on every rank
+    assert out[1][1] == -5 and "boundary layer" in out[1][2], out     # SPH_E_STATE, the cause
+    assert out[0][1] == -6 and out[2][1] == -6, out                   # SPH_E_PEER on both neighbours
+    assert max(o[3] for o in out) < 30.0, out
+
+
+def test_a_failure_on_the_last_step_still_lets_every_slab_close():
+    """a rank that fails queues an "abort" migrant message for its neighbours' NEXT step.  When there is no next
+    step (the failure came on the last one) that message is never matched: closing the slab must give up after the wait
+    time-out (here 2 s; over RCCL the same bound ends in ncclCommAbort) instead of blocking in a stream synchronise."""
+    import time
+    pos, vel, box, grid = make_case("up")
+
+    def body(make, r):
+        sim = make(box=box, grid=grid, particles=(pos, vel), capacity_factor=1.0 if r == 2 else 1.5,
+                   capacity_slack=0 if r == 2 else 4096)
+        capi._check(capi.load().sph_slab_set_wait_timeout(sim._slab, 2.0))
+        done, err = 0, None
+        try:
+            for k in range(60):
+                gate.wait(timeout=60)                                 # in lockstep: nobody starts step k + 1 before everybody
+                if stop.is_set():                                     # is through step k -- or has failed in it
+                    break
+                sim.run(DT, 1)
+                done = k + 1
+        except capi.SphError as e:
+            err = e
+            stop.set()
+            gate.wait(timeout=60)                                     # release the others: they take no further step
+        t0 = time.perf_counter()
+        try:
+            sim.sync()
+        except capi.SphError:
+            pass
+        sim.close()
+        return done, str(err), time.perf_counter() - t0
+
+    stop, gate = threading.Event(), threading.Barrier(3)
+    out, errors = _with_ranks(3, body, timeout_s=200, hub_timeout=2.0)
+    assert errors == [None] * 3, errors
+    assert "exceed the capacity" in out[2][1], out
+    assert out[0][0] == out[1][0] == out[2][0] + 1, out               # the neighbours finished the step the top rank failed in
+    assert max(o[2] for o in out) < 20.0, out

@@ -72,6 +72,25 @@ def test_bench_strong_scaling_rehearsal_eight_ranks_on_one_gpu():
     assert out["slab_stats_rank0"]["host_waits"] == out["slab_stats_rank0"]["steps"]
     assert out["imbalance"] < 1.1
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    _check_diagnostics(out, 8)
+    assert out["rccl"] is None                                   # the device-to-device transport: no communicator to describe
+
+
+def _check_diagnostics(out, world):
+    """The fields that make an N-rank line self-diagnosing: every rank's phases, the preflight pings at
+    the step's three message sizes, event-timed message groups and the host wait."""
+    ranks = out["phases_ms"]
+    assert [r["rank"] for r in ranks] == list(range(world)) and sum(r["owned"] for r in ranks) == out["owned_sum"]
+    assert all(r["phases_ms"]["force"] > 0 and r["phases_ms"]["dens"] > 0 and r["phases_ms"]["sort"] > 0 for r in ranks)
+    assert out["ping_us"]["migrants"]["bytes"] == 8192 and out["ping_us"]["halo_a"]["bytes"] == 4 * out["ping_us"]["halo_b"]["bytes"]
+    for g in ("migrants", "halo_a", "halo_b"):
+        assert 0.0 < out["ping_us"][g]["mean"] <= out["ping_us"][g]["max"]
+        e = out["exchange_us"][g]
+        assert e["calls_per_rank"] == out["probe_steps"] and 0.0 < e["mean"] <= e["max"], (g, e)
+        assert all(r["exchange_us"][g]["calls"] == out["probe_steps"] for r in ranks)
+    assert 0.0 < out["host_wait_us"]["mean"] <= out["host_wait_us"]["max"] and 0.0 <= out["host_wait_us"]["waits_ready_frac"] <= 1.0
+    assert all(r["steps_timed"] == out["steps"] for r in ranks)
+    assert out["host_step_us"]["host_step_us"]["mean"] >= out["host_wait_us"]["mean"]
 
 
 def test_bench_strong_scaling_rehearsal_four_processes():
@@ -83,3 +102,4 @@ def test_bench_strong_scaling_rehearsal_four_processes():
     assert out["n_gpus"] == 4 and out["scaling"] == "strong"
     assert out["config"]["particles"] == 262144 == out["owned_sum"]
     assert min(out["config"]["layers_per_slab"]) >= 2 and out["config"]["ranks_as"] == "processes"
+    _check_diagnostics(out, 4)
