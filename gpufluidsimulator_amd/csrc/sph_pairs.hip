@@ -625,22 +625,41 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
             cw[i] = neighbour_terms(ph, rho, p);
         }
     };
-    if (wave_has_long_hull(H, my_key, tg.direct_hull)) {
+    // The packed arithmetic works on coordinates RELATIVE to the wave's reference point, and fp16 carries 11 bits: that is
+    // 2^-9 h while everything lies within ~4 h of the reference -- an ordinary wave: 64 sorted particles are ~8 cells of one
+    // x-row, 5 h -- and NOTHING when the wave's 64 particles are far apart: a wave that straddles the end of an x-row (its
+    // second half starts again at the other side of the fluid, tens of h away) or holds the few particles of a nearly empty
+    // cell layer.  Round 5 found densities 33 % off on such waves (config 5 cut into slabs against one context: the cuts
+    // change which particles share a wave).  A wave with a lane further than MIXED_SPAN h from the reference -- and a wave
+    // with a pathological hull, as in the fp32 kernel -- therefore takes the fp32 direct walk: every lane gathers ITS OWN
+    // candidates and sums (h^2 - r^2)^3 in fp32, exactly k_density's arithmetic and order (those particles get the fp32
+    // result, bit for bit).  They are few: one wave in sixteen where a 128-cell row holds 8 particles per cell.
+    constexpr float MIXED_SPAN = 8.0f;
+    const float far = fmaxf(fmaxf(fabsf(pi.x - rx), fabsf(pi.y - ry)), fabsf(pi.z - rz)) * inv_h;
+    if (__ballot(active && far > MIXED_SPAN) != 0ull || wave_has_long_hull(H, my_key, tg.direct_hull)) {
         const uint32_t me = active ? i : tgt_hi - 1u;        // (= ii, derived again: nothing of this branch stays alive in the staged walk)
-        direct_rows(cells, g, keyS[me], active, [&](uint32_t l0, uint32_t len, uint32_t) {        // every lane gathers its own candidates, two at a time
-            const uint32_t T = wave_max_u32((len + 1u) >> 1);
-            h2 row = zero;
-            for (uint32_t k = 0; k < T; k++) {
-                const bool v0 = 2u * k < len, v1 = 2u * k + 1u < len;
-                const float4 a = posi[v0 ? l0 + 2u * k : me], b = posi[v1 ? l0 + 2u * k + 1u : me];
-                const h2 x = h2{(_Float16)((a.x - rx) * inv_h), (_Float16)((b.x - rx) * inv_h)};
-                const h2 y = h2{(_Float16)((a.y - ry) * inv_h), (_Float16)((b.y - ry) * inv_h)};
-                const h2 z = h2{(_Float16)((a.z - rz) * inv_h), (_Float16)((b.z - rz) * inv_h)};
-                pair_math(row, x, y, z, h2_mask(v0, v1), true);
+        const float h2_v = in_vgpr(ph.h2);
+        float acc32 = 0.f;
+        direct_rows(cells, g, keyS[me], active, [&](uint32_t l0, uint32_t len, uint32_t T) {      // a lane out of range reads itself (masked)
+            for (uint32_t t = 0; t < T; t += 2u) {
+                float4 q[2];
+#pragma unroll
+                for (uint32_t u = 0; u < 2u; u++) q[u] = posi[t + u < len ? l0 + t + u : me];
+#pragma unroll
+                for (uint32_t u = 0; u < 2u; u++) {
+                    const float dx = pi.x - q[u].x, dy = pi.y - q[u].y, dz = pi.z - q[u].z;
+                    float d = fmaxf(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, h2_v))), 0.f);
+                    d = t + u < len ? d : 0.f;
+                    acc32 = fmaf(d * d, d, acc32);
+                }
             }
-            acc += (float)row.x + (float)row.y;
         });
-        finish();
+        if (active) {
+            const float rho = acc32 * ph.poly6_mass;
+            const float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
+            dp[i] = make_float2(rho, p);
+            cw[i] = neighbour_terms(ph, rho, p);
+        }
         return;
     }
     traverse(

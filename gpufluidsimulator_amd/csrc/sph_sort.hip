@@ -1425,4 +1425,27 @@ int launch_merge_arrivals(sph_ctx* c, uint32_t n_in, uint32_t n_front) {
 // seam to move the caller's AoS structs the way thrust::sort would (it sets keep_perm)
 const uint32_t* last_sort_permutation(sph_ctx* c) { return c->last_perm; }
 
+// Stable LSD radix sort of the indices 0 .. n-1 by `keys_dev[i]` (`bits` significant bits), with the context's radix
+// scratch: *perm_out[a] = the index with the a-th smallest key.  The pointer is into the scratch: valid until the next
+// sph_hash / sph_sort; the keys the hash left in k0 (and the permutation of the last particle sort) are overwritten.
+// Used by the compat seam to number its caller's array the reference's way (Morton) on top of the native order.
+int sort_indices_by_key(sph_ctx* c, const uint32_t* keys_dev, uint32_t n, uint32_t bits, const uint32_t** perm_out) {
+    *perm_out = nullptr;
+    if (n == 0) return SPH_OK;
+    const uint32_t nblocks = ceil_div(n, SORT_TILE);
+    SPH_REQUIRE(nblocks <= c->sort_blocks_cap && n <= c->cap, SPH_E_CAPACITY, "sort: %u keys > capacity %u", n, c->cap);
+    SPH_HIP(hipMemcpyAsync(c->k0, keys_dev, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    uint32_t* kin = c->k0; uint32_t* vin = c->v0;
+    uint32_t* kout = c->k1; uint32_t* vout = c->v1;
+    const uint32_t saved = c->key_bits;
+    c->key_bits = bits;
+    const int rc = radix_sort_pairs(c, n, nullptr, nblocks, true, kin, vin, kout, vout);
+    c->key_bits = saved;
+    if (rc) return rc;
+    c->keys_fresh = false;
+    c->last_perm = nullptr;
+    *perm_out = vin;
+    return SPH_OK;
+}
+
 }  // namespace sph

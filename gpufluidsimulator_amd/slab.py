@@ -923,7 +923,7 @@ def bench_rank(comm, local, args, transport, log=None):
             "value_sustained": total * tail / tail_wall if tail_wall > 0 else None,
             "ms_per_step_sustained": tail_wall / max(tail, 1) * 1e3 if tail_wall > 0 else None,
             # rank 0's fused force pass (its interior + boundary launches of one step), algorithmic bytes as at N = 1
-            "roofline": {"bound": "hbm", "kernel": "k_force<force+collision+integrate> (rank 0, launches of one step)",
+            "roofline": {"bound": "valu-issue", "kernel": "k_force<force+collision+integrate> (rank 0, launches of one step)",
                          "achieved": 84.0 * n_own / t_force / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": 84.0 * n_own / t_force / 1e9 / 8000.0, "traffic": None, "traffic_source": None,
                          "algorithmic_bytes_per_particle": 84, "avg_launch_ms": t_force * 1e3,

@@ -10,8 +10,14 @@
  * call runs the corresponding sph_* phase on the context's sorted SoA state and then writes the
  * fields the reference kernel would have written back into the caller's 88-byte AoS array, so the
  * array always looks the way the reference would have left it (sorted by cell, fields updated).
- * dev_B / dev_B_prime are accepted and left untouched: only this library would read them, and it
- * keeps its own cell table (the reference numbers cells in Morton order, this library row-major).
+ * Every integer a caller can see is the reference's: Particle::zindex is the Morton code
+ * coord2zIndex(cell) (particleSystem.cu:68-91), cudaSortParticles leaves the array sorted by it,
+ * cudaConstructBGrid fills dev_B[zindex] = {nParticles, start} and cudaConstructGridArray fills
+ * dev_B_prime with one {nParticles <= 32, start} entry per chunk and hands its size back
+ * (particleSystem.cu:311-373, 503-528) -- array for array what the reference's own code leaves there
+ * (tests/test_gpu_dropin.py).  The native context underneath keeps its row-major cell key and its own
+ * cell table; the seam holds the permutation between the two orders.  Only the order of the particles
+ * INSIDE one cell is this library's (stable); the reference's is what thrust::sort leaves, unspecified.
  * The AoS round trips make this path slower than the native one; it exists for drop-in
  * verification.  GL interop is headless: the "VBO" handed to cudaIntegrate is a device buffer.
  */
@@ -86,6 +92,8 @@ void cudaIntegrate(float* gl_pos, float deltaTime, sph_compat_particle* p, unsig
 /* additive: the native context behind a particle array (NULL before the first cudaMapZIndex) */
 struct sph_ctx;
 struct sph_ctx* sph_compat_context(const void* dev_particles);
+/* additive: drop that context without freeing the array (freeArray does both) -- for arrays another allocator owns */
+void sph_compat_release(const void* dev_particles);
 /* the headless "VBO": device float4 per creation index behind a mapped resource */
 void* sph_compat_vbo_dev(struct cudaGraphicsResource* res, size_t* bytes);
 

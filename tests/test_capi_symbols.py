@@ -39,7 +39,7 @@ def test_reference_seam_symbols_are_exported():
             "cudaConstructBGrid", "cudaConstructGridArray", "cudaIntegrate"]
     src = open(os.path.join(ROOT, "include", "sph_compat_seam.h")).read()
     ref = open("/root/reference/SPH/particleSystem.cuh").read() if os.path.exists("/root/reference/SPH/particleSystem.cuh") else None
-    for n in seam + ["sph_compat_context", "sph_compat_vbo_dev", "sph_ic_dam_break", "sph_ic_random_box"]:
+    for n in seam + ["sph_compat_context", "sph_compat_release", "sph_compat_vbo_dev", "sph_ic_dam_break", "sph_ic_random_box"]:
         assert hasattr(lib, n), f"{n} not exported"
         if n in seam:
             assert re.search(r"\b%s\s*\(" % n, src), f"{n} not declared in sph_compat_seam.h"

@@ -45,48 +45,86 @@ def test_reference_update_random_clump():
     assert ep.max() <= 1e-5 * 2.0 and (ep > 1e-6 * 2.0).mean() <= 1e-3
 
 
-def _morton_decode(z):
-    """zIndex2coord of the reference (particleSystem.cu:105-124): every third bit."""
-    z = np.asarray(z, dtype=np.uint64)
-    out = []
-    for a in range(3):
-        v = np.zeros_like(z)
-        for b in range(10):
-            v |= ((z >> np.uint64(3 * b + a)) & np.uint64(1)) << np.uint64(b)
-        out.append(v.astype(np.int64))
-    return out
-
-
 @pytest.mark.parametrize("name", ["c1_jitter", "random_clump"])
 def test_seam_fills_B_and_Bprime_like_the_reference(name):
-    """cudaConstructBGrid / cudaConstructGridArray leave {nParticles, start} per occupied cell in the caller's B and
-    one {nParticles <= 32, start} entry per 32-particle chunk in B', with the size handed back to the host
-    (particleSystem.cu:503-528).  Cells carry this library's row-major number (as does Particle::zindex), so B is
-    compared cell by cell through the cell coordinates; B' must chunk the sorted array exactly like the
-    reference's (same number of entries, same chunk sizes per cell)."""
+    """Bit-exact index work behind the reference's own interface.  The reference's host class runs two of its update()s on
+    the HIP seam; what the seam left in the caller's arrays is compared `array_equal` -- no mapping between numberings --
+    with what the reference's own code (its CPU path, tests/golden) leaves there:
+      * Particle::zindex = coord2zIndex(cell), the reference's Morton code (particleSystem.cu:68-91, :307);
+      * the particle array sorted by it (cudaSortParticles, :497-501);
+      * dev_B[zindex] = {nParticles, start} for every occupied cell, zero elsewhere (:311-329, :503-509);
+      * dev_B_prime = one {start, nParticles <= 32} entry per 32-particle chunk, and its size (:331-373, :511-528).
+    (Only the order of the particles INSIDE a cell is unspecified in the reference -- std::sort / thrust::sort -- and is
+    not compared.)"""
     g = load_golden(name)
     grid = int(g["grid"][0])
-    recs, _ = refio.run_ref(g["pos"], g["vel"], g["box"], grid, float(g["dt"]), 1, phases=True, binary=refio.DROPIN_BIN)
-    cells, bprime = recs[("bcells", 1)], recs[("bprime", 1)]
-    sorted_z, order = recs[("sorted_z", 1)], recs[("order", 1)]
-    ref_cells, ref_bprime = g["s1_bcells"], g["s1_bprime"]
-    n = order.shape[0]
-    # the particle array is sorted by the key it carries, and B describes exactly its runs
-    assert np.all(np.diff(sorted_z.astype(np.int64)) >= 0)
-    key, cnt, start = cells[:, 0].astype(np.int64), cells[:, 1].astype(np.int64), cells[:, 2].astype(np.int64)
-    assert cnt.sum() == n
-    for k, c, s in zip(key[:2000], cnt[:2000], start[:2000]):
-        assert np.all(sorted_z[s:s + c] == k) and (s == 0 or sorted_z[s - 1] != k) and (s + c == n or sorted_z[s + c] != k)
-    # same occupied cells with the same counts as the reference's B (Morton-numbered there)
-    x, y, z = key % grid, (key // grid) % grid, key // (grid * grid)
-    rx, ry, rz = _morton_decode(ref_cells[:, 0])
-    mine = dict(zip(zip(x.tolist(), y.tolist(), z.tolist()), cnt.tolist()))
-    theirs = dict(zip(zip(rx.tolist(), ry.tolist(), rz.tolist()), ref_cells[:, 1].astype(np.int64).tolist()))
-    assert mine == theirs
-    # B': one entry per chunk of <= 32, tiling the sorted array in order; same multiset of chunk sizes per cell
-    assert bprime.shape[0] == ref_bprime.shape[0]
-    bs, bn = bprime[:, 0].astype(np.int64), bprime[:, 1].astype(np.int64)
-    assert bs[0] == 0 and np.all(bs[1:] == bs[:-1] + bn[:-1]) and bs[-1] + bn[-1] == n and bn.max() <= 32 and bn.min() >= 1
-    assert sorted(bn.tolist()) == sorted(ref_bprime[:, 1].astype(np.int64).tolist())
-    for s, c in zip(bs[:2000], bn[:2000]):
-        assert np.all(sorted_z[s:s + c] == sorted_z[s])
+    recs, _ = refio.run_ref(g["pos"], g["vel"], g["box"], grid, float(g["dt"]), 2, phases=True, binary=refio.DROPIN_BIN)
+    n = g["pos"].shape[0]
+    for step in (1, 2):
+        sorted_z, order = recs[("sorted_z", step)], recs[("order", step)]
+        assert np.array_equal(sorted_z, g[f"s{step}_sorted_z"]), step
+        assert np.array_equal(np.sort(order), np.arange(n, dtype=order.dtype))
+        zindex = np.empty(n, np.uint32)
+        zindex[order] = sorted_z                                   # by creation index
+        ref_z = np.empty(n, np.uint32)
+        ref_z[g[f"s{step}_order"]] = g[f"s{step}_sorted_z"]
+        assert np.array_equal(zindex, ref_z), step
+        if step == 1:                                              # the initial array is in creation order
+            assert np.array_equal(zindex, g["s1_zindex"])
+        assert np.array_equal(recs[("bcells", step)], g[f"s{step}_bcells"]), step      # {zindex, nParticles, start}
+        assert np.array_equal(recs[("bprime", step)], g[f"s{step}_bprime"]), step      # {start, nParticles}
+
+
+def test_morton_golden_through_the_seam():
+    """cudaMapZIndex / cudaSortParticles / cudaConstructBGrid called directly (ctypes, device arrays from torch) on the
+    `morton_c1` fixture: the z-indices the reference computed for these positions, the sorted order and a B table that
+    describes exactly the runs of equal z-index."""
+    import ctypes as C
+    import torch
+    from gpufluidsimulator_amd import capi
+    g = load_golden("morton_c1")
+    pos, want = g["pos"], g["zindex"]
+    n, grid, box = pos.shape[0], int(g["grid"][0]), [float(b) for b in g["box"]]
+    L = capi.load()
+    aos = np.zeros((n, 22), np.uint32)
+    aos[:, 0] = np.arange(n)
+    aos[:, 1:4] = pos.view(np.uint32)
+    aos[:, 16] = np.float32(65.0).view(np.uint32)
+    aos[:, 19] = np.float32(1.0 / 64.0).view(np.uint32)
+    prm = np.zeros(18, np.float32)
+    prm[7] = 1.0 / 64.0
+    prm[8:11] = [-b / 2 for b in box]; prm[11:14] = [b / 2 for b in box]; prm[14:17] = box
+    prm.view(np.uint32)[17] = grid
+    dev = torch.device("cuda", 0)
+    d_aos = torch.from_numpy(aos.view(np.int32)).to(dev)
+    d_prm = torch.from_numpy(prm).to(dev)
+    b_size = grid ** 3
+    d_B = torch.full((b_size, 2), -1, dtype=torch.int32, device=dev)
+    vp = C.c_void_p
+    L.cudaMapZIndex.argtypes = [vp, C.c_uint, vp]; L.cudaMapZIndex.restype = None
+    L.cudaSortParticles.argtypes = [vp, C.c_uint]; L.cudaSortParticles.restype = None
+    L.cudaConstructBGrid.argtypes = [vp, C.c_uint, vp, C.c_uint, vp]; L.cudaConstructBGrid.restype = None
+    L.freeArray.argtypes = [vp]; L.threadSync.restype = None
+    L.cudaMapZIndex(d_aos.data_ptr(), n, d_prm.data_ptr())
+    L.threadSync()
+    got = d_aos.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[:, 21], want)                        # by array slot, before the sort
+    assert np.array_equal(got[:, 0], np.arange(n))
+    L.cudaSortParticles(d_aos.data_ptr(), n)
+    L.cudaConstructBGrid(d_aos.data_ptr(), n, d_B.data_ptr(), b_size, d_prm.data_ptr())
+    L.threadSync()
+    srt = d_aos.cpu().numpy().view(np.uint32)
+    B = d_B.cpu().numpy().view(np.uint32)
+    assert np.array_equal(srt[:, 21], np.sort(want, kind="stable"))
+    assert np.array_equal(srt[:, 21], want[srt[:, 0]])             # every struct moved whole
+    assert np.array_equal(srt[:, 1:4].view(np.float32), pos[srt[:, 0]])
+    z, start, cnt = np.unique(srt[:, 21], return_index=True, return_counts=True)
+    ref_B = np.zeros((b_size, 2), np.uint32)
+    ref_B[z, 0], ref_B[z, 1] = cnt, start
+    assert np.array_equal(B, ref_B)
+    # torch owns the array here, so the context behind it is dropped on its own (freeArray would free the array too)
+    L.sph_compat_context.argtypes = [vp]; L.sph_compat_context.restype = vp
+    L.sph_compat_release.argtypes = [vp]; L.sph_compat_release.restype = None
+    assert L.sph_compat_context(d_aos.data_ptr())
+    L.sph_compat_release(d_aos.data_ptr())
+    assert not L.sph_compat_context(d_aos.data_ptr())
