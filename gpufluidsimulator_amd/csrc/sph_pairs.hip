@@ -435,15 +435,34 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
 #else
 #define DSK(j) (j)
 #endif
+    // SPH_DENS_ZZ (round 5): the z coordinates of TWO neighbouring candidates come out of ONE ds_read_b64.  The LDS pipe
+    // charges an instruction by its bytes with 8 as the minimum -- a ds_read_b32 costs what a ds_read_b64 costs, 1.1 ns per
+    // wave-instruction and CU (profiles/r02_lds_read_rates.txt) -- so {x, y} as a b64 plus z as a b32 paid for 16 bytes per
+    // candidate and used 12.  Now a group of four candidates is four b64 {x, y} + two b64 {z, z}: 6 reads instead of 8, on
+    // the pipe that is 87 % busy in this kernel.  A lane's range may start at an odd entry: the z array is kept twice,
+    // s_z[j] = z_j and s_zo[j] = z_(j+1), and a lane reads pairs from the copy in which ITS first candidate sits at an
+    // even index (two more ds_write_b32 per staged piece and lane).  Same candidates, same order, same arithmetic: the
+    // sums keep their bits.
+#ifndef SPH_DENS_ZZ
+#define SPH_DENS_ZZ (!SPH_DENS_SKEW && (SPH_DENS_UNROLL % 2 == 0))
+#endif
     constexpr int DENS_LDS = (DENS_WAVES + 1) * PIECE + 8;          // as LDS_ENT, for this kernel's block
     constexpr int DENS_ENT = SPH_DENS_SKEW ? DENS_LDS + DENS_LDS / 32 + 2 : DENS_LDS;
     __shared__ float2 s_xy[DENS_ENT];
-    __shared__ float s_z[DENS_ENT];
+    __shared__ __attribute__((aligned(8))) float s_z[DENS_ENT];
+#if SPH_DENS_ZZ
+    __shared__ __attribute__((aligned(8))) float s_zo_[DENS_ENT + 2];
+    float* const s_zo = s_zo_ + 2;                                   // s_zo[-1] exists (the entry in front of the first slice)
+#endif
     // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
     if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)DENS_THREADS >= tg.dev[1]) return;
     for (uint32_t k = threadIdx.x; k < DENS_ENT; k += DENS_THREADS) {   // see LDS_ENT: keep over-reads finite
         s_xy[k] = make_float2(0.f, 0.f);
         s_z[k] = 0.f;
+#if SPH_DENS_ZZ
+        s_zo_[k] = 0.f;
+        if (k < 2u) s_zo_[DENS_ENT + k] = 0.f;
+#endif
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -502,13 +521,39 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
             s_z[DSK(slice + lane)] = q0.z;
             s_xy[DSK(slice + WAVE + lane)] = make_float2(q1.x, q1.y);
             s_z[DSK(slice + WAVE + lane)] = q1.z;
+#if SPH_DENS_ZZ
+            // the shifted copy; entry slice - 1 belongs to the slice in front (or to the pad): only a lane's masked
+            // over-read ever looks at a slice's last shifted entry, and whatever stands there is a finite z
+            s_zo[(int)(slice + lane) - 1] = q0.z;
+            s_zo[slice + WAVE + lane - 1u] = q1.z;
+#endif
         },
         [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
             const uint32_t len = l1 > l0 ? l1 - l0 : 0u;
-            uint32_t idx = slice + (len ? l0 - a : 0u);
+            const uint32_t rel = len ? l0 - a : 0u;
+            uint32_t idx = slice + rel;
             // every lane has at least tmin candidates: that part of the walk needs no per-lane range test
             const uint32_t tmin = wave_min_u32_uniform_first(len) & ~(uint32_t)(UNROLL - 1);
+#if SPH_DENS_ZZ
+            // z pairs: candidates (rel, rel + 1), (rel + 2, rel + 3), ... -- from s_z when rel is even, else from the copy
+            // shifted by one, where candidate rel sits at the even index rel - 1
+            lds_v2f_ptr zp = (lds_v2f_ptr)((rel & 1u) ? (const float*)s_zo : (const float*)s_z) + ((slice + rel) >> 1);
+            auto group = [&](uint32_t t, bool check) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; u += 2) {
+                    const v2f xy0 = ((lds_v2f_ptr)s_xy)[idx + u], xy1 = ((lds_v2f_ptr)s_xy)[idx + u + 1];
+                    const v2f zz = zp[u >> 1];
+                    pair_math(xy0.x, xy0.y, zz.x, !check || t + u < len);
+                    pair_math(xy1.x, xy1.y, zz.y, !check || t + u + 1 < len);
+                }
+                idx += UNROLL;
+                zp += UNROLL / 2;
+            };
+            uint32_t t = 0;
+            for (; t < tmin; t += UNROLL) group(t, false);
+            for (; __ballot(t < len) != 0ull; t += UNROLL) group(t, true);    // until every lane is through its range
+#else
             auto pair = [&](int u, bool valid) {
                 const v2f xy = ((lds_v2f_ptr)s_xy)[DSK(idx + u)];
                 const float z = ((lds_f32_ptr)s_z)[DSK(idx + u)];
@@ -525,6 +570,7 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
                 for (int u = 0; u < UNROLL; u++) pair(u, t + u < len);
                 idx += UNROLL;
             }
+#endif
         });
     finish();
 }

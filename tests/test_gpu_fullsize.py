@@ -334,17 +334,37 @@ def test_c4_in_eight_slabs_on_one_gpu_bit_for_bit():
         assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
 
 
+def test_c5_size_in_eight_slabs_on_one_gpu_bit_for_bit():
+    """Config 5's 2^27 = 134,217,728 particles (1024^3 cells) through the eight-slab path in fp32: `array_equal` to the
+    one-context run, as for config 4."""
+    got, ref, stats, movers, n = _eight_slabs_against_one_context("C5", False, 12, 2e-5, 43)
+    assert n == 134217728 and sum(s["owned"] for s in stats) == n and movers > 100000
+    assert sum(s["migrants"] for s in stats) > 1000, stats
+    for k in ("pos", "vel", "density", "pressure"):
+        assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
+
+
 def test_c5_mixed_precision_in_eight_slabs_on_one_gpu():
     """BASELINE config 5 as stated -- 2^27 particles, fp32 state with packed-fp16 neighbour accumulators -- through the same
-    eight-slab path.  The integer work and everything fp32 is bit for bit the one-context run's; the fp16 row sums of the
-    density pass pair their candidates per staged piece, which depends on a wave's 63 other particles and so on the cuts
-    (include/sph_hip.h, sph_set_direct_hull): densities agree within the mixed tolerance of DESIGN.md section 4."""
+    eight-slab path.  Mixed mode is NOT invariant under the cuts: the fp16 row sums of the density pass pair their
+    candidates per staged piece, and which particles share a wave (hence the pieces, the wave's reference point, and
+    whether it takes the fp32 walk) depends on where a slab begins (include/sph_hip.h, sph_set_direct_hull).  So the bar is
+    the mixed tolerance of DESIGN.md section 4 between the two runs: EVERY density within 2 % (0.4 % rms) after twelve
+    steps of a kicked lattice at 40x the reference's dt -- and since pressure switches on at rho0 and collision counts
+    are integers, a 1 % density difference can flip either for a particle: velocities and positions agree for all but a
+    stated fraction of the particles (1e-3) and in the rms."""
     got, ref, stats, movers, n = _eight_slabs_against_one_context("C5", True, 12, 2e-5, 43)
     assert n == 134217728 and sum(s["owned"] for s in stats) == n and movers > 100000
     assert sum(s["migrants"] for s in stats) > 1000, stats
     rel = got["density"] / ref["density"] - 1
     assert np.isfinite(rel).all() and np.abs(rel).max() <= 2e-2 and np.sqrt(np.mean(rel.astype(np.float64) ** 2)) <= 4e-3
-    assert np.abs(got["vel"] - ref["vel"]).max() <= 5e-3 * np.abs(ref["vel"]).max()
-    assert np.abs(got["pos"] - ref["pos"]).max() <= 2e-6 * 64.0
+    vmax = float(np.abs(ref["vel"]).max())
+    dv = np.abs(got["vel"] - ref["vel"]).max(axis=1)
+    dx = np.abs(got["pos"] - ref["pos"]).max(axis=1)
+    frac_v, frac_x = float((dv > 5e-3 * vmax).mean()), float((dx > 2e-6 * 64.0).mean())
+    rms_v = float(np.sqrt(np.mean(dv.astype(np.float64) ** 2))) / vmax
     same = float(np.mean(got["density"].view(np.uint32) == ref["density"].view(np.uint32)))
-    print(f"C5 mixed, 8 slabs vs 1 context: {same:.6f} of the densities bit-identical, max rel {np.abs(rel).max():.2e}")
+    print(f"C5 mixed, 8 slabs vs 1 context: {same:.6f} of the densities bit-identical, max rel {np.abs(rel).max():.2e}; "
+          f"velocity beyond 5e-3 vmax: {frac_v:.2e} of the particles (max {dv.max() / vmax:.2e} vmax, rms {rms_v:.2e} vmax); "
+          f"position beyond 2e-6 box: {frac_x:.2e}")
+    assert frac_v <= 1e-3 and frac_x <= 1e-3 and rms_v <= 1e-3, (frac_v, frac_x, rms_v)
