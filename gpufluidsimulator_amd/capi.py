@@ -117,6 +117,8 @@ SIGNATURES = {
     "sph_rccl_transport_selftest": (C.c_int, [C.POINTER(Transport), C.c_size_t]),
     "sph_rccl_transport_info": (C.c_int, [C.POINTER(Transport), C.POINTER(C.c_int)]),
     "sph_slab_ping": (C.c_int, [_P, C.c_size_t, _U32, C.POINTER(C.c_double)]),
+    "sph_slab_recut": (C.c_int, [_P, _U32, _U32]),
+    "sph_slab_recut_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "sph_slab_timing_enable": (C.c_int, [_P, C.c_int]),
     "sph_slab_timing_reset": (C.c_int, [_P]),
     "sph_slab_timing_get": (C.c_int, [_P, C.POINTER(C.c_double)]),

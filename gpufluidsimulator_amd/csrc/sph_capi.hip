@@ -164,7 +164,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     if (!rc) rc = dev_alloc(&c->pos_out, (size_t)c->pos_out_cap);
     // one guard entry on either side: the pair kernels read cells[key - 1 .. key + 1] of a row unconditionally
     if (!rc) rc = dev_alloc(&c->cells_base, (size_t)c->grid.ncells + 2);
-    if (!rc) c->cells = c->cells_base + 1;
+    if (!rc) { c->cells = c->cells_base + 1; c->cells_alloc = c->grid.ncells; }
     if (!rc) rc = dev_alloc(&c->k0, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->v0, (size_t)capacity);
     if (!rc) rc = dev_alloc(&c->k1, (size_t)capacity);
@@ -337,6 +337,40 @@ static int do_density(sph_ctx* c) {
     return SPH_OK;
 }
 
+}  // namespace sph
+
+namespace sph {
+// A slab context takes over the cell layers [z_lo, z_hi) (sph_slab_recut): local keys, the ghost layers and the width of
+// the sort keys follow; the cell table -- which the caller has CLEARED (no entry of the old numbering may survive) -- is
+// kept when it is large enough, else replaced.  The particles keep their slots; the next sph_hash re-keys them.
+int set_slab_range(sph_ctx* c, uint32_t z_lo, uint32_t z_hi) {
+    SPH_REQUIRE(c && c->slab, SPH_E_INVALID, "set_slab_range needs a slab context");
+    sph_ctx tmp;
+    tmp.params = c->params;
+    int rc = derive(&tmp, &c->params, z_lo, z_hi, true);
+    if (rc) return rc;
+    if (tmp.grid.ncells > c->cells_alloc) {
+        SPH_HIP(hipStreamSynchronize(c->stream));
+        uint2* base = nullptr;
+        rc = dev_alloc(&base, (size_t)tmp.grid.ncells + 2);
+        if (rc) return rc;
+        if (hipMemset(base, 0, ((size_t)tmp.grid.ncells + 2) * sizeof(uint2)) != hipSuccess) {
+            hipFree(base);
+            set_error("set_slab_range: clearing the new cell table failed");
+            return SPH_E_DEVICE;
+        }
+        hipFree(c->cells_base);
+        c->cells_base = base; c->cells = base + 1; c->cells_alloc = tmp.grid.ncells;
+    }
+    c->grid = tmp.grid; c->z_lo = z_lo; c->z_hi = z_hi; c->key_bits = tmp.key_bits;
+    c->cells_valid = false; c->cells_clear_deferred = false;
+    c->keys_fresh = false; c->order_valid = false;
+    c->stage = sph_ctx::ST_LOADED;
+    c->have_dens = c->have_force = c->have_coll = false;
+    c->n_glo = c->n_ghi = 0;
+    c->halo_n_valid = false;
+    return SPH_OK;
+}
 }  // namespace sph
 
 using namespace sph;

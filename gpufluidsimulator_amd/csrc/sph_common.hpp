@@ -100,6 +100,7 @@ struct sph_ctx {
     // cell table: {start, end} per local cell, zero = empty
     uint2* cells = nullptr;        // = cells_base + 1
     uint2* cells_base = nullptr;   // the allocation: ncells + one zero guard entry on either side
+    uint32_t cells_alloc = 0;      // cells the allocation holds (a slab whose layer range grows gets a bigger table: set_slab_range)
     uint32_t cells_lo = 0, cells_hi = 0;   // slot range the table was built from
     bool cells_valid = false;
     bool cells_clear_deferred = false;   // sph_hash left the clearing of the old table to the sort (merge path)
@@ -211,6 +212,7 @@ bool force_begin(sph_ctx* c, bool integrate);
 int launch_force_range(sph_ctx* c, uint32_t lo, uint32_t hi, bool force, bool collide, bool integrate, float dt, bool mark);
 void force_finish(sph_ctx* c, bool integrate, bool mark);
 // phase bodies of sph_capi.hip (with their bookkeeping), for the slab driver
+int set_slab_range(sph_ctx* c, uint32_t z_lo, uint32_t z_hi);   // sph_capi.hip: a slab context takes over another layer range (its table must be clear)
 int step_hash(sph_ctx* c);
 int step_sort(sph_ctx* c);
 int step_cells(sph_ctx* c);

@@ -64,6 +64,7 @@ enum {
     HL_SEQ = 16,      // written last: the step number
     HL_ERR = 17,      // [17..18] sticky error words set by device-side checks (plain stores of 1): SLAB_ERR_*
     HL_NEAR = 20,     // [20..21] first slot of local layer 3 / of local layer zl-3 (ABSOLUTE): the layers next to the deep interior
+    HL_RECUT = 24,    // [24..25] sph_slab_recut: particles that go down / up ; [26..27] what the neighbours send (from below, from above)
     HL_WORDS = 32
 };
 enum { SLAB_ERR_INSERT_LAYER = 0, SLAB_ERR_ARRIVAL_OUTSIDE = 1 };
@@ -356,6 +357,96 @@ __global__ __launch_bounds__(256) void k_slab_copy_back(const float4* __restrict
     k_dst[first + t] = k_src[first + t];
 }
 
+// ---- re-cut (sph_slab_recut): whole layers change owner on the device --------------------------------------------------
+// Where a particle of the sorted owned range goes under the NEW cuts: 0 = to the lower neighbour (its true cell layer is
+// below new_z_lo), 2 = to the upper one, 1 = stays.  By POSITION, not by key: a leaver's key is clamped into a ghost layer.
+constexpr uint32_t RECUT_BLOCK = 1024;          // slots per block of the three-way partition
+__device__ __forceinline__ uint32_t recut_dest(const float4& p, const GridDesc& g, uint32_t new_lo, uint32_t new_hi) {
+    const uint32_t lz = cell_coord(p.z, g.box_min[2], g.box_dims[2], g.inv_dims[2], g.gf[2], g.g[2]);
+    return lz < new_lo ? 0u : (lz >= new_hi ? 2u : 1u);
+}
+__global__ __launch_bounds__(256) void k_recut_count(const float4* __restrict__ posi, uint32_t n, GridDesc g, uint32_t new_lo,
+                                                     uint32_t new_hi, uint32_t* __restrict__ blk) {
+    __shared__ uint32_t s_c[2];
+    if (threadIdx.x < 2) s_c[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t c0 = 0, c2 = 0;
+    for (uint32_t k = threadIdx.x; k < RECUT_BLOCK; k += 256u) {
+        const uint32_t i = blockIdx.x * RECUT_BLOCK + k;
+        if (i < n) { const uint32_t d = recut_dest(posi[i], g, new_lo, new_hi); c0 += d == 0u; c2 += d == 2u; }
+    }
+    if (c0) atomicAdd(&s_c[0], c0);
+    if (c2) atomicAdd(&s_c[1], c2);
+    __syncthreads();
+    if (threadIdx.x < 2) blk[2 * blockIdx.x + threadIdx.x] = s_c[threadIdx.x];
+}
+// exclusive scan of the per-block {down, up} counts by one block; the totals go to mapped host memory
+__global__ __launch_bounds__(1024) void k_recut_scan(uint32_t* __restrict__ blk, uint32_t nblk, volatile uint32_t* __restrict__ host) {
+    __shared__ uint32_t part[2][1024];
+    const uint32_t per = (nblk + 1023u) / 1024u, lo = min(threadIdx.x * per, nblk), hi = min(lo + per, nblk);
+    uint32_t s0 = 0, s2 = 0;
+    for (uint32_t b = lo; b < hi; b++) { s0 += blk[2 * b]; s2 += blk[2 * b + 1]; }
+    part[0][threadIdx.x] = s0; part[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t a = threadIdx.x >= (uint32_t)o ? part[0][threadIdx.x - o] : 0u, b = threadIdx.x >= (uint32_t)o ? part[1][threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[0][threadIdx.x] += a; part[1][threadIdx.x] += b;
+        __syncthreads();
+    }
+    uint32_t r0 = part[0][threadIdx.x] - s0, r2 = part[1][threadIdx.x] - s2;
+    for (uint32_t b = lo; b < hi; b++) { const uint32_t c0 = blk[2 * b], c2 = blk[2 * b + 1]; blk[2 * b] = r0; blk[2 * b + 1] = r2; r0 += c0; r2 += c2; }
+    if (threadIdx.x == 1023) { host[0] = part[0][1023]; host[1] = part[1][1023]; }
+}
+// stable three-way partition: who stays -> [keep0 + rank), who goes down -> [down0 + rank), up -> [up0 + rank) of the
+// ping-pong arrays, each class in slot order (one wave per 64 slots: ranks by ballot, the waves of a block in sequence)
+__global__ __launch_bounds__(64) void k_recut_scatter(const float4* __restrict__ posi, const float4* __restrict__ velr, uint32_t n,
+                                                      GridDesc g, uint32_t new_lo, uint32_t new_hi, const uint32_t* __restrict__ blk,
+                                                      float4* __restrict__ posi_o, float4* __restrict__ velr_o, uint32_t keep0,
+                                                      uint32_t down0, uint32_t up0) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t r0 = blk[2 * blockIdx.x], r2 = blk[2 * blockIdx.x + 1];
+    uint32_t r1 = blockIdx.x * RECUT_BLOCK - r0 - r2;                      // slots in front of this block that stay
+    for (uint32_t k = 0; k < RECUT_BLOCK; k += 64u) {
+        const uint32_t i = blockIdx.x * RECUT_BLOCK + k + lane;
+        const bool live = i < n;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p;
+        uint32_t d = 3u;
+        if (live) { p = posi[i]; v = velr[i]; d = recut_dest(p, g, new_lo, new_hi); }
+        const uint64_t m0 = __ballot(d == 0u), m1 = __ballot(d == 1u), m2 = __ballot(d == 2u), below = (1ull << lane) - 1ull;
+        if (live) {
+            const uint32_t dst = d == 0u ? down0 + r0 + (uint32_t)__popcll(m0 & below)
+                               : d == 1u ? keep0 + r1 + (uint32_t)__popcll(m1 & below) : up0 + r2 + (uint32_t)__popcll(m2 & below);
+            posi_o[dst] = p; velr_o[dst] = v;
+        }
+        r0 += (uint32_t)__popcll(m0); r1 += (uint32_t)__popcll(m1); r2 += (uint32_t)__popcll(m2);
+    }
+}
+// one chunk of both leaving lists -> 8-float records ; arrived records -> their final slots ; the kept run -> its final place
+__global__ __launch_bounds__(256) void k_recut_pack(const float4* __restrict__ p, const float4* __restrict__ v, uint32_t first_lo,
+                                                    uint32_t n_lo, uint32_t first_hi, uint32_t n_hi, float4* __restrict__ rec_lo,
+                                                    float4* __restrict__ rec_hi) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n_lo) { rec_lo[2 * t] = p[first_lo + t]; rec_lo[2 * t + 1] = v[first_lo + t]; }
+    else if (t - n_lo < n_hi) { const uint32_t i = t - n_lo; rec_hi[2 * i] = p[first_hi + i]; rec_hi[2 * i + 1] = v[first_hi + i]; }
+}
+__global__ __launch_bounds__(256) void k_recut_unpack(const float4* __restrict__ rec_lo, uint32_t n_lo, uint32_t slot_lo,
+                                                      const float4* __restrict__ rec_hi, uint32_t n_hi, uint32_t slot_hi,
+                                                      float4* __restrict__ p, float4* __restrict__ v) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n_lo) { p[slot_lo + t] = rec_lo[2 * t]; v[slot_lo + t] = rec_lo[2 * t + 1]; }
+    else if (t - n_lo < n_hi) { const uint32_t i = t - n_lo; p[slot_hi + i] = rec_hi[2 * i]; v[slot_hi + i] = rec_hi[2 * i + 1]; }
+}
+__global__ __launch_bounds__(256) void k_recut_copy(const float4* __restrict__ ps, const float4* __restrict__ vs, uint32_t src,
+                                                    float4* __restrict__ pd, float4* __restrict__ vd, uint32_t dst, uint32_t count) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < count) { pd[dst + t] = ps[src + t]; vd[dst + t] = vs[src + t]; }
+}
+__global__ void k_recut_counts_out(float4* __restrict__ out_lo, float4* __restrict__ out_hi, uint32_t down, uint32_t up) {
+    if (threadIdx.x == 0) out_lo[0] = make_float4(__uint_as_float(down), 0.f, 0.f, 0.f);
+    if (threadIdx.x == 1) out_hi[0] = make_float4(__uint_as_float(up), 0.f, 0.f, 0.f);
+}
+
 // ---- neighbour ping (sph_slab_ping): a message whose every word says who sent it, towards which side, in which round --
 __device__ __forceinline__ uint32_t ping_word(uint32_t rank, uint32_t side, uint32_t rep, uint32_t i) {
     uint32_t x = (rank * 2u + side) * 0x9E3779B9u + rep * 0x85EBCA6Bu + i;
@@ -601,6 +692,8 @@ struct sph_slab {
     size_t stage_bytes = 0;
     uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0, inserts = 0, far_steps = 0, rest_msgs = 0;
     uint64_t exchanges = 0;              // transport calls so far (3 in a usual step: migrants, halo A, halo B)
+    uint32_t* recut_blk = nullptr;       // sph_slab_recut: {down, up} counts per 1024-slot block, then their scan
+    uint64_t recuts = 0, recut_moved = 0;
     // failure: the first error of this slab (sticky), its message, and whether the transport may still be used
     int failed = 0;
     char fail_msg[512] = {0};
@@ -638,6 +731,7 @@ void slab_free(sph_slab* s) {
         if (s->stage_recv[k]) hipHostFree(s->stage_recv[k]);
     }
     hipFree(s->d_lb);
+    hipFree(s->recut_blk);
     if (s->h_lb) hipHostFree((void*)s->h_lb);
     if (s->ev_main) hipEventDestroy(s->ev_main);
     if (s->ev_comm) hipEventDestroy(s->ev_comm);
@@ -1522,6 +1616,134 @@ int sph_slab_ping(sph_slab* s, size_t bytes, uint32_t reps, double out[3]) {
     s->t_group[4] = acc0;
     if (rc) { s->failed = rc; snprintf(s->fail_msg, sizeof s->fail_msg, "%s", sph_last_error()); }
     return rc;
+}
+
+// a stream of this slab, drained with a bound: a neighbour that never takes part must be an error, not a hang
+static int slab_wait_stream(sph_slab* s, hipStream_t st, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    while ((q = hipStreamQuery(st)) == hipErrorNotReady) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > s->wait_timeout_s) {
+            set_error("rank %d: %s: no answer from a neighbour after %.0f s", s->rank, what, s->wait_timeout_s);
+            s->transport_dead = true;
+            if (s->tr.abort) s->tr.abort(s->tr.self);
+            return SPH_E_DEVICE;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    if (q != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(q)); return SPH_E_DEVICE; }
+    return SPH_OK;
+}
+
+// Re-cut: this slab takes over the cell layers [new_z_lo, new_z_hi).  Everything stays on the device and the context is
+// kept: the owned particles are sorted once more (so that order and positions agree), split by their TRUE layer into
+// "goes down" | "stays" | "goes up" (stable), the two leaving runs travel to rank - 1 / rank + 1 in chunks of the halo
+// buffers (one small message tells the counts first), what arrives is put in front of / behind what stays -- exactly
+// the order in which the whole-domain sorted array lists the new owner's particles -- and the context is re-keyed for
+// its new layers; the next step starts with a full (stable) radix sort, as after an upload.  COLLECTIVE over the
+// chain; every particle may move ONE rank per call: the caller keeps new cut r within [old cut r-1, old cut r+1].
+static int slab_recut_body(sph_slab* s, uint32_t new_lo, uint32_t new_hi) {
+    sph_ctx* c = s->c;
+    int rc;
+    const size_t rec = 2 * sizeof(float4);
+    SPH_HIP(hipStreamSynchronize(s->comm));
+    rc = step_hash(c); if (rc) return rc;
+    rc = step_sort(c); if (rc) return rc;                 // (a slab's sort also builds the table of its owned slots)
+    rc = launch_cells_clear(c); if (rc) return rc;        // no entry of the old numbering survives
+    mm_drop_marks(c);
+    const uint32_t n = c->n, off = c->own_off, nblk = ceil_div(max(n, 1u), RECUT_BLOCK);
+    if (!s->recut_blk) SPH_HIP(hipMalloc((void**)&s->recut_blk, (size_t)2 * (ceil_div(c->cap, RECUT_BLOCK) + 1) * sizeof(uint32_t)));
+    s->h_lb[HL_RECUT] = s->h_lb[HL_RECUT + 1] = 0u;
+    hipLaunchKernelGGL(k_recut_count, dim3(nblk), dim3(256), 0, c->stream, c->posi + off, n, c->grid, new_lo, new_hi, s->recut_blk);
+    hipLaunchKernelGGL(k_recut_scan, dim3(1), dim3(1024), 0, c->stream, s->recut_blk, nblk, s->h_lb_dev + HL_RECUT);
+    SPH_HIP(hipGetLastError());
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t down = s->h_lb[HL_RECUT], up = s->h_lb[HL_RECUT + 1];
+    SPH_REQUIRE(down + up <= n, SPH_E_STATE, "rank %d: re-cut counts %u + %u exceed the %u owned particles", s->rank, down, up, n);
+    SPH_REQUIRE((s->has_lo || down == 0u) && (s->has_hi || up == 0u), SPH_E_INVALID,
+                "rank %d: the new layers [%u, %u) leave %u / %u particles without an owner", s->rank, new_lo, new_hi, down, up);
+    const uint32_t keep = n - down - up;
+    // [stays | goes down | goes up] in the ping-pong arrays, from the canonical offset
+    const uint32_t keep0 = c->gcap, down0 = keep0 + keep, up0 = down0 + down;
+    hipLaunchKernelGGL(k_recut_scatter, dim3(nblk), dim3(64), 0, c->stream, c->posi + off, c->velr + off, n, c->grid, new_lo, new_hi,
+                       s->recut_blk, c->posi2, c->velr2, keep0, down0, up0);
+    // the counts: one record each way (the first record of the migrant buffers)
+    hipLaunchKernelGGL(k_recut_counts_out, dim3(1), dim3(64), 0, c->stream, s->mig_send[0], s->mig_send[1], down, up);
+    SPH_HIP(hipGetLastError());
+    rc = after_main(s); if (rc) return rc;
+    rc = slab_exchange(s, SPH_TAG_RECUT_COUNTS, s->mig_send[0], rec, s->mig_recv[0], rec, s->mig_send[1], rec, s->mig_recv[1], rec);
+    if (rc) return rc;
+    uint32_t in_lo = 0, in_hi = 0;
+    if (s->has_lo) SPH_HIP(hipMemcpyAsync((void*)&s->h_lb[HL_RECUT + 2], s->mig_recv[0], sizeof(uint32_t), hipMemcpyDeviceToHost, s->comm));
+    if (s->has_hi) SPH_HIP(hipMemcpyAsync((void*)&s->h_lb[HL_RECUT + 3], s->mig_recv[1], sizeof(uint32_t), hipMemcpyDeviceToHost, s->comm));
+    rc = slab_wait_stream(s, s->comm, "re-cut (counts)"); if (rc) return rc;
+    if (s->has_lo) in_lo = s->h_lb[HL_RECUT + 2];
+    if (s->has_hi) in_hi = s->h_lb[HL_RECUT + 3];
+    const uint64_t n_new = (uint64_t)keep + in_lo + in_hi;
+    SPH_REQUIRE(n_new <= c->cap, SPH_E_CAPACITY, "rank %d: the layers [%u, %u) hold %llu particles, the capacity is %u", s->rank, new_lo,
+                new_hi, (unsigned long long)n_new, c->cap);
+    // what stays goes to its final place in the (now free) primary arrays: behind what comes from below
+    const uint32_t base = c->gcap;
+    if (keep)
+        hipLaunchKernelGGL(k_recut_copy, dim3(ceil_div(keep, 256u)), dim3(256), 0, c->stream, c->posi2, c->velr2, keep0, c->posi, c->velr,
+                           base + in_lo, keep);
+    // the two leaving runs, chunk by chunk; both ends of a link know both counts, so they agree on every size
+    const uint32_t chunk = s->gcap;
+    const uint32_t rounds = max(max(ceil_div(down, chunk), ceil_div(up, chunk)), max(ceil_div(in_lo, chunk), ceil_div(in_hi, chunk)));
+    for (uint32_t j = 0; j < rounds; j++) {
+        auto part = [&](uint32_t total) { return total > j * chunk ? min(chunk, total - j * chunk) : 0u; };
+        const uint32_t s_lo = part(down), s_hi = part(up), r_lo = part(in_lo), r_hi = part(in_hi);
+        if (s_lo + s_hi)
+            hipLaunchKernelGGL(k_recut_pack, dim3(ceil_div(s_lo + s_hi, 256u)), dim3(256), 0, c->stream, c->posi2, c->velr2, down0 + j * chunk,
+                               s_lo, up0 + j * chunk, s_hi, s->halo_send[0], s->halo_send[1]);
+        SPH_HIP(hipGetLastError());
+        rc = after_main(s); if (rc) return rc;
+        rc = slab_exchange(s, SPH_TAG_RECUT, s->halo_send[0], s_lo * rec, s->halo_recv[0], r_lo * rec, s->halo_send[1], s_hi * rec,
+                           s->halo_recv[1], r_hi * rec);
+        if (rc) return rc;
+        if (r_lo + r_hi)
+            hipLaunchKernelGGL(k_recut_unpack, dim3(ceil_div(r_lo + r_hi, 256u)), dim3(256), 0, s->comm, s->halo_recv[0], r_lo,
+                               base + j * chunk, s->halo_recv[1], r_hi, base + in_lo + keep + j * chunk, c->posi, c->velr);
+        SPH_HIP(hipGetLastError());
+        rc = after_comm(s); if (rc) return rc;            // the send buffers are free again, the arrivals are in
+    }
+    rc = slab_wait_stream(s, s->comm, "re-cut (particles)"); if (rc) return rc;
+    SPH_HIP(hipStreamSynchronize(c->stream));
+    c->own_off = base;
+    c->n = (uint32_t)n_new;
+    rc = set_slab_range(c, new_lo, new_hi); if (rc) return rc;
+    s->recuts++;
+    s->recut_moved += down + up;
+    return SPH_OK;
+}
+
+int sph_slab_recut(sph_slab* s, uint32_t new_z_lo, uint32_t new_z_hi) {
+    SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
+    if (s->failed) { set_error("%s", s->fail_msg); return s->failed; }
+    SPH_REQUIRE(new_z_lo < new_z_hi && new_z_hi <= s->c->params.grid[2], SPH_E_INVALID, "bad layer range [%u, %u)", new_z_lo, new_z_hi);
+    SPH_REQUIRE(s->world == 1 || new_z_hi - new_z_lo >= 2, SPH_E_INVALID, "a slab needs at least two cell layers");
+    SPH_REQUIRE((s->has_lo || new_z_lo == 0u) && (s->has_hi || new_z_hi == s->c->params.grid[2]), SPH_E_INVALID,
+                "rank %d of %d: the outer slabs reach to the ends of the grid", s->rank, s->world);
+    SPH_HIP(hipSetDevice(s->c->device));
+    const uint64_t exchanges0 = s->exchanges;
+    const bool timed0 = s->time_groups;
+    s->time_groups = false;
+    s->pg = sph_slab::Progress();
+    const int rc = slab_recut_body(s, new_z_lo, new_z_hi);
+    s->time_groups = timed0;
+    s->exchanges = exchanges0;                            // (the step counters count the steps' messages)
+    if (rc) {                                             // a half-done re-cut cannot be resumed: the slab is failed
+        s->failed = rc;
+        snprintf(s->fail_msg, sizeof s->fail_msg, "%s", sph_last_error());
+        if (s->transport_dead && s->tr.abort) s->tr.abort(s->tr.self);
+    }
+    return rc;
+}
+
+int sph_slab_recut_stats(const sph_slab* s, uint64_t out[2]) {
+    SPH_REQUIRE(s && out, SPH_E_INVALID, "null argument");
+    out[0] = s->recuts; out[1] = s->recut_moved;
+    return SPH_OK;
 }
 
 // test hook: raise one of the sticky device-side error words by hand (what k_slab_insert / k_slab_unpack do when an

@@ -80,6 +80,20 @@ def choose_cuts(hist, world):
     return [int(c) for c in cuts]
 
 
+def single_hop_cuts(old, new):
+    """The cuts one `sph_slab_recut` call may go to on the way from `old` to `new`: a re-cut moves every particle at most
+    ONE rank, i.e. new cut r must lie within [old cut r-1, old cut r+1] (what rank r gives away below its new lower cut
+    must belong to rank r-1's new layers, and the same above).  Clipping every target cut into that interval keeps the
+    cuts ordered and the slabs at least MIN_SLAB_LAYERS thick (both `old` and `new` are); repeat until old == new."""
+    old, new = [int(c) for c in old], [int(c) for c in new]
+    assert len(old) == len(new) and old[0] == new[0] and old[-1] == new[-1]
+    out = [old[0]]
+    for r in range(1, len(old) - 1):
+        out.append(min(max(new[r], old[r - 1]), old[r + 1]))
+    out.append(old[-1])
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # communication back ends (same three calls)
 # ------------------------------------------------------------------------------------------------
@@ -702,18 +716,39 @@ class NativeSlabSimulation(SlabSimulation):
         capi._check(capi.load().sph_slab_sync(self._slab))
 
     def rebalance(self, tolerance=0.02, cuts=None):
+        """Re-cut ON THE DEVICE (sph_slab_recut): whole layers change owner point to point through the slab's own
+        transport, the context, the slab object and its buffers are kept -- no host round trip of the particles, no new
+        context (round 4 moved them through host numpy).  Collective.  A move of a cut past a neighbouring cut is taken
+        in several hops (single_hop_cuts)."""
         self.sync()
+        hist = None
         if cuts is None:
-            cuts = self.plan_rebalance(tolerance)          # device-side histogram + one small all-reduce
-        if cuts is None:
-            return False                                   # balanced: the slab object and its buffers stay as they are
-        self._pull_stats()
-        self._stats_base = {k: self.stats.get(k, 0) for k in ("migrants", "resorts", "ghosts", "host_waits", "steps",
-                                                              "in_place_merges", "far_steps", "rest_messages", "exchanges")}
-        self._unbind()                 # the engine (context) is replaced when the cuts move
-        moved = super().rebalance(tolerance, cuts=cuts)
-        self._bind()
-        return moved
+            hist = self._layer_histogram()                 # device-side histogram + one small all-reduce
+            counts = [int(hist[a:b].sum()) for a, b in zip(self.cuts, self.cuts[1:])]
+            if max(counts) <= (1.0 + tolerance) * self.total / self.world:
+                return False                               # balanced: nothing moves
+            cuts = choose_cuts(hist, self.world)
+        cuts = [int(c) for c in cuts]
+        if cuts == self.cuts:
+            return False
+        if hist is None:
+            hist = self._layer_histogram()
+        L = capi.load()
+        while self.cuts != cuts:
+            step = single_hop_cuts(self.cuts, cuts)
+            # every rank sees every rank's new count: a slab that would overflow stops the re-cut on ALL ranks, before
+            # anything has moved (the histogram counts owned particles by their layer: exact up to the step's leavers)
+            need = [int(hist[a:b].sum()) for a, b in zip(step, step[1:])]
+            caps = self.comm.allreduce_sum(np.eye(self.world, dtype=np.int64)[self.rank] * int(self.capacity)).astype(np.int64)
+            over = [r for r in range(self.world) if need[r] + 1024 > caps[r]]
+            if over:
+                raise capi.SphError(f"re-balancing to the cuts {step} needs {need[over[0]]} particles on rank {over[0]}, "
+                                    f"whose capacity is {int(caps[over[0]])}")
+            capi._check(L.sph_slab_recut(self._slab, step[self.rank], step[self.rank + 1]))
+            self.cuts = step
+            self.z_lo, self.z_hi = step[self.rank], step[self.rank + 1]
+        self.stats["rebalances"] = self.stats.get("rebalances", 0) + 1
+        return True
 
     def close(self):
         self._unbind()                 # before the context goes: sph_slab_destroy drains the context's stream

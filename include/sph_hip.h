@@ -281,7 +281,8 @@ int sph_layer_histogram(sph_ctx* c, uint32_t* hist, uint32_t n_layers);
  *   host_buffers = 1 (tests): the pointers are pinned HOST buffers the library staged, the call blocks until its
  *                    receives are complete (several slabs of one GPU in one process; processes over gloo).
  * Return 0 or a negative SPH_E* code. */
-enum { SPH_TAG_MIGRANTS = 1, SPH_TAG_HALO_A = 2, SPH_TAG_HALO_B = 3, SPH_TAG_MIGRANTS_REST = 4, SPH_TAG_PING = 5 };
+enum { SPH_TAG_MIGRANTS = 1, SPH_TAG_HALO_A = 2, SPH_TAG_HALO_B = 3, SPH_TAG_MIGRANTS_REST = 4, SPH_TAG_PING = 5,
+       SPH_TAG_RECUT_COUNTS = 6, SPH_TAG_RECUT = 7 };
 /* ZERO-INITIALISE the struct before filling it in (`sph_transport t = {0};`): sph_slab_create copies it by value, and
  * members added at its end (so far: `abort`, ABI v2 of round 4) must read as NULL in a caller built against an older
  * header -- there is no size field, a garbage `abort` pointer would be called on the first failure. */
@@ -348,6 +349,19 @@ uint64_t sph_slab_in_place_merges(const sph_slab* s);
 /* transport calls so far: 3 in a usual step (migrants, halo A, halo B), 4 when a side has more leavers than ride in the
  * fixed-size migrant message */
 uint64_t sph_slab_exchanges(const sph_slab* s);
+/* Re-cut (re-balancing): this slab takes over the cell layers [new_z_lo, new_z_hi) of the global grid.  Entirely on the
+ * device, the context and the slab object are kept: the owned particles are split by their layer into "to rank - 1" |
+ * "stay" | "to rank + 1" (stable), the leaving runs travel point to point through the slab's transport in chunks of the
+ * halo buffers, arrivals from below are put in front of what stays and arrivals from above behind it -- the order of the
+ * whole-domain sorted array, so an N-slab run keeps the bits of the one-context run across re-cuts -- and the next step
+ * starts with a full stable sort, as after an upload.  COLLECTIVE: every rank of the chain calls it (a rank whose layers do
+ * not change passes its old range), with cuts that agree across ranks; a particle moves at most ONE rank per call, i.e.
+ * new cut r lies within [old cut r-1, old cut r+1] (gpufluidsimulator_amd/slab.py: single_hop_cuts steps a larger move).
+ * SPH_E_CAPACITY if the new layers hold more particles than the context's capacity (nothing is lost: the slab is failed,
+ * download and destroy).  Replaces nothing in the reference (single GPU); SURVEY.md section 8e "re-cut every K steps". */
+int sph_slab_recut(sph_slab* s, uint32_t new_z_lo, uint32_t new_z_hi);
+/* {re-cuts so far, particles that changed owner in them} */
+int sph_slab_recut_stats(const sph_slab* s, uint64_t out[2]);
 /* Neighbour ping: `reps` timed rounds (+ one untimed round first) of ONE exchange-shaped group -- `bytes` to and from
  * rank - 1 and rank + 1, through this slab's transport, comm stream and halo buffers -- every word checked on arrival for
  * sender, direction and round.  out = {mean us per group, max us, wrong words}; event times on the comm stream, i.e. what a
