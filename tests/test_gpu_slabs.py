@@ -36,9 +36,12 @@ def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport=
             sim = slab.NativeSlabSimulation(_comm(hub, dev_hub, r), box, grid, device_index=0, transport=transport,
                                             particles=particles, lattice=lattice)
             cuts0 = list(sim.cuts)
+            handles0 = (sim.engine.ctx.h.value, sim._slab.value)
             sim.run(DT, steps, rebalance_every=rebalance_every)
             sim.sync()
-            results[r] = (sim.gather_state(), dict(sim.stats, sort_forms=sim.engine.ctx.sort_forms()), sim.cuts, sim.engine.n, cuts0)
+            kept = handles0 == (sim.engine.ctx.h.value, sim._slab.value)       # same sph_ctx, same sph_slab (re-cuts keep both)
+            results[r] = (sim.gather_state(), dict(sim.stats, sort_forms=sim.engine.ctx.sort_forms(), kept=kept), sim.cuts, sim.engine.n,
+                          cuts0)
             sim.close()
         except BaseException as e:     # noqa: BLE001
             errors.append(e)
@@ -216,6 +219,11 @@ def test_rebalance_on_gpu_engines(transport):
     results = _run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, rebalance_every=20)
     st, stats, cuts1, _, cuts0 = results[0]
     assert stats.get("rebalances", 0) >= 1 and cuts1 != cuts0
+    # the re-cut happens on the device (sph_slab_recut): no rank got a new context or a new slab object, and the step
+    # counters ran on through it (one host wait and three messages per step, re-cut traffic not counted)
+    assert all(r[1]["kept"] for r in results)
+    assert all(r[1]["steps"] == steps and r[1]["host_waits"] == steps + r[1]["far_steps"] for r in results), [r[1] for r in results]
+    assert all(r[1]["exchanges"] == 3 * steps + r[1]["rest_messages"] for r in results), [r[1] for r in results]
     owned = [r[3] for r in results]
     assert sum(owned) == pos.shape[0] and max(owned) <= 1.35 * pos.shape[0] / world, owned
     ref = _whole_domain(pos, vel, box, grid, steps)
@@ -723,3 +731,41 @@ def test_a_failure_on_the_last_step_still_lets_every_slab_close():
     assert "exceed the capacity" in out[2][1], out
     assert out[0][0] == out[1][0] == out[2][0] + 1, out               # the neighbours finished the step the top rank failed in
     assert max(o[2] for o in out) < 20.0, out
+
+
+def test_recut_by_several_layers_in_hops_and_into_an_empty_slab():
+    """sph_slab_recut beyond the easy case: the cuts are set BY HAND far from where they were -- a cut jumps past its
+    neighbour's old position (taken in several single-hop re-cuts), a slab is emptied completely and later refilled, the
+    layer range of a slab grows beyond the cell table it was created with (the table is replaced, the context kept) --
+    with steps in between; the state stays bit for bit the one-context run's, capacity permitting."""
+    pos, vel, box, grid = make_case("shear")
+    world, gz = 4, grid[2]
+    plans = [[0, 2, 4, 6, gz], [0, 13, 15, 17, gz], [0, 5, 9, 11, gz], [0, 3, 6, 9, gz], [0, 8, 10, 12, gz]]
+
+    def body(make, r):
+        sim = make(box=box, grid=grid, particles=(pos, vel), capacity_factor=4.2)
+        try:
+            h0 = (sim.engine.ctx.h.value, sim._slab.value)
+            owned = []
+            for cuts in plans:
+                sim.run(DT, 5)
+                moved = sim.rebalance(cuts=cuts)
+                owned.append((moved, sim.engine.n, list(sim.cuts)))
+            sim.run(DT, 5)
+            sim.sync()
+            import ctypes as C
+            rs = (C.c_uint64 * 2)()
+            capi._check(capi.load().sph_slab_recut_stats(sim._slab, rs))
+            return sim.gather_state(), owned, h0 == (sim.engine.ctx.h.value, sim._slab.value), (int(rs[0]), int(rs[1])), dict(sim.stats)
+        finally:
+            sim.close()
+
+    out, errors = _with_ranks(world, body, timeout_s=300)
+    assert errors == [None] * world, errors
+    ref = _whole_domain(pos, vel, box, grid, 5 * (len(plans) + 1))
+    _same_bits(out[0][0], ref)
+    assert all(o[2] for o in out), "context and slab object are kept across re-cuts"
+    for k, cuts in enumerate(plans):
+        assert all(o[1][k][2] == cuts for o in out) and sum(o[1][k][1] for o in out) == pos.shape[0]
+    assert sum(o[3][1] for o in out) > pos.shape[0] // 2 and max(o[3][0] for o in out) >= len(plans)     # whole layers moved, in several hops
+    assert all(o[4]["host_waits"] == o[4]["steps"] + o[4]["far_steps"] for o in out)

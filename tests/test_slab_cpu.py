@@ -163,3 +163,23 @@ def test_bench_config_is_strong_scaling_of_config_3_by_default():
     cuts = slab.choose_cuts(hist, 8)
     assert cuts == [0, 16, 32, 48, 64, 80, 96, 112, 512]
     assert all(b - a >= 7 for a, b in zip(cuts, cuts[1:]))        # every slab has a deep interior (>= 7 owned layers)
+
+
+def test_single_hop_cuts_reach_any_target_one_rank_at_a_time():
+    """slab.single_hop_cuts: the sequence of cuts a device-side re-cut (sph_slab_recut moves a particle at most one rank per
+    call) goes through; every hop keeps new cut r within [old cut r-1, old cut r+1], the order and the minimum thickness."""
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        world, gz = int(rng.integers(2, 9)), 64
+        def cuts():
+            inner = np.sort(rng.choice(np.arange(2, gz - 1, 2), world - 1, replace=False))
+            return [0] + [int(v) for v in inner] + [gz]
+        old, new = cuts(), cuts()
+        hops = 0
+        while old != new:
+            step = slab.single_hop_cuts(old, new)
+            assert step != old and step[0] == 0 and step[-1] == gz
+            assert all(old[r - 1] <= step[r] <= old[r + 1] for r in range(1, world))
+            assert all(b - a >= 2 for a, b in zip(step, step[1:])), (old, new, step)
+            old, hops = step, hops + 1
+            assert hops <= world + 2
