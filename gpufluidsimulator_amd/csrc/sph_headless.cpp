@@ -1,17 +1,33 @@
 // sph_headless.cpp -- headless driver with the reference's command line
-// (SPH/particles.cpp:676-706: -n= -box= -i= -benchmark -device=) and its runBenchmark()
+// (SPH/particles.cpp:676-706: -n= -box= -i= -benchmark -device= -file=) and its runBenchmark()
 // output line (:176-192), on top of include/particleSystem.h.  No GLUT / OpenGL.
 //   sph_headless -benchmark -n=262144 -box=8 -i=100 [-device=0] [-grid=128] [-ic=grid|random] [-steps=1] [-dump=8]
-//                [-log=benchmark.txt]
-// Several GPUs: one process per GPU (z-slabs, RCCL) -- `python bench.py --gpus N`; this driver is the
-// reference's single-device program.
+//                [-log=benchmark.txt] [-file=<snapshot>]
+// Several GPUs (no counterpart in the reference, which is a single-device program): -gpus=N cuts the dam into N
+// z-slabs and steps them with sph_slab_step through the C ABI --
+//   -gpus=N            N child PROCESSES, forked before anything touches a GPU, rank r on device r (+ -device=), messages
+//                      over RCCL (sph_rccl_transport_create; rank 0 hands the id to the others through pipes);
+//   -gpus=N -onegpu    N THREADS of this process on one device over the device-to-device transport (a one-GPU box).
+// The reference's line is printed with NumDevsUsed = N.
 #include "../../include/particleSystem.h"
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 static bool flag(int argc, char** argv, const char* name) {   // checkCmdLineFlag, helper_string.h:111
     for (int i = 1; i < argc; i++) {
@@ -33,6 +49,229 @@ static const char* value(int argc, char** argv, const char* name) {
     return nullptr;
 }
 
+// ---- -gpus=N: z-slabs through the C ABI ---------------------------------------------------------------------------
+namespace {
+
+struct SlabJob {
+    uint32_t lattice[3];
+    uint64_t particles;              // the first `particles` lattice points (creation index = x + nx (y + ny z))
+    float box;
+    uint32_t grid;
+    int iterations, substeps;
+    bool warmup;
+    float dt;
+    const char* out;                 // xyzw per creation index, then vxyz0 (as the one-device -out)
+};
+
+struct Plan { std::vector<uint32_t> cuts; std::vector<uint64_t> hist; uint64_t per_layer = 0; };
+
+// Count-balanced cuts of whole cell layers, every slab at least two layers (gpufluidsimulator_amd/slab.py: choose_cuts).
+// The lattice planes must not straddle a cell face (every BASELINE config: planes sit a quarter of a cell from the faces,
+// the jitter is 0.08 of a cell), so that a slab is one run of creation indices generated on its own device.
+bool plan_slabs(const SlabJob& j, int world, Plan& pl, std::string& err) {
+    const uint32_t nx = j.lattice[0], ny = j.lattice[1], nz = j.lattice[2], gz = j.grid;
+    const double radius = 1.0 / 64.0, spacing = 2.0 * radius, amp = 0.5 * j.box * 0.01 * radius + 1e-4;
+    pl.hist.assign(gz, 0);
+    auto layer = [&](double z) { long c = (long)std::floor((z + j.box / 2.0) / j.box * gz); return (uint32_t)std::min<long>(std::max<long>(c, 0), gz - 1); };
+    for (uint32_t iz = 0; iz < nz; iz++) {
+        const uint64_t first = (uint64_t)iz * nx * ny;
+        if (first >= j.particles) break;
+        const uint64_t cnt = std::min<uint64_t>((uint64_t)nx * ny, j.particles - first);
+        const double zc = -j.box / 2.0 + radius + spacing * iz;
+        if (layer(zc - amp) != layer(zc + amp)) { err = "a lattice plane straddles a cell face: use `python bench.py --gpus N`"; return false; }
+        pl.hist[layer(zc)] += cnt;
+    }
+    if ((uint64_t)world * 2 > gz) { err = "more slabs than pairs of cell layers"; return false; }
+    std::vector<uint64_t> prefix(gz + 1, 0);
+    for (uint32_t z = 0; z < gz; z++) { prefix[z + 1] = prefix[z] + pl.hist[z]; pl.per_layer = std::max(pl.per_layer, pl.hist[z]); }
+    pl.cuts.assign(1, 0u);
+    for (int r = 1; r < world; r++) {
+        const double target = (double)j.particles * r / world;
+        uint32_t z = (uint32_t)(std::lower_bound(prefix.begin(), prefix.end(), (uint64_t)std::ceil(target)) - prefix.begin());
+        if (z > 0 && std::fabs((double)prefix[z - 1] - target) <= std::fabs((double)prefix[std::min(z, gz)] - target)) z--;
+        z = std::max(z, pl.cuts.back() + 2u);
+        z = std::min(z, gz - 2u * (uint32_t)(world - r));
+        pl.cuts.push_back(z);
+    }
+    pl.cuts.push_back(gz);
+    return true;
+}
+
+struct RankResult { double seconds = 0.0; uint32_t owned = 0; double ping_us[3] = {0, 0, 0}; int rc = 0; char err[256] = {0}; };
+
+// a barrier between the ranks: threads share a counter, processes talk to the parent through pipes
+struct Gate {
+    std::mutex mu; std::condition_variable cv; int world = 1, waiting = 0; uint64_t round = 0;
+    int to_parent = -1, from_parent = -1;        // process mode
+    void wait() {
+        if (to_parent >= 0) {
+            char b = 1;
+            if (write(to_parent, &b, 1) != 1 || read(from_parent, &b, 1) != 1) _exit(3);
+            return;
+        }
+        std::unique_lock<std::mutex> g(mu);
+        const uint64_t my = round;
+        if (++waiting == world) { waiting = 0; round++; cv.notify_all(); }
+        else cv.wait(g, [&] { return round != my; });
+    }
+};
+
+void rank_main(const SlabJob& j, const Plan& pl, int rank, int world, int device, sph_local_hub* hub, const uint8_t* rccl_id, Gate& gate,
+               RankResult& res) {
+    auto fail = [&](const char* what) { res.rc = -1; snprintf(res.err, sizeof res.err, "rank %d: %s: %s", rank, what, sph_last_error()); };
+    const uint32_t z_lo = pl.cuts[rank], z_hi = pl.cuts[rank + 1];
+    uint64_t n_own = 0, first = 0;
+    {   // my lattice planes: one run of creation indices
+        const uint32_t nx = j.lattice[0], ny = j.lattice[1];
+        const double radius = 1.0 / 64.0, spacing = 2.0 * radius;
+        bool any = false;
+        for (uint32_t iz = 0; iz < j.lattice[2]; iz++) {
+            const uint64_t f = (uint64_t)iz * nx * ny;
+            if (f >= j.particles) break;
+            const double zc = -j.box / 2.0 + radius + spacing * iz;
+            long c = (long)std::floor((zc + j.box / 2.0) / j.box * j.grid);
+            c = std::min<long>(std::max<long>(c, 0), (long)j.grid - 1);
+            if ((uint32_t)c < z_lo || (uint32_t)c >= z_hi) continue;
+            if (!any) { first = f; any = true; }
+            n_own += std::min<uint64_t>((uint64_t)nx * ny, j.particles - f);
+        }
+    }
+    const float dims[3] = {j.box, j.box, j.box};
+    const uint32_t grid[3] = {j.grid, j.grid, j.grid};
+    sph_params prm;
+    sph_default_params(&prm, dims, grid);
+    const uint32_t gcap = (uint32_t)(3 * pl.per_layer + 1024);
+    const uint32_t cap = (uint32_t)(1.5 * (double)std::max<uint64_t>(n_own, j.particles / world)) + 4096u;
+    sph_ctx* ctx = nullptr; sph_transport* tr = nullptr; sph_slab* slab = nullptr;
+    bool ok = sph_create_slab(&ctx, device, cap, &prm, z_lo, z_hi, gcap) == 0;
+    if (!ok) fail("sph_create_slab");
+    if (ok && n_own && sph_reset_lattice(ctx, j.lattice, 1, nullptr, first, (uint32_t)n_own) < 0) { ok = false; fail("sph_reset_lattice"); }
+    if (ok && (hub ? sph_local_transport_create(&tr, hub, rank) : sph_rccl_transport_create(&tr, rccl_id, rank, world, device)) < 0) {
+        ok = false; fail("transport");
+    }
+    if (ok && sph_slab_create(&slab, ctx, rank, world, tr, 0) < 0) { ok = false; fail("sph_slab_create"); }
+    if (ok) {       // preflight: one exchange-shaped group at the step's three message sizes, contents checked
+        const size_t sizes[3] = {8192, (size_t)std::min<uint64_t>(pl.per_layer * 32, (uint64_t)(gcap + 1) * 32),
+                                 (size_t)std::min<uint64_t>(pl.per_layer * 8, (uint64_t)(gcap + 1) * 32)};
+        for (int k = 0; k < 3 && ok; k++) {
+            double o[3];
+            if (sph_slab_ping(slab, std::max<size_t>(sizes[k] & ~(size_t)3, 4), 3, o) < 0) { ok = false; fail("sph_slab_ping"); }
+            else res.ping_us[k] = o[0];
+        }
+    }
+    if (ok && j.warmup && (sph_slab_step(slab, j.dt, (uint32_t)j.substeps) < 0 || sph_slab_sync(slab) < 0)) { ok = false; fail("warm-up step"); }
+    gate.wait();
+    const auto t0 = std::chrono::steady_clock::now();
+    if (ok && (sph_slab_step(slab, j.dt, (uint32_t)(j.iterations * j.substeps)) < 0 || sph_slab_sync(slab) < 0)) { ok = false; fail("sph_slab_step"); }
+    gate.wait();
+    res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (ok) res.owned = sph_num_particles(ctx);
+    if (ok && j.out) {          // every rank writes the rows of the particles it owns into the shared file
+        const uint32_t n = res.owned;
+        std::vector<float> p((size_t)n * 3), v((size_t)n * 3);
+        std::vector<uint32_t> idx(n);
+        if (sph_download_owned(ctx, p.data(), v.data(), idx.data()) < 0) { ok = false; fail("sph_download_owned"); }
+        const int fd = ok ? open(j.out, O_RDWR) : -1;
+        const size_t bytes = (size_t)j.particles * 4 * sizeof(float) * 2;
+        float* m = fd >= 0 ? (float*)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : (float*)MAP_FAILED;
+        if (ok && m == (float*)MAP_FAILED) { ok = false; res.rc = -1; snprintf(res.err, sizeof res.err, "rank %d: cannot map %s", rank, j.out); }
+        if (ok) {
+            float* vel = m + (size_t)j.particles * 4;
+            for (uint32_t s = 0; s < n; s++) {
+                const size_t i = idx[s];
+                if (i >= j.particles) continue;
+                for (int a = 0; a < 3; a++) { m[4 * i + a] = p[3 * (size_t)s + a]; vel[4 * i + a] = v[3 * (size_t)s + a]; }
+                m[4 * i + 3] = 1.0f; vel[4 * i + 3] = 0.0f;
+            }
+            munmap(m, bytes);
+        }
+        if (fd >= 0) close(fd);
+    }
+    if (slab) sph_slab_destroy(slab);
+    if (tr) { if (hub) sph_local_transport_destroy(tr); else sph_rccl_transport_destroy(tr); }
+    if (ctx) sph_destroy(ctx);
+}
+
+bool read_all(int fd, void* p, size_t n) { char* c = (char*)p; while (n) { ssize_t k = read(fd, c, n); if (k <= 0) return false; c += k; n -= (size_t)k; } return true; }
+bool write_all(int fd, const void* p, size_t n) { const char* c = (const char*)p; while (n) { ssize_t k = write(fd, c, n); if (k <= 0) return false; c += k; n -= (size_t)k; } return true; }
+
+int run_slabs(const SlabJob& j, int world, bool onegpu, int device0) {
+    setenv("SPH_SLAB_TIMEOUT_S", "30", 0);      // a rank that failed must not leave the others in the library's 120 s waits
+    Plan pl; std::string err;
+    if (!plan_slabs(j, world, pl, err)) { fprintf(stderr, "-gpus=%d: %s\n", world, err.c_str()); return EXIT_FAILURE; }
+    if (j.out) {
+        const int fd = open(j.out, O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0 || ftruncate(fd, (off_t)(j.particles * 4 * sizeof(float) * 2)) != 0) { fprintf(stderr, "cannot create %s\n", j.out); return EXIT_FAILURE; }
+        close(fd);
+    }
+    printf("Run %llu particles simulation for %d iterations... (grid %u^3, box %g, %d z-slabs, cuts", (unsigned long long)j.particles,
+           j.iterations, j.grid, j.box, world);
+    for (uint32_t c : pl.cuts) printf(" %u", c);
+    printf(")\n\n");
+    fflush(stdout);
+    std::vector<RankResult> res(world);
+    if (onegpu) {       // N threads, one device, device-to-device transport
+        int is950 = 0;
+        if (sph_device_count(&is950) <= 0 || !is950 || sph_select_device(device0) < 0) { fprintf(stderr, "No gfx950 (MI355X) device found, exiting\n"); return EXIT_FAILURE; }
+        sph_local_hub* hub = nullptr;
+        if (sph_local_hub_create(&hub, world, device0) < 0) { fprintf(stderr, "%s\n", sph_last_error()); return EXIT_FAILURE; }
+        Gate gate; gate.world = world;
+        std::vector<std::thread> th;
+        for (int r = 0; r < world; r++) th.emplace_back([&, r] { rank_main(j, pl, r, world, device0, hub, nullptr, gate, res[r]); });
+        for (auto& t : th) t.join();
+        sph_local_hub_destroy(hub);
+    } else {            // N processes, forked BEFORE anything touches a GPU; rank r on device device0 + r, RCCL
+        std::vector<int> id_pipe(2 * world, -1), up(2 * world, -1), down(2 * world, -1), out_pipe(2 * world, -1);
+        for (int r = 0; r < world; r++)
+            if (pipe(&id_pipe[2 * r]) || pipe(&up[2 * r]) || pipe(&down[2 * r]) || pipe(&out_pipe[2 * r])) { perror("pipe"); return EXIT_FAILURE; }
+        std::vector<pid_t> kids(world);
+        for (int r = 0; r < world; r++) {
+            kids[r] = fork();
+            if (kids[r] < 0) { perror("fork"); return EXIT_FAILURE; }
+            if (kids[r] == 0) {
+                RankResult rr;
+                uint8_t id[128] = {0};
+                int ndev = sph_device_count(nullptr);
+                if (ndev < device0 + world) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank %d: %d GPUs asked for, %d visible (one GPU: -onegpu)", r, device0 + world, ndev); }
+                if (!rr.rc && sph_select_device(device0 + r) < 0) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank %d: %s", r, sph_last_error()); }
+                if (r == 0) {
+                    if (!rr.rc && sph_rccl_unique_id(id) < 0) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank 0: %s", sph_last_error()); }
+                    for (int q = 1; q < world; q++) write_all(id_pipe[2 * q + 1], id, 128);       // (zeros on failure: the others fail too)
+                } else if (!read_all(id_pipe[2 * r], id, 128)) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank %d: no RCCL id from rank 0", r); }
+                Gate gate; gate.to_parent = up[2 * r + 1]; gate.from_parent = down[2 * r];
+                if (!rr.rc) rank_main(j, pl, r, world, device0 + r, nullptr, id, gate, rr);
+                else { gate.wait(); gate.wait(); }
+                write_all(out_pipe[2 * r + 1], &rr, sizeof rr);
+                _exit(rr.rc ? 1 : 0);
+            }
+        }
+        for (int round = 0; round < 2; round++) {      // the two barriers of rank_main
+            char b;
+            for (int r = 0; r < world; r++) if (read(up[2 * r], &b, 1) != 1) { fprintf(stderr, "rank %d died\n", r); }
+            for (int r = 0; r < world; r++) if (write(down[2 * r + 1], &b, 1) != 1) {}
+        }
+        for (int r = 0; r < world; r++) { if (!read_all(out_pipe[2 * r], &res[r], sizeof(RankResult))) { res[r].rc = -1; snprintf(res[r].err, sizeof res[r].err, "rank %d: no result", r); } }
+        for (int r = 0; r < world; r++) { int st = 0; waitpid(kids[r], &st, 0); }
+    }
+    double secs = 0.0; uint64_t owned = 0; bool bad = false;
+    for (int r = 0; r < world; r++) {
+        if (res[r].rc) { fprintf(stderr, "%s\n", res[r].err); bad = true; }
+        secs = std::max(secs, res[r].seconds); owned += res[r].owned;
+    }
+    if (bad) return EXIT_FAILURE;
+    if (owned != j.particles) { fprintf(stderr, "the slabs hold %llu of %llu particles\n", (unsigned long long)owned, (unsigned long long)j.particles); return EXIT_FAILURE; }
+    const double avg = secs / (j.iterations > 0 ? j.iterations : 1);
+    printf("particles, Throughput = %.4f KParticles/s, Time = %.5f s, Size = %llu particles, NumDevsUsed = %u, Workgroup = %u\n",
+           (1.0e-3 * (double)j.particles) / avg, avg, (unsigned long long)j.particles, (unsigned)world, 0);
+    printf("{\"particle_steps_per_s\": %.1f, \"particles\": %llu, \"iterations\": %d, \"steps_per_update\": %d, \"seconds\": %.6f, "
+           "\"gpus\": %d, \"ranks_as\": \"%s\", \"ping_us\": [%.1f, %.1f, %.1f]}\n",
+           (double)j.particles * j.iterations * j.substeps / secs, (unsigned long long)j.particles, j.iterations, j.substeps, secs, world,
+           onegpu ? "threads" : "processes", res[0].ping_us[0], res[0].ping_us[1], res[0].ping_us[2]);
+    return 0;
+}
+
+}  // namespace
+
 int main(int argc, char** argv) {
     uint numParticles = 262144;            // NUM_PARTICLES, particleSystem.h:15
     float box = 2.0f;                      // BOX_SIZE
@@ -52,16 +291,41 @@ int main(int argc, char** argv) {
         if (!strcmp(v, "random")) ic = ParticleSystem::CONFIG_RANDOM;
         else if (strcmp(v, "grid")) { fprintf(stderr, "-ic=%s: expected grid or random\n", v); return EXIT_FAILURE; }
     }
-    if (value(argc, argv, "gpus") && atoi(value(argc, argv, "gpus")) > 1) {
-        fprintf(stderr, "-gpus=N>1: one process per GPU -- launch `python bench.py --gpus N` (z-slabs over RCCL)\n");
-        return EXIT_FAILURE;
-    }
+    // -file=<path>: the reference runs ONE update and would compare with a reference file (particles.cpp:690-692, 194-217;
+    // the comparison itself is commented out upstream).  Here the file is a state snapshot (-save): it is loaded like -load.
+    const char* file = value(argc, argv, "file");
+    const char* load = value(argc, argv, "load");
+    if (file && !load) load = file;
+    if (file && !value(argc, argv, "i")) iterations = 1;                    // numIterations = 1, particles.cpp:692
+    // -benchmark selects the headless path upstream (without it a GLUT window opens); this build has no other path
     const bool benchmark = flag(argc, argv, "benchmark");
+    if (!benchmark && !file) fprintf(stderr, "note: no OpenGL in this build -- running headless, as with -benchmark\n");
     if (flag(argc, argv, "help")) {
         printf("usage: sph_headless [-benchmark] [-n=<particles>] [-box=<edge>] [-i=<iterations>] [-device=<id>] [-grid=<cells per axis>] "
-               "[-ic=grid|random] [-steps=<per update>] "
-               "[-dump=<count>] [-log=<file>] [-sphere=<update>[,<radius>]] [-out=<file>] [-save=<file>] [-load=<file>]\n");
+               "[-ic=grid|random] [-steps=<per update>] [-gpus=<N> [-onegpu] [-lattice=nx,ny,nz]] "
+               "[-dump=<count>] [-log=<file>] [-sphere=<update>[,<radius>]] [-out=<file>] [-save=<file>] [-load=<file>] [-file=<file>]\n");
         return 0;
+    }
+    const int gpus = value(argc, argv, "gpus") ? atoi(value(argc, argv, "gpus")) : 1;
+    if (gpus > 1) {
+        if (ic != ParticleSystem::CONFIG_GRID || load || value(argc, argv, "sphere") || value(argc, argv, "save") || value(argc, argv, "log") || dump) {
+            fprintf(stderr, "-gpus=%d runs the dam-break lattice (-ic=grid) and takes -n -box -grid -i -steps -lattice -out -device -onegpu -nowarmup\n", gpus);
+            return EXIT_FAILURE;
+        }
+        SlabJob j{};
+        uint32_t s = (uint32_t)std::floor(std::cbrt((double)numParticles));
+        while ((uint64_t)s * s * s < numParticles) s++;                     // the lattice of reset(CONFIG_GRID)
+        j.lattice[0] = j.lattice[1] = j.lattice[2] = s;
+        j.particles = numParticles;
+        if (const char* v = value(argc, argv, "lattice")) {
+            if (sscanf(v, "%u,%u,%u", &j.lattice[0], &j.lattice[1], &j.lattice[2]) != 3) { fprintf(stderr, "-lattice=nx,ny,nz\n"); return EXIT_FAILURE; }
+            j.particles = (uint64_t)j.lattice[0] * j.lattice[1] * j.lattice[2];
+        }
+        j.box = box;
+        j.grid = gridDim ? gridDim : sph_grid_dim_for_edge(box, 0.1f);
+        j.iterations = iterations; j.substeps = substeps; j.warmup = !flag(argc, argv, "nowarmup"); j.dt = timestep;
+        j.out = value(argc, argv, "out");
+        return run_slabs(j, gpus, flag(argc, argv, "onegpu"), device);
     }
     int is950 = 0;
     if (sph_device_count(&is950) <= 0 || !is950) {
@@ -75,7 +339,7 @@ int main(int argc, char** argv) {
     ParticleSystem* psystem = new ParticleSystem(numParticles, make_float3(box, box, box), ParticleSystem::HIP_PARALLEL,
                                                  uint3{gridDim, gridDim, gridDim});
     psystem->reset(ic);                                   // initParticleSystem, particles.cpp:119-132
-    if (const char* v = value(argc, argv, "load")) {
+    if (const char* v = load) {
         psystem->loadState(v);
         numParticles = (uint)psystem->getNumParticles();  // the snapshot decides how many particles there are
     }
@@ -122,7 +386,6 @@ int main(int argc, char** argv) {
         fclose(f);
     }
     if (const char* v = value(argc, argv, "save")) psystem->saveState(v);
-    (void)benchmark;
     delete psystem;
     return 0;
 }

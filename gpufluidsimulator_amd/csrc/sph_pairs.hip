@@ -281,6 +281,11 @@ constexpr int UNROLL = SPH_DENS_UNROLL;        // density: candidates per unroll
 #ifndef SPH_COLL_EXACT_DIV
 #define SPH_COLL_EXACT_DIV 0
 #endif
+// 1: IEEE divisions in the integrate / collision epilogue as the reference writes them (kernelIntegrate f / rho,
+// particleSystem.cu:375-420; kernelComputeCollisions :299); 0 (product): one v_rcp_f32 each.  A/B knob, see integrate_one.
+#ifndef SPH_EXACT_DIV
+#define SPH_EXACT_DIV 0
+#endif
 // 1: viscosity accumulated as sum w_j v_j and sum w_j (see k_force); 0: as sum w_j (v_j - v_i), for A/B runs
 #ifndef SPH_VISC_SPLIT
 #define SPH_VISC_SPLIT 1
@@ -769,9 +774,15 @@ __device__ __forceinline__ void integrate_one(const Phys& ph, float dt, float4& 
                                               float fy, float fz, float dvx, float dvy, float dvz) {
     fy += ph.gravity_y * rho;
     // one v_rcp_f32 (1 ulp) and three multiplications instead of three IEEE divisions (~10 instructions each): the
-    // acceleration moves by <= 1.5 ulp, five orders below the stated tolerance
+    // acceleration moves by <= 1.5 ulp, five orders below the stated tolerance.  -DSPH_EXACT_DIV=1 builds the reference's
+    // divisions (f / rho here, -dv / (m (1 + count)) in the collision epilogue) for A/B runs of long free trajectories
+    // (profiles/r05_long_run_parity_rcp_vs_exact_div.txt: the two builds leave the oracle at the same step, by the same amount)
+#if SPH_EXACT_DIV
+    float ax = fx / rho, ay = fy / rho, az = fz / rho;
+#else
     const float ir = __builtin_amdgcn_rcpf(rho);
     float ax = fx * ir, ay = fy * ir, az = fz * ir;
+#endif
     vi.x += dt * ax + dvx;
     vi.y += dt * ay + dvy;
     vi.z += dt * az + dvz;
@@ -946,8 +957,13 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
         if (active) {
             float dvx = 0.f, dvy = 0.f, dvz = 0.f;
             if (COLL) {
+#if SPH_EXACT_DIV
+                const float den = ph.mass * (float)(1u + ccount);
+                dvx = -cvx / den; dvy = -cvy / den; dvz = -cvz / den;
+#else
                 const float nid = -__builtin_amdgcn_rcpf(ph.mass * (float)(1u + ccount));       // one v_rcp_f32 for the three components
                 dvx = cvx * nid; dvy = cvy * nid; dvz = cvz * nid;
+#endif
             }
             if (INTEG) {
                 integrate_one(ph, dt, pi, vi, dpi.x, fpx + fvx, fpy + fvy, fpz + fvz, dvx, dvy, dvz);

@@ -178,3 +178,31 @@ def test_snapshot_with_bad_indices_is_rejected():
         st = a.download(index_base=100, count=50)
         assert st["pos"].shape == (50, 3) and np.isfinite(st["pos"]).all()
         assert np.array_equal(st["pos"], pos[100:150])
+
+
+def test_driver_gpus_flag_runs_z_slabs_through_the_c_abi():
+    """-gpus=N (row f1): the driver cuts the dam into N z-slabs and steps them with sph_slab_step.  On this one-GPU box:
+    `-gpus=4 -onegpu` = four threads over the device-to-device transport, result bit for bit the one-device run's and the
+    reference's line with NumDevsUsed = 4; plain `-gpus=2` forks one process per GPU BEFORE touching a GPU and, with one
+    GPU visible, says so and exits non-zero (the RCCL path needs two devices)."""
+    with tempfile.TemporaryDirectory() as d:
+        f1, f4 = os.path.join(d, "one.bin"), os.path.join(d, "four.bin")
+        _run("-benchmark", "-n=32768", "-box=4", "-i=20", "-nowarmup", f"-out={f1}")
+        text = _run("-benchmark", "-n=32768", "-box=4", "-i=20", "-nowarmup", "-gpus=4", "-onegpu", f"-out={f4}")
+        a, b = np.fromfile(f1, dtype=np.float32), np.fromfile(f4, dtype=np.float32)
+    assert "NumDevsUsed = 4" in text and "4 z-slabs" in text and '"ranks_as": "threads"' in text
+    assert a.size == b.size == 2 * 32768 * 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    bad = subprocess.run([EXE, "-benchmark", "-n=32768", "-box=4", "-i=2", "-gpus=2"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "GPUs asked for" in bad.stderr
+
+
+def test_driver_file_flag_is_the_reference_s_one_update_run():
+    """-file=<path> (particles.cpp:690-692): one update unless -i says otherwise; the file is a state snapshot, loaded as
+    -load does."""
+    with tempfile.TemporaryDirectory() as d:
+        snap, a, b = os.path.join(d, "s.sph"), os.path.join(d, "a.bin"), os.path.join(d, "b.bin")
+        _run("-benchmark", "-n=4096", "-box=4", "-i=3", f"-save={snap}")
+        ta = _run("-n=4096", "-box=4", f"-file={snap}", "-nowarmup", f"-out={a}")
+        _run("-benchmark", "-n=4096", "-box=4", "-i=1", f"-load={snap}", "-nowarmup", f"-out={b}")
+        assert "for 1 iterations" in ta
+        assert np.array_equal(np.fromfile(a, dtype=np.uint32), np.fromfile(b, dtype=np.uint32))
