@@ -183,6 +183,72 @@ def cpu_baseline(budget_s=24.0, headline=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# HBM-side traffic of the pair kernels, measured for THIS run: rocprofv3 --pmc passes over a child of this script
+# ---------------------------------------------------------------------------------------------------------------
+def pmc_child(args):
+    """`bench.py --pmc-child <snapshot>` (started under rocprofv3 by pmc_traffic below): the flowing state the parent saved,
+    W + K more steps of it.  Nothing is printed; the profiler's counter CSV is the output."""
+    n, _ = capi.Context.snapshot_info(args.pmc_child)
+    cfg = ic.CONFIGS[args.workload]
+    with capi.Context(n, box=cfg["box"], grid=cfg["grid"], device=0) as c:
+        c.set_precision(args.precision == "mixed")
+        c.load_snapshot(args.pmc_child)
+        c.step(float(ic.DEFAULT_DT), args.warmup + args.steps)
+        c.sync()
+
+
+def pmc_traffic(ctx, args, steps=20, warmup=5, timeout_s=240):
+    """FETCH_SIZE and WRITE_SIZE of k_force<1,1,1> and k_density per launch, measured on the state of this run's timed window:
+    the context is saved to a snapshot, and a child process (this script, --pmc-child) steps it under `rocprofv3 --pmc`,
+    one pass per counter as MI355X_MICROARCH.md prescribes for gfx950 (the two cannot share a pass; --pmc alone, no trace
+    domain).  Reads = FETCH_SIZE x 2 (wide coalesced reads are tallied at half their bytes), both in KB.  Returns
+    ({kernel: bytes per launch}, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    work = tempfile.mkdtemp(prefix="sph_pmc_", dir="/tmp")
+    snap = os.path.join(work, "flow.snap")
+    out = {}
+    try:
+        ctx.save(snap)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-include-regex", "k_force|k_density", "--output-format", "csv", "-d", d, "-o", "p",
+                   "--", sys.executable, os.path.abspath(__file__), "--pmc-child", snap, "--workload", args.workload, "--precision",
+                   args.precision, "--steps", str(steps), "--warmup", str(warmup)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-300:]}"
+            per, name = {}, {}
+            for row in csv.DictReader(open(files[0], newline="")):
+                if row["Counter_Name"] != counter:
+                    continue
+                i = int(row["Dispatch_Id"])
+                per[i] = per.get(i, 0.0) + float(row["Counter_Value"])
+                name[i] = row["Kernel_Name"]
+            for key, pat in (("force_fused", "k_force<"), ("density", "k_density")):       # (sph_step runs only the fused k_force<1,1,1>)
+                ids = sorted(i for i in per if pat in name[i])[-steps:]
+                if not ids:
+                    return None, f"no {pat} dispatch in the {counter} pass"
+                out.setdefault(key, {})[counter] = sum(per[i] for i in ids) / len(ids)
+        res = {k: int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024) for k, v in out.items()}
+        return res, (f"measured in THIS run: the state of the timed window saved to a snapshot and stepped {warmup} + {steps} times by a "
+                     "child of this script under `rocprofv3 --pmc`, one pass each for FETCH_SIZE and WRITE_SIZE (KB; reads = FETCH_SIZE x 2 "
+                     f"per the gfx950 correction), means over the last {steps} launches; fabric requests of the L2s, Infinity-Cache hits "
+                     "included: an upper bound on HBM traffic")
+    except Exception as e:      # noqa: BLE001 -- the bench line must not depend on the profiler
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # single GPU
 # ---------------------------------------------------------------------------------------------------------------
 def _timed(ctx, dt, steps):
@@ -246,6 +312,11 @@ def run_single(args):
     # per-phase device times (HIP events on the library's stream) from a second, instrumented pass over the same regime
     res["phases_ms"] = _phases(ctx, dt, args.steps)
     st = ctx.download(want=("density", "vel") if args.no_cpu else ("density", "vel", "pos"))
+    if not args.no_pmc:                     # counter passes on exactly this state (a child process under rocprofv3)
+        t_p = time.perf_counter()
+        res["pmc"], res["pmc_note"] = pmc_traffic(ctx, args)
+        print(f"[bench] PMC traffic passes: {time.perf_counter() - t_p:.1f} s ({'ok' if res['pmc'] else res['pmc_note']})",
+              file=sys.stderr, flush=True)
     res["finite"] = bool(np.isfinite(st["density"]).all() and np.isfinite(st["vel"]).all())
     res["vmax"] = float(np.abs(st["vel"]).max())
     if not args.no_cpu:                     # the CPU legs step the SAME particles (by creation index) once
@@ -296,12 +367,16 @@ def main():
                     help="mixed = BASELINE config 5's arithmetic (fp32 state, packed-fp16 pair arithmetic and per-row sums in "
                          "the density pass): a separate dtype line, never the fp32 headline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic for this run")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
     ap.add_argument("--one-gpu", action="store_true",
                     help="rehearsal of the multi-rank path on a one-GPU box: every rank uses device 0.  Without a launcher the "
                          "N ranks are N THREADS of this process (--transport local or host; a GPU box admits at most 6 "
                          "processes on its card); under torch.distributed.run they are processes (--transport host)")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
     rank, world, local = _dist_env()
     if args.gpus > 1 and world == 1 and "RANK" not in os.environ and not args.one_gpu:
         # called without a launcher: start one rank per GPU as child processes (nothing has touched the GPU yet)
@@ -325,17 +400,20 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the one
     # profiles/collect_pmc.sh measured for the same workload and state (separate rocprofv3 --pmc passes), and
     # `traffic_source` says so -- it is NOT a measurement of this run
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_density = None, None, None
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
+    if r.get("pmc"):
+        traffic, traffic_density, traffic_source = r["pmc"]["force_fused"], r["pmc"].get("density"), r["pmc_note"]
+    elif os.path.exists(prof):
         try:
             pj = json.load(open(prof))
             if pj.get("workload") == args.workload and pj.get("state") == "flow":
                 traffic = pj.get("force_fused_hbm_bytes_per_launch")
+                traffic_density = pj.get("density_hbm_bytes_per_launch")
                 traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                   f"profiles/collect_pmc.sh ({pj.get('collected', 'date not recorded')}), FETCH_SIZE x 2 + "
                                   "WRITE_SIZE per the gfx950 correction; a constant of an earlier run of this command, not "
-                                  "of this process")
+                                  f"of this process (the live passes were not taken: {r.get('pmc_note', '--no-pmc')})")
         except Exception:
             traffic = None
     # What binds the dominant kernel is VALU issue, not HBM: the instruction counts per wave are SQ
@@ -386,7 +464,9 @@ def main():
                               "achieved_tflops": FLOP_PER_PARTICLE["force_fused"] * n / t_force / 1e12,
                               "peak_tflops": VALU_PEAK_TFLOPS,
                               "frac": FLOP_PER_PARTICLE["force_fused"] * n / t_force / 1e12 / VALU_PEAK_TFLOPS},
+                     "traffic_over_algorithmic": (traffic / (BYTES_PER_PARTICLE["force_fused"] * n)) if traffic else None,
                      "density_kernel": {"achieved": BYTES_PER_PARTICLE["dens"] * n / t_dens / 1e9, "unit": "GB/s",
+                                        "traffic": traffic_density,
                                         "frac": BYTES_PER_PARTICLE["dens"] * n / t_dens / 1e9 / HBM_PEAK_GBS,
                                         "avg_launch_ms": phases_ms["dens"],
                                         "valu_tflops": FLOP_PER_PARTICLE["dens"] * n / t_dens / 1e12},
