@@ -216,9 +216,10 @@ def pmc_traffic(ctx, args, steps=20, warmup=5, timeout_s=240):
     out = {}
     try:
         ctx.save(snap)
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
             d = os.path.join(work, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-include-regex", "k_force|k_density", "--output-format", "csv", "-d", d, "-o", "p",
+            names = [counter] if counter != "SQ" else ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"]
+            cmd = [exe, "--pmc"] + names + ["--kernel-include-regex", "k_force|k_density", "--output-format", "csv", "-d", d, "-o", "p",
                    "--", sys.executable, os.path.abspath(__file__), "--pmc-child", snap, "--workload", args.workload, "--precision",
                    args.precision, "--steps", str(steps), "--warmup", str(warmup)]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
@@ -227,19 +228,22 @@ def pmc_traffic(ctx, args, steps=20, warmup=5, timeout_s=240):
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-300:]}"
             per, name = {}, {}
             for row in csv.DictReader(open(files[0], newline="")):
-                if row["Counter_Name"] != counter:
+                if row["Counter_Name"] not in names:
                     continue
                 i = int(row["Dispatch_Id"])
-                per[i] = per.get(i, 0.0) + float(row["Counter_Value"])
+                per.setdefault(i, {})
+                per[i][row["Counter_Name"]] = per[i].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                 name[i] = row["Kernel_Name"]
             for key, pat in (("force_fused", "k_force<"), ("density", "k_density")):       # (sph_step runs only the fused k_force<1,1,1>)
                 ids = sorted(i for i in per if pat in name[i])[-steps:]
                 if not ids:
                     return None, f"no {pat} dispatch in the {counter} pass"
-                out.setdefault(key, {})[counter] = sum(per[i] for i in ids) / len(ids)
+                for c in names:
+                    out.setdefault(key, {})[c] = sum(per[i].get(c, 0.0) for i in ids) / len(ids)
         res = {k: int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024) for k, v in out.items()}
+        res["sq"] = {k: {c: v[c] for c in v if c.startswith("SQ_")} for k, v in out.items()}
         return res, (f"measured in THIS run: the state of the timed window saved to a snapshot and stepped {warmup} + {steps} times by a "
-                     "child of this script under `rocprofv3 --pmc`, one pass each for FETCH_SIZE and WRITE_SIZE (KB; reads = FETCH_SIZE x 2 "
+                     "child of this script under `rocprofv3 --pmc`, one pass each for FETCH_SIZE, WRITE_SIZE and the SQ_INSTS_* group (KB; reads = FETCH_SIZE x 2 "
                      f"per the gfx950 correction), means over the last {steps} launches; fabric requests of the L2s, Infinity-Cache hits "
                      "included: an upper bound on HBM traffic")
     except Exception as e:      # noqa: BLE001 -- the bench line must not depend on the profiler
@@ -417,13 +421,14 @@ def main():
         except Exception:
             traffic = None
     # What binds the dominant kernel is VALU issue, not HBM: the instruction counts per wave are SQ
-    # counters of an earlier rocprofv3 --pmc run of this command (a PROFILE CONSTANT like `traffic`: this process cannot
-    # read them), the issue fraction prices them against THIS run's launch time
+    # counters -- of this run's own rocprofv3 --pmc child when it ran (pmc_traffic), else of an earlier run of this command
+    # (profiles/*_sq_counters.json) -- and the issue fraction prices them against THIS run's launch time
     issue = None
     sq = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_c3_flow_sq_counters.json"))
-    if sq and args.workload == "C3" and args.precision == "f32":
+    live_sq = (r.get("pmc") or {}).get("sq", {}).get("force_fused")
+    if live_sq or (sq and args.workload == "C3" and args.precision == "f32"):
         try:
-            kj = json.load(open(os.path.join(ROOT, "profiles", sq[-1])))["k_force<true, true, true>"]
+            kj = live_sq or json.load(open(os.path.join(ROOT, "profiles", sq[-1])))["k_force<true, true, true>"]
             waves, clk_ghz, simds = kj["SQ_WAVES"], 2.4, 1024
             issue_s = kj["SQ_INSTS_VALU"] * 2.0 / simds / (clk_ghz * 1e9)      # one fp32 wave-instruction = 2 cycles of a SIMD
             issue = {"valu_insts_per_wave": kj["SQ_INSTS_VALU"] / waves, "lds_insts_per_wave": kj["SQ_INSTS_LDS"] / waves,
@@ -431,8 +436,9 @@ def main():
                      "issue_ms_at_spec_clock": issue_s * 1e3, "issue_frac": issue_s / t_force,
                      "assumes": f"{simds} SIMDs, 2 cycles per fp32 wave-instruction, {clk_ghz} GHz spec clock (the chip holds ~2.0-2.1 "
                                 "GHz at its power cap: the fraction at the held clock is ~1.17x this)",
-                     "source": f"profiles/{sq[-1]}: rocprofv3 --pmc SQ_INSTS_* of profiles/collect_pmc.sh over the timed window of "
-                               "this command; a constant of an earlier run, not of this process"}
+                     "source": ("measured in THIS run: the SQ_INSTS_* pass of the rocprofv3 --pmc child (see traffic_source)" if live_sq else
+                                f"profiles/{sq[-1]}: rocprofv3 --pmc SQ_INSTS_* of profiles/collect_pmc.sh over the timed window of "
+                                "this command; a constant of an earlier run, not of this process")}
         except Exception:
             issue = None
     # a flowing state: no sort of the timed window was skipped, particles changed cell in it, and over the last 1000
