@@ -5,14 +5,14 @@
 # combined with a trace domain), restricted to the step's big kernels; profiles/pmc_summarize.py keeps the dispatches
 # of the timed window and writes profiles/pmc_traffic.json + profiles/<tag>_c3_flow_sq_counters.json.
 set -e
-RUNUP=${1:-6000}; STEPS=${2:-20}; WARM=${3:-5}; TAG=${4:-r04}
+RUNUP=${1:-6000}; STEPS=${2:-20}; WARM=${3:-5}; TAG=${4:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_flow; rm -rf $OUT; mkdir -p $OUT
 KRE='k_force|k_density|k_mm_move|k_cells_build|k_os_pass'
 pass() {   # name, counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-include-regex "$KRE" --output-format csv -d $OUT/$name -o p -- \
-      python bench.py --runup $RUNUP --steps $STEPS --warmup $WARM --no-cpu > $OUT/$name.log 2>&1
+      python bench.py --runup $RUNUP --steps $STEPS --warmup $WARM --no-cpu --no-pmc > $OUT/$name.log 2>&1
   echo "pass $name done: $(grep -c . $OUT/$name/*counter_collection.csv 2>/dev/null || echo 0) rows"
 }
 pass fetch FETCH_SIZE

@@ -1,17 +1,17 @@
 #!/bin/bash
 # Kernel trace of the default bench command (run on the GPU box from the repo root):
 #   bash profiles/collect_trace.sh [tag]      (tag = r04: prefix of the output files)
-# rocprofv3 --kernel-trace --stats over `python bench.py --steps 100 --warmup 20 --no-cpu`; profiles/trace_window.py cuts the
+# rocprofv3 --kernel-trace --stats over `python bench.py --steps 100 --warmup 20 --no-cpu --no-pmc`; profiles/trace_window.py cuts the
 # timed windows out of the trace (bench.py steps the dam 6000 times before it times anything):
 #   steps 6021..6120  the flowing dam, merge sort      -> profiles/${TAG}_c3_flow_kernel_stats.csv
 #   per-dispatch durations of k_force / k_density      -> profiles/${TAG}_c3_outlier_launches.txt (+ the two series as JSON)
 #   steps 6224..6323  the same state, full radix sort   -> profiles/${TAG}_c3_fullsort_kernel_stats.csv
 # and the JSON line the bench printed under the profiler -> profiles/${TAG}_c3_flow_bench_under_rocprof.json
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_trace; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o c3 -- python bench.py --steps 100 --warmup 20 --no-cpu > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o c3 -- python bench.py --steps 100 --warmup 20 --no-cpu --no-pmc > $OUT/bench.log 2>&1
 python - <<PY
 import re
 txt = open("$OUT/bench.log").read()

@@ -12,7 +12,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 root, runup, warm, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-tag = sys.argv[5] if len(sys.argv) > 5 else "r04"
+tag = sys.argv[5] if len(sys.argv) > 5 else "r05"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
