@@ -1224,6 +1224,7 @@ int slab_fail(sph_slab* s, int rc) {
         // the neighbours are about to post theirs, so the abort header travels as THIS step's migrant message -- they
         // read it at this step's wait and stop; nothing else is owed (no header of this rank promised anything)
         g.mig_posted = true;
+        after_main(s);          // (a bounds kernel of this step may be queued on the main stream: it writes the same header words)
         hipLaunchKernelGGL(k_slab_abort_headers, dim3(1), dim3(64), 0, s->comm, s->mig_send[0], s->mig_send[1]);
         const size_t mig_bytes = (size_t)(1 + inl) * rec;
         e = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
