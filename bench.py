@@ -374,6 +374,11 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic for this run")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
+    ap.add_argument("--periodic-z", action="store_true",
+                    help="with --force-slab: ONE slab between its own periodic images (loop transport) -- a middle rank's whole step, "
+                         "halo work included, on one GPU; default lattice 256,256,32 (an eighth of C3)")
+    ap.add_argument("--link-gbs", type=float, default=153.0, help="--periodic-z: bandwidth a message is held back for (0: no hold)")
+    ap.add_argument("--link-latency-us", type=float, default=10.0, help="--periodic-z: latency a message is held back for")
     ap.add_argument("--one-gpu", action="store_true",
                     help="rehearsal of the multi-rank path on a one-GPU box: every rank uses device 0.  Without a launcher the "
                          "N ranks are N THREADS of this process (--transport local or host; a GPU box admits at most 6 "

@@ -138,6 +138,8 @@ SIGNATURES = {
     "sph_local_hub_set_timeout": (C.c_int, [_P, C.c_double]),
     "sph_local_transport_create": (C.c_int, [C.POINTER(C.POINTER(Transport)), _P, C.c_int]),
     "sph_local_transport_destroy": (None, [C.POINTER(Transport)]),
+    "sph_loop_transport_create": (C.c_int, [C.POINTER(C.POINTER(Transport)), C.c_float, C.c_double, C.c_double]),
+    "sph_loop_transport_destroy": (None, [C.POINTER(Transport)]),
     # include/particleSystem.h: host-only twins of ic.py (used by the C++ class's reset())
     "sph_ic_dam_break": (None, [C.POINTER(_U32), C.POINTER(C.c_float), C.c_int, C.c_uint64, C.c_uint64, _P, _P]),
     "sph_ic_random_box": (None, [C.c_uint64, C.POINTER(C.c_float), C.c_float, _U32, C.c_float, _P, _P]),

@@ -447,6 +447,26 @@ __global__ void k_recut_counts_out(float4* __restrict__ out_lo, float4* __restri
     if (threadIdx.x == 1) out_hi[0] = make_float4(__uint_as_float(up), 0.f, 0.f, 0.f);
 }
 
+// ---- loop transport (sph_loop_transport_create): ONE slab whose two neighbours are its own periodic images ------------
+// what leaves through the top comes back in at the bottom, shifted down by the slab's height, and the other way round:
+// records carry a position float4 at every even float4 index (z = component 2); the (rho, p) message is a plain copy
+__global__ __launch_bounds__(256) void k_loop_copy(const float4* __restrict__ up_src, float4* __restrict__ lo_dst, uint32_t n_up,
+                                                   const float4* __restrict__ down_src, float4* __restrict__ hi_dst, uint32_t n_down,
+                                                   uint32_t first_record4, float shift, int shift_z) {
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_up + n_down; t += gridDim.x * 256u) {
+        const bool up = t < n_up;                            // sent upwards: arrives from below, one slab height lower
+        const uint32_t i = up ? t : t - n_up;
+        float4 v = up ? up_src[i] : down_src[i];
+        if (shift_z && i >= first_record4 && ((i - first_record4) & 1u) == 0u) v.z += up ? -shift : shift;
+        (up ? lo_dst : hi_dst)[i] = v;
+    }
+}
+// what a message of that size would spend on a link: a one-wave spin on the 100 MHz wall clock
+__global__ void k_loop_delay(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // ---- neighbour ping (sph_slab_ping): a message whose every word says who sent it, towards which side, in which round --
 __device__ __forceinline__ uint32_t ping_word(uint32_t rank, uint32_t side, uint32_t rep, uint32_t i) {
     uint32_t x = (rank * 2u + side) * 0x9E3779B9u + rep * 0x85EBCA6Bu + i;
@@ -664,6 +684,34 @@ int local_exchange(void* self, int tag, const void* send_lo, size_t send_lo_byte
     return SPH_OK;
 }
 
+}  // namespace
+
+namespace {
+struct LoopEnd { float shift; double gbs, latency_us; };
+
+int loop_exchange(void* self, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
+                  const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes, void* stream) {
+    LoopEnd* E = (LoopEnd*)self;
+    hipStream_t st = (hipStream_t)stream;
+    SPH_REQUIRE(send_hi_bytes == recv_lo_bytes && send_lo_bytes == recv_hi_bytes, SPH_E_STATE,
+                "loop transport (tag %d): what goes up (%zu bytes) is not what is expected from below (%zu), or down %zu / from above %zu: "
+                "the two ends of a link disagree on a message size", tag, send_hi_bytes, recv_lo_bytes, send_lo_bytes, recv_hi_bytes);
+    SPH_REQUIRE((send_hi_bytes | send_lo_bytes) % 16 == 0, SPH_E_INVALID, "loop transport: messages are whole float4s");
+    if (E->latency_us > 0.0 || E->gbs > 0.0) {           // both links carry their message at the same time
+        const size_t big = send_hi_bytes > send_lo_bytes ? send_hi_bytes : send_lo_bytes;
+        const double us = E->latency_us + (E->gbs > 0.0 ? (double)big / (E->gbs * 1e3) : 0.0);
+        hipLaunchKernelGGL(k_loop_delay, dim3(1), dim3(1), 0, st, (unsigned long long)(us * 100.0));
+    }
+    const uint32_t n_up = (uint32_t)(send_hi_bytes / 16), n_down = (uint32_t)(send_lo_bytes / 16);
+    if (n_up + n_down) {
+        const bool recs = tag == SPH_TAG_MIGRANTS || tag == SPH_TAG_MIGRANTS_REST || tag == SPH_TAG_HALO_A;
+        hipLaunchKernelGGL(k_loop_copy, dim3(min(ceil_div(n_up + n_down, 256u), 2048u)), dim3(256), 0, st, (const float4*)send_hi,
+                           (float4*)recv_lo, n_up, (const float4*)send_lo, (float4*)recv_hi, n_down, tag == SPH_TAG_MIGRANTS ? 2u : 0u,
+                           E->shift, recs ? 1 : 0);
+        SPH_HIP(hipGetLastError());
+    }
+    return SPH_OK;
+}
 }  // namespace
 
 struct sph_slab {
@@ -1386,6 +1434,26 @@ int sph_local_hub_set_timeout(sph_local_hub* H, double seconds) {
     SPH_REQUIRE(H && seconds > 0.0, SPH_E_INVALID, "bad argument");
     H->timeout_s = seconds;
     return SPH_OK;
+}
+
+int sph_loop_transport_create(sph_transport** out, float z_shift, double link_gbs, double latency_us) {
+    SPH_REQUIRE(out && z_shift > 0.f && link_gbs >= 0.0 && latency_us >= 0.0, SPH_E_INVALID, "bad argument");
+    *out = nullptr;
+    LoopEnd* E = new (std::nothrow) LoopEnd{z_shift, link_gbs, latency_us};
+    sph_transport* t = new (std::nothrow) sph_transport();
+    if (!E || !t) { delete E; delete t; set_error("out of host memory"); return SPH_E_NOMEM; }
+    t->self = E;
+    t->exchange = loop_exchange;
+    t->host_buffers = 0;
+    t->abort = nullptr;
+    *out = t;
+    return SPH_OK;
+}
+
+void sph_loop_transport_destroy(sph_transport* t) {
+    if (!t) return;
+    delete (LoopEnd*)t->self;
+    delete t;
 }
 
 int sph_local_transport_create(sph_transport** out, sph_local_hub* hub, int rank) {

@@ -981,12 +981,116 @@ def bench_rank(comm, local, args, transport, log=None):
     return out, (strict_flow and out is not None and not out["flowing"])
 
 
+def bench_periodic(args):
+    """`bench.py --force-slab --periodic-z [--lattice nx,ny,nz]`: ONE slab between its own periodic images (the loop
+    transport, sph_loop_transport_create): the stand-in for a MIDDLE rank of an N-GPU run that a one-GPU box allows.  The
+    slab does everything a rank between two neighbours does -- migrants, halo A and halo B at their real sizes, ghost unpack,
+    the boundary layers' launches, the host wait -- with the device to itself; every message is held back on the comm stream by
+    --link-latency-us + bytes / --link-gbs (a PARAMETER: 153 GB/s is one xGMI link's figure, not a measurement).  Default
+    lattice 256,256,32: an eighth of config 3, the metric's 8-GPU point."""
+    import ctypes as C
+
+    import torch  # noqa: F401
+    L = capi.load()
+    cfg = ic.CONFIGS[getattr(args, "workload", "C3") or "C3"]
+    nx, ny, nz = (int(v) for v in (args.lattice or "256,256,32").split(","))
+    assert nz % 2 == 0 and nz >= 8, "whole cell layers, at least four of them"
+    layers = nz // 2                                   # two lattice planes per cell layer (spacing 1/32, cells 1/16)
+    z_lo, z_hi = layers, 2 * layers                    # away from the box's z faces: ghost layers on both sides
+    box, grid = cfg["box"], cfg["grid"]
+    assert z_hi + 1 < grid[2]
+    n = nx * ny * nz
+    edge = float(box[2]) / grid[2]
+    params = capi.default_params(box, grid)
+    per_layer = 2 * nx * ny
+    ctx = capi.Context(int(1.5 * n) + 4096, params=params, device=0, slab=(z_lo, z_hi), ghost_capacity=3 * per_layer + 1024)
+    ctx.set_precision(getattr(args, "precision", "f32") == "mixed")
+    ctx.reset_lattice((nx, ny, 2 * nz), jitter=True, jitter_dims=box, start=n, count=n)      # the planes of layers [z_lo, z_hi)
+    tr = C.POINTER(capi.Transport)()
+    capi._check(L.sph_loop_transport_create(C.byref(tr), layers * edge, float(args.link_gbs), float(args.link_latency_us)))
+    h = C.c_void_p()
+    capi._check(L.sph_slab_create(C.byref(h), ctx.h, 1, 3, tr, 0))
+    dt = float(ic.DEFAULT_DT)
+    step = lambda k: capi._check(L.sph_slab_step(h, dt, int(k)))          # noqa: E731
+    sync = lambda: capi._check(L.sph_slab_sync(h))                        # noqa: E731
+
+    def timing():
+        w = (C.c_double * 22)()
+        capi._check(L.sph_slab_timing_get(h, w))
+        k = max(w[0], 1.0)
+        out = {"steps": int(w[0]), "waits_ready": int(w[1])}
+        for i, name in enumerate(("host_wait_us", "host_pre_us", "host_post_us", "host_step_us")):
+            out[name] = {"mean": w[2 + 2 * i] / k, "max": w[3 + 2 * i]}
+        for g, name in enumerate(_GROUPS):
+            c = w[10 + 3 * g]
+            out["exchange_us_" + name] = {"calls": int(c), "mean": w[11 + 3 * g] / c if c else None, "max": w[12 + 3 * g]}
+        return out
+
+    runup = 6000 if args.runup is None else args.runup
+    tail = min(1000, runup)
+    t0 = time.perf_counter()
+    step(runup - tail); sync()
+    q0, t_tail = ctx.sort_stats(), time.perf_counter()
+    step(tail); sync()
+    tail_wall = time.perf_counter() - t_tail
+    q1 = ctx.sort_stats()
+    print(f"[bench] periodic slab: run-up {runup} steps in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+    step(args.warmup); sync()
+    capi._check(L.sph_slab_timing_reset(h))
+    s0 = ctx.sort_stats()
+    t0 = time.perf_counter()
+    step(args.steps); sync()
+    wall = time.perf_counter() - t0
+    s1 = ctx.sort_stats()
+    host_t = timing()
+    ctx.timing(True); ctx.timing_reset()
+    capi._check(L.sph_slab_timing_reset(h)); capi._check(L.sph_slab_timing_enable(h, 1))
+    probe = max(2, min(args.steps, 50))
+    step(probe); sync()
+    ph, _ = ctx.timing_get()
+    ctx.timing(False)
+    probe_t = timing()
+    capi._check(L.sph_slab_timing_enable(h, 0))
+    stats = (C.c_uint64 * 8)()
+    capi._check(L.sph_slab_counters(h, stats))
+    owned = ctx.n
+    st = ctx.download(index_base=n, count=n, want=("density", "vel"))
+    finite = bool(np.isfinite(st["density"]).all() and np.isfinite(st["vel"]).all())
+    out = {
+        "metric": "particle-steps/sec (ONE slab between its periodic images: a middle rank's step, not a whole job)",
+        "value": n * args.steps / wall, "unit": "particle-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "ms_per_step_sustained": tail_wall / max(tail, 1) * 1e3,
+        "higher_is_better": True, "scaling": "n/a", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"dam-break slice {nx}x{ny}x{nz} = {n} particles on cell layers [{z_lo}, {z_hi}) of the {grid[2]}-layer grid, "
+                               f"periodic images along z through the loop transport (shift {layers * edge}); every message held back by "
+                               f"{args.link_latency_us} us + bytes / {args.link_gbs} GB/s; timed after {runup} run-up steps",
+                   "particles": n, "link_gbs": float(args.link_gbs), "link_latency_us": float(args.link_latency_us), "runup_steps": runup,
+                   "movers_per_step": (s1["movers_total"] - s0["movers_total"]) / max(args.steps, 1),
+                   "movers_per_step_runup_tail": (q1["movers_total"] - q0["movers_total"]) / max(tail, 1)},
+        "phases_ms": {k: v / probe for k, v in ph.items()}, "probe_steps": probe,
+        "host_wait_us": host_t["host_wait_us"], "waits_ready_frac": host_t["waits_ready"] / max(host_t["steps"], 1),
+        "host_step_us": {k: host_t[k] for k in ("host_pre_us", "host_post_us", "host_step_us")},
+        "exchange_us": {g: probe_t["exchange_us_" + g] for g in _GROUPS},
+        "slab_counters": dict(zip(("steps", "migrants", "resorts", "ghosts", "host_waits", "in_place_merges", "far_steps", "rest_messages"),
+                                  (int(v) for v in stats))),
+        "owned": int(owned), "finite": finite, "roofline": None, "cpu_baseline": None,
+    }
+    L.sph_slab_destroy(h)
+    L.sph_loop_transport_destroy(tr)
+    ctx.close()
+    print(json.dumps(out), flush=True)
+    if owned != n or not finite:
+        sys.exit(f"bench: the periodic slab holds {owned} of {n} particles (finite: {finite})")
+
+
 def bench_main(args):
     """bench.py --gpus N.  Under torch.distributed.run: one process per rank (RCCL, or gloo with --transport host).
     `--one-gpu` WITHOUT a launcher: the N ranks run as N threads of this one process on device 0 (a GPU box admits at
     most 6 processes on its card, so an 8-rank rehearsal cannot be 8 processes)."""
     import torch
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if getattr(args, "periodic_z", False):
+        return bench_periodic(args)
     transport = getattr(args, "transport", "rccl")
     launched = "RANK" in os.environ
     if getattr(args, "one_gpu", False) and not launched and args.gpus > 1:

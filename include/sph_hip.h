@@ -321,6 +321,17 @@ int sph_local_hub_set_timeout(sph_local_hub* hub, double seconds);
 int sph_local_transport_create(sph_transport** out, sph_local_hub* hub, int rank);
 void sph_local_transport_destroy(sph_transport* t);
 
+/* Loop transport: ONE slab whose two neighbours are its own periodic images along z -- what it sends up arrives from below
+ * with every position shifted down by `z_shift` (the height of the slab's owned layers), and the other way round.  The slab is
+ * created as the middle rank of three (sph_slab_create(..., rank 1, world 3, ...)) on cell layers away from the box's z faces
+ * and then does ALL the work of a rank between two neighbours -- migrants, both halo messages at their real sizes, ghost
+ * unpack, boundary launches, the host wait -- on one device, with nothing else sharing it: the measured stand-in for a middle
+ * rank of an N-GPU run that a one-GPU box allows (`bench.py --force-slab --periodic-z`).  Every message is held back by
+ * latency_us + bytes / link_gbs (0 / 0: no delay) on the comm stream before it is delivered: the link is a parameter, not a
+ * measurement.  sph_slab_ping does not apply (a slab cannot tell its images apart). */
+int sph_loop_transport_create(sph_transport** out, float z_shift, double link_gbs, double latency_us);
+void sph_loop_transport_destroy(sph_transport* t);
+
 typedef struct sph_slab sph_slab;
 /* Bind a slab context (sph_create_slab, particles uploaded) to its place in the chain of `world` slabs.  The halo
  * capacity is the context's ghost capacity; migrant_capacity (records per side and step, 0 = half the ghost capacity)

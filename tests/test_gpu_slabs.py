@@ -769,3 +769,55 @@ def test_recut_by_several_layers_in_hops_and_into_an_empty_slab():
         assert all(o[1][k][2] == cuts for o in out) and sum(o[1][k][1] for o in out) == pos.shape[0]
     assert sum(o[3][1] for o in out) > pos.shape[0] // 2 and max(o[3][0] for o in out) >= len(plans)     # whole layers moved, in several hops
     assert all(o[4]["host_waits"] == o[4]["steps"] + o[4]["far_steps"] for o in out)
+
+
+def test_one_slab_between_its_periodic_images_matches_three_stacked_copies():
+    """The loop transport (sph_loop_transport_create; `bench.py --force-slab --periodic-z`): one slab whose neighbours are its own
+    images shifted by the slab height does ALL the work of a rank between two neighbours -- migrants in both directions,
+    both halo messages, ghost unpack, boundary launches -- on one device.  Physics check: the same slice stacked THREE times
+    in one whole-domain context; for a few steps (before the free outer faces of the outer copies are felt: one cell layer
+    per step) the middle copy lives between two copies of itself, i.e. in the periodic slab's world.  Positions modulo the
+    slab height, velocities and densities agree to rounding (the images are shifted positions, the copies evolve on their
+    own: not the same bits)."""
+    import ctypes as C
+    box, grid, layers = (4.0, 4.0, 4.0), (64, 64, 64), 8
+    H = np.float32(layers * 4.0 / 64)                                     # 0.5
+    nx = ny = 12
+    nz = 2 * layers
+    n = nx * ny * nz
+    P, _ = ic.dam_break_lattice((nx, ny, 64), box, jitter=True, start=nx * ny * 48, count=n)      # cell layers 24 .. 31
+    rng = np.random.default_rng(8)
+    V = np.zeros_like(P)
+    V[:, 2] = rng.uniform(-12000, 12000, n).astype(np.float32)
+    steps = 5
+    z_lo, z_hi = 24, 32
+    L = capi.load()
+    with capi.Context(2 * n + 1024, params=capi.default_params(box, grid), slab=(z_lo, z_hi), ghost_capacity=4 * nx * ny + 1024) as c:
+        c.upload(P, V)
+        tr = C.POINTER(capi.Transport)()
+        capi._check(L.sph_loop_transport_create(C.byref(tr), float(H), 0.0, 0.0))
+        h = C.c_void_p()
+        capi._check(L.sph_slab_create(C.byref(h), c.h, 1, 3, tr, 0))
+        try:
+            capi._check(L.sph_slab_step(h, DT, steps))
+            capi._check(L.sph_slab_sync(h))
+            cnt = (C.c_uint64 * 8)()
+            capi._check(L.sph_slab_counters(h, cnt))
+            got = c.download(count=n)
+            owned, exchanges = c.n, int(L.sph_slab_exchanges(h))
+        finally:
+            L.sph_slab_destroy(h)
+            L.sph_loop_transport_destroy(tr)
+    assert owned == n and int(cnt[1]) > 0 and int(cnt[4]) == steps            # nobody lost, some wrapped around, one wait per step
+    assert exchanges == 3 * steps + int(cnt[7])
+    lo, hi = P.copy(), P.copy()
+    lo[:, 2] = P[:, 2] - H; hi[:, 2] = P[:, 2] + H                        # the images' fp32 positions, as the transport makes them
+    ref = _whole_domain(np.concatenate([lo, P, hi]), np.concatenate([V, V, V]), box, grid, steps)
+    mid = slice(n, 2 * n)
+    zb = np.float32(-2.0 + z_lo * 0.0625)
+    wrap = lambda z: np.mod(z - zb, H)                                    # noqa: E731
+    dz = np.abs(wrap(got["pos"][:, 2]) - wrap(ref["pos"][mid, 2]))
+    dz = np.minimum(dz, H - dz)
+    assert np.abs(got["pos"][:, :2] - ref["pos"][mid, :2]).max() <= 1e-6 * 4.0 and dz.max() <= 1e-6 * 4.0
+    assert np.abs(got["vel"] - ref["vel"][mid]).max() <= 1e-5 * np.abs(ref["vel"]).max()
+    assert np.abs(got["density"] / ref["density"][mid] - 1).max() <= 1e-5
