@@ -696,15 +696,20 @@ int loop_exchange(void* self, int tag, const void* send_lo, size_t send_lo_bytes
     SPH_REQUIRE(send_hi_bytes == recv_lo_bytes && send_lo_bytes == recv_hi_bytes, SPH_E_STATE,
                 "loop transport (tag %d): what goes up (%zu bytes) is not what is expected from below (%zu), or down %zu / from above %zu: "
                 "the two ends of a link disagree on a message size", tag, send_hi_bytes, recv_lo_bytes, send_lo_bytes, recv_hi_bytes);
-    SPH_REQUIRE((send_hi_bytes | send_lo_bytes) % 16 == 0, SPH_E_INVALID, "loop transport: messages are whole float4s");
     if (E->latency_us > 0.0 || E->gbs > 0.0) {           // both links carry their message at the same time
         const size_t big = send_hi_bytes > send_lo_bytes ? send_hi_bytes : send_lo_bytes;
         const double us = E->latency_us + (E->gbs > 0.0 ? (double)big / (E->gbs * 1e3) : 0.0);
         hipLaunchKernelGGL(k_loop_delay, dim3(1), dim3(1), 0, st, (unsigned long long)(us * 100.0));
     }
+    const bool recs = tag == SPH_TAG_MIGRANTS || tag == SPH_TAG_MIGRANTS_REST || tag == SPH_TAG_HALO_A;
+    if (!recs) {                                          // (rho, p) pairs, pings: bytes as they are
+        if (send_hi_bytes) SPH_HIP(hipMemcpyAsync(recv_lo, send_hi, send_hi_bytes, hipMemcpyDeviceToDevice, st));
+        if (send_lo_bytes) SPH_HIP(hipMemcpyAsync(recv_hi, send_lo, send_lo_bytes, hipMemcpyDeviceToDevice, st));
+        return SPH_OK;
+    }
+    SPH_REQUIRE((send_hi_bytes | send_lo_bytes) % 32 == 0, SPH_E_INVALID, "loop transport: a particle message is made of 32-byte records");
     const uint32_t n_up = (uint32_t)(send_hi_bytes / 16), n_down = (uint32_t)(send_lo_bytes / 16);
     if (n_up + n_down) {
-        const bool recs = tag == SPH_TAG_MIGRANTS || tag == SPH_TAG_MIGRANTS_REST || tag == SPH_TAG_HALO_A;
         hipLaunchKernelGGL(k_loop_copy, dim3(min(ceil_div(n_up + n_down, 256u), 2048u)), dim3(256), 0, st, (const float4*)send_hi,
                            (float4*)recv_lo, n_up, (const float4*)send_lo, (float4*)recv_hi, n_down, tag == SPH_TAG_MIGRANTS ? 2u : 0u,
                            E->shift, recs ? 1 : 0);

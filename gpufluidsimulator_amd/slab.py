@@ -531,6 +531,23 @@ class SlabSimulation:
 # ------------------------------------------------------------------------------------------------
 # the native step: csrc/sph_slab.hip under the C ABI (sph_slab_step); Python is launcher and set-up only
 # ------------------------------------------------------------------------------------------------
+def slab_timing_dict(slab_handle):
+    """sph_slab_timing_get of an `sph_slab*` as a dict (microseconds): host_wait / host_pre / host_post / host_step {mean, max}
+    over the steps since the last reset, waits_ready (the header was there before the host looked: host-paced steps), and per
+    message group {calls, mean, max} of the event pairs on the comm stream (only while sph_slab_timing_enable)."""
+    import ctypes as C
+    w = (C.c_double * 22)()
+    capi._check(capi.load().sph_slab_timing_get(slab_handle, w))
+    n = max(w[0], 1.0)
+    out = {"steps": int(w[0]), "waits_ready": int(w[1])}
+    for k, name in enumerate(("host_wait_us", "host_pre_us", "host_post_us", "host_step_us")):
+        out[name] = {"mean": w[2 + 2 * k] / n, "max": w[3 + 2 * k]}
+    for g, name in enumerate(("migrants", "halo_a", "halo_b", "migrants_rest")):
+        c = w[10 + 3 * g]
+        out["exchange_us_" + name] = {"calls": int(c), "mean": w[11 + 3 * g] / c if c else None, "max": w[12 + 3 * g]}
+    return out
+
+
 def host_transport(comm):
     """A `sph_transport` that moves the library's pinned HOST staging buffers through `comm.exchange`
     (LocalComm: several slabs of one GPU in one process; TorchDistComm over gloo: several processes on one
@@ -660,22 +677,10 @@ class NativeSlabSimulation(SlabSimulation):
         return out
 
     def slab_timing(self, reset=False):
-        """sph_slab_timing_get as a dict (microseconds): host_wait / host_pre / host_post / host_step {mean, max} over
-        the steps since the last reset, waits_ready (the header was there before the host looked: host-paced steps),
-        and per message group {calls, mean, max} of the event pairs on the comm stream (only while enabled)."""
-        import ctypes as C
-        L = capi.load()
-        w = (C.c_double * 22)()
-        capi._check(L.sph_slab_timing_get(self._slab, w))
-        n = max(w[0], 1.0)
-        out = {"steps": int(w[0]), "waits_ready": int(w[1])}
-        for k, name in enumerate(("host_wait_us", "host_pre_us", "host_post_us", "host_step_us")):
-            out[name] = {"mean": w[2 + 2 * k] / n, "max": w[3 + 2 * k]}
-        for g, name in enumerate(("migrants", "halo_a", "halo_b", "migrants_rest")):
-            c = w[10 + 3 * g]
-            out["exchange_us_" + name] = {"calls": int(c), "mean": w[11 + 3 * g] / c if c else None, "max": w[12 + 3 * g]}
+        """sph_slab_timing_get as a dict, see slab_timing_dict."""
+        out = slab_timing_dict(self._slab)
         if reset:
-            capi._check(L.sph_slab_timing_reset(self._slab))
+            capi._check(capi.load().sph_slab_timing_reset(self._slab))
         return out
 
     def slab_timing_enable(self, on=True):
@@ -1014,17 +1019,7 @@ def bench_periodic(args):
     step = lambda k: capi._check(L.sph_slab_step(h, dt, int(k)))          # noqa: E731
     sync = lambda: capi._check(L.sph_slab_sync(h))                        # noqa: E731
 
-    def timing():
-        w = (C.c_double * 22)()
-        capi._check(L.sph_slab_timing_get(h, w))
-        k = max(w[0], 1.0)
-        out = {"steps": int(w[0]), "waits_ready": int(w[1])}
-        for i, name in enumerate(("host_wait_us", "host_pre_us", "host_post_us", "host_step_us")):
-            out[name] = {"mean": w[2 + 2 * i] / k, "max": w[3 + 2 * i]}
-        for g, name in enumerate(_GROUPS):
-            c = w[10 + 3 * g]
-            out["exchange_us_" + name] = {"calls": int(c), "mean": w[11 + 3 * g] / c if c else None, "max": w[12 + 3 * g]}
-        return out
+    timing = lambda: slab_timing_dict(h)                                  # noqa: E731
 
     runup = 6000 if args.runup is None else args.runup
     tail = min(1000, runup)
