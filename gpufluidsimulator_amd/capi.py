@@ -119,6 +119,8 @@ SIGNATURES = {
     "sph_slab_ping": (C.c_int, [_P, C.c_size_t, _U32, C.POINTER(C.c_double)]),
     "sph_slab_recut": (C.c_int, [_P, _U32, _U32]),
     "sph_slab_recut_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "sph_slab_set_early_force": (C.c_int, [_P, C.c_int]),
+    "sph_slab_early_force_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "sph_slab_timing_enable": (C.c_int, [_P, C.c_int]),
     "sph_slab_timing_reset": (C.c_int, [_P]),
     "sph_slab_timing_get": (C.c_int, [_P, C.POINTER(C.c_double)]),

@@ -206,6 +206,7 @@ int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt)
 int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi);
 int launch_density_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi);   // [lo, hi) minus the hole
 int launch_density_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count);            // range in device memory
+int launch_force_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count, float dt);   // fused pass, range in device memory
 int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, uint32_t hole_hi, bool force, bool collide,
                       bool integrate, float dt, bool mark);
 bool force_begin(sph_ctx* c, bool integrate);

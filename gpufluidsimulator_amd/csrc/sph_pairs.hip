@@ -838,6 +838,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     // 8-entry (one cell) distance between the lane groups of a wave is 80 dwords = 16 banks, so the four
     // distinct addresses of a half-wave never share a bank.
     __shared__ float2 s_e[LDS_ENT * 5];
+    // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
+    if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)PAIR_THREADS >= tg.dev[1]) return;
     for (uint32_t k = threadIdx.x; k < LDS_ENT * 5; k += PAIR_THREADS)   // see LDS_ENT: keep over-reads finite
         s_e[k] = make_float2(0.f, 0.f);
     __syncthreads();
@@ -1157,6 +1159,20 @@ int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, ui
         return SPH_E_INVALID;
     }
 #undef SPH_LAUNCH_FORCE
+    SPH_HIP(hipGetLastError());
+    return SPH_OK;
+}
+
+// The fused force pass over the slots [range_dev[0], range_dev[1]) -- two words of DEVICE memory written by an earlier kernel
+// of the stream -- for the slab step's early launch (csrc/sph_slab.hip): at most max_count slots size the grid, waves beyond
+// the range leave at once.  The next step's cell keys go to keyS2 by ABSOLUTE slot (the owned range does not have its
+// final start yet) and no movers are marked: k_slab_early_finish does both later.
+int launch_force_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count, float dt) {
+    if (max_count == 0) return SPH_OK;
+    const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev, c->direct_hull, BlockOrder{0u, 0u, 0u, 0u, 0u}};
+    hipLaunchKernelGGL((k_force<true, true, true>), dim3(ceil_div(max_count, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi, c->velr,
+                       c->dp, c->cw, c->keyS, c->cells, c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out,
+                       c->keyS2, (uint64_t*)nullptr, c->mm_tile_cnt, tg, 0u, dt, c->grid, c->phys);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
 }

@@ -64,13 +64,14 @@ enum {
     HL_SEQ = 16,      // written last: the step number
     HL_ERR = 17,      // [17..18] sticky error words set by device-side checks (plain stores of 1): SLAB_ERR_*
     HL_NEAR = 20,     // [20..21] first slot of local layer 3 / of local layer zl-3 (ABSOLUTE): the layers next to the deep interior
+    HL_EARLY = 22,    // [22..23] the slots whose force pass may run in front of the wait: local layers [6, zl-6) (ABSOLUTE; empty: equal)
     HL_RECUT = 24,    // [24..25] sph_slab_recut: particles that go down / up ; [26..27] what the neighbours send (from below, from above)
     HL_WORDS = 32
 };
 enum { SLAB_ERR_INSERT_LAYER = 0, SLAB_ERR_ARRIVAL_OUTSIDE = 1 };
 // device words (sph_slab::d_lb): [0..3] bounds, [4..5] deep range (absolute), [6..7] far counts, [8..10] the
 // fused kernel's block counters {far down, far up, blocks done}
-enum { DL_DEEP = 4, DL_FAR = 6, DL_CTR = 8, DL_NEAR = 12, DL_PING = 14, DL_WORDS = 16 };
+enum { DL_DEEP = 4, DL_FAR = 6, DL_CTR = 8, DL_NEAR = 12, DL_PING = 14, DL_EARLY = 16, DL_WORDS = 24 };
 
 constexpr uint32_t MIG_INLINE = 255;   // leavers per side that ride in the first (fixed-size, 8 KB) migrant message
 
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
                                                           uint32_t layer, uint32_t cap, GridDesc g,
                                                           uint32_t* __restrict__ dl, float4* __restrict__ out_lo,
                                                           float4* __restrict__ out_hi) {
-    __shared__ uint32_t s_lb[8];
+    __shared__ uint32_t s_lb[12];
     __shared__ uint32_t s_last;
     const uint32_t zl = g.zl;
     {
@@ -134,10 +135,14 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
         // without waiting for the deep launch (the host checks that it really stays inside: targets 6 and 7)
         const uint32_t d0 = min(4u, zl - 1u), d1 = zl >= 8u ? zl - 4u : d0;
         const uint32_t e0 = min(3u, zl - 1u), e1 = zl >= 6u ? zl - 3u : e0;
-        const uint32_t targets[8] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer, d0 * layer, max(d1, d0) * layer,
-                                     e0 * layer, max(e1, e0) * layer};
+        // [8..10]: the EARLY force range, local layers [6, zl-6) -- particles whose 27 cells lie in layers 5 .. zl-6, all of
+        // whose densities the deep launch (layers >= 4, from a chunk boundary inside layer 4) has written: their force pass
+        // needs nothing that comes over a link or moves before it.  [10] = first slot of layer 5, to check exactly that.
+        const uint32_t f0 = min(6u, zl - 1u), f1 = zl >= 13u ? zl - 6u : f0;
+        const uint32_t targets[11] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer, d0 * layer, max(d1, d0) * layer,
+                                      e0 * layer, max(e1, e0) * layer, f0 * layer, max(f1, f0) * layer, min(5u, zl - 1u) * layer};
         const uint32_t wave = threadIdx.x >> 6;
-        for (uint32_t t = wave; t < 8u; t += 4u) {                          // wave w: targets w and w + 4
+        for (uint32_t t = wave; t < 11u; t += 4u) {                         // wave w: targets w, w + 4, w + 8
             const uint32_t r = wave_lower_bound(keys, n, targets[t]);
             if ((threadIdx.x & 63u) == 0u) s_lb[t] = r;
         }
@@ -186,6 +191,31 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     dl[DL_DEEP + 1] = own_off + max(s_lb[5], deep0);
     dl[DL_FAR] = far_lo; dl[DL_FAR + 1] = far_hi;
     dl[DL_NEAR] = own_off + s_lb[6]; dl[DL_NEAR + 1] = own_off + max(s_lb[7], s_lb[6]);
+    {   // empty unless every slot of layer 5 (and so of every layer up to zl-6) lies inside the deep range
+        const bool ok = zl >= 13u && s_lb[10] >= deep0 && s_lb[9] <= max(s_lb[5], deep0) && s_lb[9] > s_lb[8];
+        dl[DL_EARLY] = own_off + s_lb[8];
+        dl[DL_EARLY + 1] = own_off + (ok ? s_lb[9] : s_lb[8]);
+    }
+}
+
+// The early force launch (slab_step_body) ran before the owned range had its final start, so it left the next step's cell
+// keys in a scratch array by ABSOLUTE slot and marked no movers.  This pass, over whole 64-slot chunks of the final owned
+// range, puts the keys where the sort reads them and writes the chunks' mover bits (as the fused epilogue of k_force does).
+__global__ __launch_bounds__(256) void k_slab_early_finish(const uint32_t* __restrict__ key_abs, const uint32_t* __restrict__ keyS,
+                                                           uint32_t lo, uint32_t hi, uint32_t slot0, uint32_t* __restrict__ keys_out,
+                                                           uint64_t* __restrict__ mm_mask, uint32_t* __restrict__ mm_tile_cnt) {
+    const uint32_t i = lo + blockIdx.x * 256u + threadIdx.x;             // (lo - slot0 and hi - lo are multiples of 64)
+    if (i >= hi) return;
+    const uint32_t key = key_abs[i];
+    keys_out[i - slot0] = key;
+    if (mm_mask) {
+        const uint64_t m = __ballot(key != keyS[i]);
+        if ((threadIdx.x & 63u) == 0u) {
+            const uint32_t chunk = (i - slot0) >> 6;
+            mm_mask[chunk] = m;
+            if (m) atomicAdd(&mm_tile_cnt[chunk / MM_TILE_CHUNKS], (uint32_t)__popcll(m));
+        }
+    }
 }
 
 // A rank that failed tells its neighbours: the header of its NEXT migrant message says "abort" (word 3), nothing else
@@ -201,6 +231,7 @@ __global__ void k_slab_post_headers(const uint32_t* __restrict__ dl, const float
     const uint32_t t = threadIdx.x;                       // one wave: a lane per word, all stores in flight together
     if (t < 8u) host[t] = dl[t];
     else if (t == 16u || t == 17u) host[HL_NEAR + (t - 16u)] = dl[DL_NEAR + (t - 16u)];
+    else if (t == 18u || t == 19u) host[HL_EARLY + (t - 18u)] = dl[DL_EARLY + (t - 18u)];
     else if (t < 16u) {
         const float4* h = t < 12u ? hdr_lo : hdr_hi;
         const uint32_t w = (t - 8u) & 3u;
@@ -745,6 +776,8 @@ struct sph_slab {
     size_t stage_bytes = 0;
     uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0, inserts = 0, far_steps = 0, rest_msgs = 0;
     uint64_t exchanges = 0;              // transport calls so far (3 in a usual step: migrants, halo A, halo B)
+    bool early_force = true;             // the force pass of the innermost layers runs in front of the step's wait (sph_slab_set_early_force)
+    uint64_t early_launches = 0, early_used = 0;
     uint32_t* recut_blk = nullptr;       // sph_slab_recut: {down, up} counts per 1024-slot block, then their scan
     uint64_t recuts = 0, recut_moved = 0;
     // failure: the first error of this slab (sticky), its message, and whether the transport may still be used
@@ -945,6 +978,20 @@ int slab_step_body(sph_slab* s, float dt) {
         rc = launch_density_dev_range(c, s->d_lb + DL_DEEP, n0);
         if (rc) return rc;
     }
+    // ---- and behind it the fused force pass of the innermost layers (local layers [6, zl-6): every density they read is
+    //      the deep launch's), also from a range in device memory.  More work that needs nothing from a link: the main
+    //      stream stays busy while the migrant message, the host's wake-up and halo A are on their way.  The owned range
+    //      does not have its final start yet (leavers go, arrivals may be merged in front), so the launch leaves its keys by
+    //      ABSOLUTE slot in the sort's scratch keys and marks no movers; k_slab_early_finish does both once the start is
+    //      known.  A step whose arrivals take the pass over all particles throws the result away (every slot moves).
+    bool early_launched = false;
+    if (deep_valid && s->early_force && c->grid.zl >= 13u) {
+        PhaseTimer t(c, SPH_PH_FORCE);
+        rc = launch_force_dev_range(c, s->d_lb + DL_EARLY, n0, dt);
+        if (rc) return rc;
+        early_launched = true;
+        s->early_launches++;
+    }
     const uint32_t inl = min(MIG_INLINE, s->mcap);
     const size_t mig_bytes = (size_t)(1 + inl) * rec;
     s->pg.mig_posted = true;                                    // (also when the call fails: the transport is dead then)
@@ -962,6 +1009,7 @@ int slab_step_body(sph_slab* s, float dt) {
     const uint32_t lb0 = s->h_lb[HL_LB], lb1 = s->h_lb[HL_LB + 1], lb2 = s->h_lb[HL_LB + 2], lb3 = s->h_lb[HL_LB + 3];
     const uint32_t deep_lo = s->h_lb[HL_DEEP], deep_hi = s->h_lb[HL_DEEP + 1];
     const uint32_t near_lo = s->h_lb[HL_NEAR], near_hi = s->h_lb[HL_NEAR + 1];     // first slot of layer 3 / of layer zl-3
+    const uint32_t early_lo = s->h_lb[HL_EARLY], early_hi = s->h_lb[HL_EARLY + 1];   // what the early force launch covered
     const uint32_t far_lo = s->has_lo ? s->h_lb[HL_FAR] : 0u, far_hi = s->has_hi ? s->h_lb[HL_FAR + 1] : 0u;
     const uint32_t m_lo = lb0, m_hi = n0 - lb3;
     uint32_t own_lo = lb1 - lb0, own_hi = lb3 - lb2;
@@ -1219,7 +1267,26 @@ int slab_step_body(sph_slab* s, float dt) {
     c->have_dens = true;
     // the interior forces run while halo B travels
     const bool mark = force_begin(c, true);
-    { PhaseTimer t(c, SPH_PH_FORCE); rc = launch_force_range(c, a, b, true, true, true, dt, mark); }   // interior: queued before the transfer
+    {
+        PhaseTimer t(c, SPH_PH_FORCE);
+        // what the early launch did is left out in whole 64-slot chunks of the FINAL owned range (the up to 63 slots at
+        // either end of its range are simply computed again: same inputs, same bits)
+        uint32_t h0 = 0, h1 = 0;
+        if (early_launched && deep_valid && early_hi > early_lo && early_lo >= c->own_off) {
+            h0 = c->own_off + ((early_lo - c->own_off + 63u) & ~63u);
+            h1 = c->own_off + ((early_hi - c->own_off) & ~63u);
+        }
+        if (h1 > h0 && h0 >= a && h1 <= b) {
+            rc = launch_force_hole(c, a, b, h0, h1, true, true, true, dt, mark);                     // interior: queued before the transfer
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_slab_early_finish, dim3(ceil_div(h1 - h0, 256u)), dim3(256), 0, c->stream, c->keyS2, c->keyS, h0, h1,
+                               c->own_off, c->k0, mark ? c->mm_mask : (uint64_t*)nullptr, c->mm_tile_cnt);
+            SPH_HIP(hipGetLastError());
+            s->early_used++;
+        } else {
+            rc = launch_force_range(c, a, b, true, true, true, dt, mark);
+        }
+    }
     if (rc) return rc;
     rc = slab_exchange(s, SPH_TAG_HALO_B, s->dens_send[0], h_lo * sizeof(float2), s->dens_recv[0], g_lo * sizeof(float2),
                        s->dens_send[1], h_hi * sizeof(float2), s->dens_recv[1], g_hi * sizeof(float2));
@@ -1588,6 +1655,18 @@ int sph_slab_sync(sph_slab* s) {
     int rc = sph_sync(s->c);
     if (rc) return rc;
     return slab_check_device_flags(s);
+}
+
+int sph_slab_set_early_force(sph_slab* s, int on) {
+    SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
+    s->early_force = on != 0;
+    return SPH_OK;
+}
+
+int sph_slab_early_force_stats(const sph_slab* s, uint64_t out[2]) {
+    SPH_REQUIRE(s && out, SPH_E_INVALID, "null argument");
+    out[0] = s->early_launches; out[1] = s->early_used;
+    return SPH_OK;
 }
 
 int sph_slab_timing_enable(sph_slab* s, int on) {

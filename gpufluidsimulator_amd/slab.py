@@ -683,6 +683,10 @@ class NativeSlabSimulation(SlabSimulation):
             capi._check(capi.load().sph_slab_timing_reset(self._slab))
         return out
 
+    def set_early_force(self, on=True):
+        """The force pass of the innermost layers in front of the step's wait (sph_slab_set_early_force); same bits either way."""
+        capi._check(capi.load().sph_slab_set_early_force(self._slab, 1 if on else 0))
+
     def slab_timing_enable(self, on=True):
         capi._check(capi.load().sph_slab_timing_enable(self._slab, 1 if on else 0))
 
@@ -716,6 +720,9 @@ class NativeSlabSimulation(SlabSimulation):
         names = ("steps", "migrants", "resorts", "ghosts", "host_waits", "in_place_merges", "far_steps", "rest_messages")
         self.stats.update({k: base.get(k, 0) + int(out[i]) for i, k in enumerate(names)})
         self.stats["exchanges"] = base.get("exchanges", 0) + int(capi.load().sph_slab_exchanges(self._slab))
+        ef = (C.c_uint64 * 2)()
+        capi._check(capi.load().sph_slab_early_force_stats(self._slab, ef))
+        self.stats["early_force_launches"], self.stats["early_force_used"] = int(ef[0]), int(ef[1])
 
     def sync(self):
         capi._check(capi.load().sph_slab_sync(self._slab))
@@ -1015,6 +1022,7 @@ def bench_periodic(args):
     capi._check(L.sph_loop_transport_create(C.byref(tr), layers * edge, float(args.link_gbs), float(args.link_latency_us)))
     h = C.c_void_p()
     capi._check(L.sph_slab_create(C.byref(h), ctx.h, 1, 3, tr, 0))
+    capi._check(L.sph_slab_set_early_force(h, 0 if getattr(args, "no_early_force", False) else 1))
     dt = float(ic.DEFAULT_DT)
     step = lambda k: capi._check(L.sph_slab_step(h, dt, int(k)))          # noqa: E731
     sync = lambda: capi._check(L.sph_slab_sync(h))                        # noqa: E731
@@ -1070,6 +1078,9 @@ def bench_periodic(args):
                                   (int(v) for v in stats))),
         "owned": int(owned), "finite": finite, "roofline": None, "cpu_baseline": None,
     }
+    ef = (C.c_uint64 * 2)()
+    capi._check(L.sph_slab_early_force_stats(h, ef))
+    out["early_force"] = {"launched": int(ef[0]), "used": int(ef[1])}
     L.sph_slab_destroy(h)
     L.sph_loop_transport_destroy(tr)
     ctx.close()

@@ -91,6 +91,8 @@ def test_slabs_with_migration_match_whole_domain(case, world, transport):
     assert all(r[1]["exchanges"] == 3 * steps + r[1]["rest_messages"] for r in res), [r[1] for r in res]
     arrivals, in_place = sum(r[1]["resorts"] for r in res), sum(r[1]["in_place_merges"] for r in res)
     assert arrivals > 0 and in_place == arrivals, "arrivals join their boundary layer in place (k_slab_insert)"
+    if case == "tall_up":        # slabs of 12 owned layers: the innermost layers' force pass runs in front of the wait, arrivals or not
+        assert all(r[1]["early_force_used"] == steps for r in res), [r[1] for r in res]
     _same_bits(st, ref)
 
 
@@ -821,3 +823,33 @@ def test_one_slab_between_its_periodic_images_matches_three_stacked_copies():
     assert np.abs(got["pos"][:, :2] - ref["pos"][mid, :2]).max() <= 1e-6 * 4.0 and dz.max() <= 1e-6 * 4.0
     assert np.abs(got["vel"] - ref["vel"][mid]).max() <= 1e-5 * np.abs(ref["vel"]).max()
     assert np.abs(got["density"] / ref["density"][mid] - 1).max() <= 1e-5
+
+
+@pytest.mark.parametrize("early", [True, False])
+def test_early_force_launch_gives_the_same_bits(early):
+    """sph_slab_set_early_force: the fused force pass of a slab's innermost layers (six layers and more from either cut) is
+    queued in front of the step's host wait -- keys by absolute slot, movers marked afterwards (k_slab_early_finish).  A dam
+    slice 40 cell layers tall in two and three slabs, particles crossing the cuts both ways and changing cell inside the
+    early range every step, the merge path of the sort consuming the marks: bit for bit the one-context run, switched on
+    and off; on, every step uses the early result (the in-place merges of arrivals do not disturb it)."""
+    box, grid = (4.0, 4.0, 4.0), (64, 64, 64)
+    pos, vel = ic.dam_break_lattice((10, 10, 80), box, jitter=True)
+    rng = np.random.default_rng(4)
+    vel[:] = rng.uniform(-9000, 9000, pos.shape).astype(np.float32)
+    steps = 30
+    for world in (2, 3):
+        def body(make, r):
+            sim = make(box=box, grid=grid, particles=(pos, vel))
+            try:
+                sim.set_early_force(early)
+                sim.run(DT, steps); sim.sync()
+                return sim.gather_state(), dict(sim.stats), sim.engine.ctx.sort_stats()
+            finally:
+                sim.close()
+        out, errors = _with_ranks(world, body, timeout_s=300)
+        assert errors == [None] * world, errors
+        ref = _whole_domain(pos, vel, box, grid, steps)
+        _same_bits(out[0][0], ref)
+        assert sum(o[1]["migrants"] for o in out) > 0 and all(o[2]["merges"] >= steps - 2 for o in out), [o[1] for o in out]
+        used = [o[1]["early_force_used"] for o in out]
+        assert used == ([steps] * world if early else [0] * world), used
