@@ -778,6 +778,7 @@ struct sph_slab {
     uint64_t exchanges = 0;              // transport calls so far (3 in a usual step: migrants, halo A, halo B)
     bool early_force = true;             // the force pass of the innermost layers runs in front of the step's wait (sph_slab_set_early_force)
     uint64_t early_launches = 0, early_used = 0;
+    uint32_t early_span = 0;             // slots the last step's early range held: sizes this step's grid (what a grid misses, the interior launch computes)
     uint32_t* recut_blk = nullptr;       // sph_slab_recut: {down, up} counts per 1024-slot block, then their scan
     uint64_t recuts = 0, recut_moved = 0;
     // failure: the first error of this slab (sticky), its message, and whether the transport may still be used
@@ -985,9 +986,12 @@ int slab_step_body(sph_slab* s, float dt) {
     //      ABSOLUTE slot in the sort's scratch keys and marks no movers; k_slab_early_finish does both once the start is
     //      known.  A step whose arrivals take the pass over all particles throws the result away (every slot moves).
     bool early_launched = false;
+    // the grid: the range's size is on the device; the host sizes the launch from the LAST step's range plus a margin (a range
+    // changes by a few slots a step) -- whatever a too small grid leaves out is computed by the interior launch below
+    const uint32_t early_grid_slots = s->early_span ? min(n0, ((s->early_span + s->early_span / 64u + 1023u) & ~255u)) : n0;
     if (deep_valid && s->early_force && c->grid.zl >= 13u) {
         PhaseTimer t(c, SPH_PH_FORCE);
-        rc = launch_force_dev_range(c, s->d_lb + DL_EARLY, n0, dt);
+        rc = launch_force_dev_range(c, s->d_lb + DL_EARLY, early_grid_slots, dt);
         if (rc) return rc;
         early_launched = true;
         s->early_launches++;
@@ -1009,7 +1013,9 @@ int slab_step_body(sph_slab* s, float dt) {
     const uint32_t lb0 = s->h_lb[HL_LB], lb1 = s->h_lb[HL_LB + 1], lb2 = s->h_lb[HL_LB + 2], lb3 = s->h_lb[HL_LB + 3];
     const uint32_t deep_lo = s->h_lb[HL_DEEP], deep_hi = s->h_lb[HL_DEEP + 1];
     const uint32_t near_lo = s->h_lb[HL_NEAR], near_hi = s->h_lb[HL_NEAR + 1];     // first slot of layer 3 / of layer zl-3
-    const uint32_t early_lo = s->h_lb[HL_EARLY], early_hi = s->h_lb[HL_EARLY + 1];   // what the early force launch covered
+    const uint32_t early_lo = s->h_lb[HL_EARLY];                                       // what the early force launch covered:
+    const uint32_t early_hi = min(s->h_lb[HL_EARLY + 1], early_lo + early_grid_slots);      // its range, as far as its grid reached
+    s->early_span = s->h_lb[HL_EARLY + 1] - early_lo;
     const uint32_t far_lo = s->has_lo ? s->h_lb[HL_FAR] : 0u, far_hi = s->has_hi ? s->h_lb[HL_FAR + 1] : 0u;
     const uint32_t m_lo = lb0, m_hi = n0 - lb3;
     uint32_t own_lo = lb1 - lb0, own_hi = lb3 - lb2;
