@@ -605,13 +605,19 @@ class NativeSlabSimulation(SlabSimulation):
     call into libsph_hip.so per rank: sph_slab_step queues sort, migrants, halo A, density, halo B and the fused
     force pass on two HIP streams and waits for the device once (csrc/sph_slab.hip)."""
 
-    def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, ping_reps=3, **kw):
+    # a message group that costs more than this on an idle device (the preflight ping of the 8 KB migrant message) makes the
+    # early force launch pay: measured on a slab between its periodic images, DESIGN.md section 6
+    EARLY_FORCE_MIN_PING_US = 30.0
+
+    def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, ping_reps=3, early_force="auto", **kw):
         self._device_index = device_index
         self._transport_kind = transport
         self._migrant_capacity = migrant_capacity
         self._slab = None
         self._tr = None
         self._ping_reps = int(ping_reps)
+        self._early_force = early_force    # True / False / "auto": from the pings (collective: the same decision on every rank)
+        self.early_force = None            # {"on": bool, "why": str}
         self.ping = None               # {bytes: {"mean_us", "max_us"}} of the preflight, per message size of a step
         self.rccl = None               # what the RCCL communicator says about itself (sph_rccl_transport_info)
         def factory(cap, gcap, p, z0, z1):
@@ -654,6 +660,19 @@ class NativeSlabSimulation(SlabSimulation):
                                     f"{self.rccl['rank_seen']} of {self.rccl['world_seen']}")
         if self.ping is None and self.world > 1 and self._ping_reps > 0:
             self.ping = self._preflight()
+        self._decide_early_force()
+
+    def _decide_early_force(self):
+        if self._early_force in (True, False):
+            on, why = bool(self._early_force), "set by the caller"
+        elif self.ping is None:
+            on, why = False, "no ping taken"
+        else:       # the slowest link any rank saw decides for all (a rank's choice is its own scheduling: nothing has to agree)
+            worst = self.comm.allreduce_max(self.ping["migrants"]["mean_us"])
+            on = worst >= self.EARLY_FORCE_MIN_PING_US
+            why = f"migrant-message ping {worst:.1f} us (max over ranks) {'>=' if on else '<'} {self.EARLY_FORCE_MIN_PING_US:.0f} us"
+        self.early_force = {"on": on, "why": why}
+        capi._check(capi.load().sph_slab_set_early_force(self._slab, 1 if on else 0))
 
     def message_sizes(self):
         """Bytes per direction of the three message groups of a usual step: the fixed migrant message (header + 255
@@ -685,6 +704,8 @@ class NativeSlabSimulation(SlabSimulation):
 
     def set_early_force(self, on=True):
         """The force pass of the innermost layers in front of the step's wait (sph_slab_set_early_force); same bits either way."""
+        self._early_force = bool(on)
+        self.early_force = {"on": bool(on), "why": "set by the caller"}
         capi._check(capi.load().sph_slab_set_early_force(self._slab, 1 if on else 0))
 
     def slab_timing_enable(self, on=True):
@@ -983,6 +1004,7 @@ def bench_rank(comm, local, args, transport, log=None):
             "host_wait_us": diag["host_wait_us"],       # the step's one host wait, timed window
             "host_step_us": diag["host_step_us"],       # host time in front of / behind the wait, whole call
             "probe_steps": probe,
+            "early_force": sim.early_force,             # the innermost layers' force pass in front of the wait: on when a group costs > 30 us
             "phases_ms": diag["ranks"],                 # EVERY rank: phases, host timing, groups, pings
             "phases_ms_max_over_ranks": diag["phases_ms_max_over_ranks"],
             "phases_ms_rank0": phases_ms, "slab_stats_rank0": sim.stats, "owned_sum": int(counts[0]),
@@ -1022,7 +1044,9 @@ def bench_periodic(args):
     capi._check(L.sph_loop_transport_create(C.byref(tr), layers * edge, float(args.link_gbs), float(args.link_latency_us)))
     h = C.c_void_p()
     capi._check(L.sph_slab_create(C.byref(h), ctx.h, 1, 3, tr, 0))
-    capi._check(L.sph_slab_set_early_force(h, 0 if getattr(args, "no_early_force", False) else 1))
+    ef_arg = getattr(args, "early_force", "auto")
+    ef_on = ef_arg == "on" or (ef_arg == "auto" and float(args.link_latency_us) >= NativeSlabSimulation.EARLY_FORCE_MIN_PING_US)
+    capi._check(L.sph_slab_set_early_force(h, 1 if ef_on else 0))
     dt = float(ic.DEFAULT_DT)
     step = lambda k: capi._check(L.sph_slab_step(h, dt, int(k)))          # noqa: E731
     sync = lambda: capi._check(L.sph_slab_sync(h))                        # noqa: E731
@@ -1080,7 +1104,7 @@ def bench_periodic(args):
     }
     ef = (C.c_uint64 * 2)()
     capi._check(L.sph_slab_early_force_stats(h, ef))
-    out["early_force"] = {"launched": int(ef[0]), "used": int(ef[1])}
+    out["early_force"] = {"on": bool(ef_on), "launched": int(ef[0]), "used": int(ef[1])}
     L.sph_slab_destroy(h)
     L.sph_loop_transport_destroy(tr)
     ctx.close()

@@ -26,7 +26,8 @@ def _comm(hub, dev_hub, r):
     return comm
 
 
-def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport="local", rebalance_every=0, expect_error=False):
+def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport="local", rebalance_every=0, expect_error=False,
+               early_force="auto"):
     hub = slab.LocalComm.Hub(world)
     dev_hub = capi.LocalHub(world, timeout_s=60) if transport == "local" else None
     results, errors = [None] * world, []
@@ -34,7 +35,7 @@ def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport=
     def rank_main(r):
         try:
             sim = slab.NativeSlabSimulation(_comm(hub, dev_hub, r), box, grid, device_index=0, transport=transport,
-                                            particles=particles, lattice=lattice)
+                                            particles=particles, lattice=lattice, early_force=early_force)
             cuts0 = list(sim.cuts)
             handles0 = (sim.engine.ctx.h.value, sim._slab.value)
             sim.run(DT, steps, rebalance_every=rebalance_every)
@@ -81,7 +82,7 @@ def _whole_domain(pos, vel, box, grid, steps):
 def test_slabs_with_migration_match_whole_domain(case, world, transport):
     pos, vel, box, grid = make_case(case)
     steps = 24
-    res = _run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport)
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, early_force=(case == "tall_up"))
     st = res[0][0]
     ref = _whole_domain(pos, vel, box, grid, steps)
     assert sum(r[1]["migrants"] for r in res) > 0
