@@ -607,7 +607,8 @@ class NativeSlabSimulation(SlabSimulation):
 
     # a message group that costs more than this on an idle device (the preflight ping of the 8 KB migrant message) makes the
     # early force launch pay: measured on a slab between its periodic images, DESIGN.md section 6
-    EARLY_FORCE_MIN_PING_US = 30.0
+    EARLY_FORCE_MIN_PING_US = 35.0
+    EARLY_FORCE_MIN_HALO_PING_US = 90.0      # ... or a halo-A-sized message more than this (a slow link rather than a late one)
 
     def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, ping_reps=3, early_force="auto", **kw):
         self._device_index = device_index
@@ -669,8 +670,10 @@ class NativeSlabSimulation(SlabSimulation):
             on, why = False, "no ping taken"
         else:       # the slowest link any rank saw decides for all (a rank's choice is its own scheduling: nothing has to agree)
             worst = self.comm.allreduce_max(self.ping["migrants"]["mean_us"])
-            on = worst >= self.EARLY_FORCE_MIN_PING_US
-            why = f"migrant-message ping {worst:.1f} us (max over ranks) {'>=' if on else '<'} {self.EARLY_FORCE_MIN_PING_US:.0f} us"
+            worst_a = self.comm.allreduce_max(self.ping["halo_a"]["mean_us"])
+            on = worst >= self.EARLY_FORCE_MIN_PING_US or worst_a >= self.EARLY_FORCE_MIN_HALO_PING_US
+            why = (f"pings, max over ranks: migrant message {worst:.1f} us (on from {self.EARLY_FORCE_MIN_PING_US:.0f}), halo A "
+                   f"{worst_a:.1f} us (on from {self.EARLY_FORCE_MIN_HALO_PING_US:.0f})")
         self.early_force = {"on": on, "why": why}
         capi._check(capi.load().sph_slab_set_early_force(self._slab, 1 if on else 0))
 
@@ -1045,7 +1048,9 @@ def bench_periodic(args):
     h = C.c_void_p()
     capi._check(L.sph_slab_create(C.byref(h), ctx.h, 1, 3, tr, 0))
     ef_arg = getattr(args, "early_force", "auto")
-    ef_on = ef_arg == "on" or (ef_arg == "auto" and float(args.link_latency_us) >= NativeSlabSimulation.EARLY_FORCE_MIN_PING_US)
+    halo_us = float(args.link_latency_us) + (per_layer * 32 / (float(args.link_gbs) * 1e3) if float(args.link_gbs) > 0 else 0.0)
+    ef_on = ef_arg == "on" or (ef_arg == "auto" and (float(args.link_latency_us) >= NativeSlabSimulation.EARLY_FORCE_MIN_PING_US
+                                                      or halo_us >= NativeSlabSimulation.EARLY_FORCE_MIN_HALO_PING_US))
     capi._check(L.sph_slab_set_early_force(h, 1 if ef_on else 0))
     dt = float(ic.DEFAULT_DT)
     step = lambda k: capi._check(L.sph_slab_step(h, dt, int(k)))          # noqa: E731

@@ -401,7 +401,7 @@ int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]);
  * layers and more) is queued IN FRONT of the step's host wait, behind the deep density: work that needs nothing from a
  * neighbour keeps the main stream busy while the migrant message and halo A are on their way.  It makes the step's time
  * nearly independent of the links' latency at a fixed price (three force launches instead of two: ~+40 us per step at 2 M
- * particles), so it pays when a message group costs more than ~30 us (measured on a slab between its
+ * particles), so it pays when a message group costs more than ~35 us (measured on a slab between its
  * periodic images) -- default 0; a launcher decides from its pings (gpufluidsimulator_amd/slab.py, csrc/sph_headless.cpp).  Same
  * bits either way.  out = {steps that launched it, steps that used its result} (a step whose arrivals re-sort the slab
  * discards it). */
