@@ -32,7 +32,8 @@ for case in range(ncases):
     reb = int(rng.choice([0, 0, 7, 13])) if os.environ.get("FUZZ_REBALANCE") else 0       # (drawn last: the seeds of round 3 keep their cases)
     t0 = time.time()
     try:
-        res = T._run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, rebalance_every=reb)
+        res = T._run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, rebalance_every=reb,
+                           early_force=True if os.environ.get("FUZZ_EARLY_FORCE") else "auto")
         st = res[0][0]
         ref = T._whole_domain(pos, vel, box, grid, steps)
         ep = np.abs(st["pos"] - ref["pos"]).max() / 8.0
@@ -46,6 +47,7 @@ for case in range(ncases):
         ok = same and sum(r[3] for r in res) == pos.shape[0]
         stats = {k: sum(r[1][k] for r in res) for k in ("migrants", "resorts", "in_place_merges", "far_steps", "rest_messages")}
         stats["rebalances"] = sum(r[1].get("rebalances", 0) for r in res); stats["reb_every"] = reb
+        stats["early_force_used"] = sum(r[1].get("early_force_used", 0) for r in res)
         print(f"case {seed0 + case}: world {world} lattice {nx}x{ny}x{nz} mode {mode} steps {steps} {transport}: "
               f"{'ok ' if ok else 'BAD'} {'same-bits' if same else 'DIFFERENT-BITS'} pos {ep:.1e} vel {ev.max():.1e} ({(ev > 1e-5).sum()} > 1e-5) rho {er:.1e} cuts {res[0][2]} {stats} {time.time() - t0:.1f}s", flush=True)
         bad += 0 if ok else 1
