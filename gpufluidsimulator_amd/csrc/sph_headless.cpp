@@ -305,12 +305,12 @@ int main(int argc, char** argv) {
     if (!benchmark && !file) fprintf(stderr, "note: no OpenGL in this build -- running headless, as with -benchmark\n");
     if (flag(argc, argv, "help")) {
         printf("usage: sph_headless [-benchmark] [-n=<particles>] [-box=<edge>] [-i=<iterations>] [-device=<id>] [-grid=<cells per axis>] "
-               "[-ic=grid|random] [-steps=<per update>] [-gpus=<N> [-onegpu] [-lattice=nx,ny,nz]] "
+               "[-ic=grid|random] [-steps=<per update>] [-gpus=<N> [-onegpu] [-slab] [-lattice=nx,ny,nz]] "
                "[-dump=<count>] [-log=<file>] [-sphere=<update>[,<radius>]] [-out=<file>] [-save=<file>] [-load=<file>] [-file=<file>]\n");
         return 0;
     }
     const int gpus = value(argc, argv, "gpus") ? atoi(value(argc, argv, "gpus")) : 1;
-    if (gpus > 1) {
+    if (gpus > 1 || (gpus == 1 && flag(argc, argv, "slab"))) {     // (-gpus=1 -slab: the same machinery with one rank -- fork, RCCL communicator of one)
         if (ic != ParticleSystem::CONFIG_GRID || load || value(argc, argv, "sphere") || value(argc, argv, "save") || value(argc, argv, "log") || dump) {
             fprintf(stderr, "-gpus=%d runs the dam-break lattice (-ic=grid) and takes -n -box -grid -i -steps -lattice -out -device -onegpu -nowarmup\n", gpus);
             return EXIT_FAILURE;

@@ -194,6 +194,14 @@ def test_driver_gpus_flag_runs_z_slabs_through_the_c_abi():
     assert a.size == b.size == 2 * 32768 * 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
     bad = subprocess.run([EXE, "-benchmark", "-n=32768", "-box=4", "-i=2", "-gpus=2"], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "GPUs asked for" in bad.stderr
+    # the process path with ONE rank (-gpus=1 -slab): a child forked before any GPU call, its RCCL communicator (of one), the slab
+    # step, the result through the pipe, the rows through the shared mapping -- everything of -gpus=N but the neighbours
+    with tempfile.TemporaryDirectory() as d:
+        f1, fp = os.path.join(d, "one.bin"), os.path.join(d, "proc.bin")
+        _run("-benchmark", "-n=32768", "-box=4", "-i=10", "-nowarmup", f"-out={f1}")
+        text = _run("-benchmark", "-n=32768", "-box=4", "-i=10", "-nowarmup", "-gpus=1", "-slab", f"-out={fp}")
+        assert "NumDevsUsed = 1" in text and '"ranks_as": "processes"' in text
+        assert np.array_equal(np.fromfile(f1, dtype=np.uint32), np.fromfile(fp, dtype=np.uint32))
 
 
 def test_driver_file_flag_is_the_reference_s_one_update_run():
