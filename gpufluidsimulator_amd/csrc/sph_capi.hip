@@ -289,8 +289,7 @@ static int do_hash(sph_ctx* c) {
     c->cells_clear_deferred = c->sort_merge && c->order_valid && c->cells_valid && c->cells_lo == lo && c->cells_hi == hi;
     int rc;
     if (c->cells_clear_deferred) {
-        rc = launch_cells_clear_range(c, lo, c->own_off);
-        if (!rc) rc = launch_cells_clear_range(c, c->own_off + c->n, hi);
+        rc = launch_cells_clear_2ranges(c, lo, c->own_off, c->own_off + c->n, hi);      // both ghost ranges, one launch
         c->cells_lo = c->own_off; c->cells_hi = c->own_off + c->n;
     } else {
         rc = launch_cells_clear(c);
