@@ -128,3 +128,66 @@ def test_morton_golden_through_the_seam():
     assert L.sph_compat_context(d_aos.data_ptr())
     L.sph_compat_release(d_aos.data_ptr())
     assert not L.sph_compat_context(d_aos.data_ptr())
+
+
+def test_seam_integers_at_config_2_in_developed_flow():
+    """The same integer work at BASELINE config 2's size in a developed flow (`c2_flow`: 262,144 particles after 2600 reference
+    steps, cells of 1 .. max_cell particles, chunks of 32): cudaMapZIndex / cudaSortParticles / cudaConstructBGrid /
+    cudaConstructGridArray called directly on device arrays, against the oracle's Morton-mode phases (the oracle is pinned
+    bit-exact to the reference's own code, tests/test_oracle_vs_ref.py): Particle::zindex per particle, the sorted z-index
+    sequence, the WHOLE dev_B table (2,097,152 entries) and dev_B_prime with its size, `array_equal`."""
+    import ctypes as C
+    import torch
+    from gpufluidsimulator_amd import capi
+    from oracle import oracle
+    g = load_golden("c2_flow")
+    pos, vel = g["pos"], g["vel"]
+    n, grid, box = pos.shape[0], int(g["grid"][0]), [float(b) for b in g["box"]]
+    o = oracle.Oracle(pos, vel, g["box"], g["grid"], oracle.CELL_MORTON)
+    o.map_zindex()
+    want_z = o.by_index("zindex").copy()
+    o.sort(); o.construct_bgrid(); o.construct_grid_array()
+    want_sorted = o.particles["zindex"].copy()
+    want_B = np.stack([o.B["nParticles"], o.B["start"]], axis=1).astype(np.uint32)
+    want_Bp = np.stack([o.Bprime["nParticles"], o.Bprime["start"]], axis=1).astype(np.uint32)
+    o.close()
+    assert int(g["s1_ncells"]) == int((want_B[:, 0] > 0).sum()) and int(g["s1_max_cell"]) == int(want_B[:, 0].max())   # the fixture's own counts
+    L = capi.load()
+    aos = np.zeros((n, 22), np.uint32)
+    aos[:, 0] = np.arange(n)
+    aos[:, 1:4] = pos.view(np.uint32); aos[:, 4:7] = vel.view(np.uint32)
+    aos[:, 16] = np.float32(65.0).view(np.uint32); aos[:, 19] = np.float32(1.0 / 64.0).view(np.uint32)
+    prm = np.zeros(18, np.float32)
+    prm[7] = 1.0 / 64.0
+    prm[8:11] = [-b / 2 for b in box]; prm[11:14] = [b / 2 for b in box]; prm[14:17] = box
+    prm.view(np.uint32)[17] = grid
+    dev = torch.device("cuda", 0)
+    d_aos, d_prm = torch.from_numpy(aos.view(np.int32)).to(dev), torch.from_numpy(prm).to(dev)
+    b_size = grid ** 3
+    d_B = torch.full((b_size, 2), -1, dtype=torch.int32, device=dev)
+    d_Bp = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
+    vp = C.c_void_p
+    L.cudaMapZIndex.argtypes = [vp, C.c_uint, vp]; L.cudaMapZIndex.restype = None
+    L.cudaSortParticles.argtypes = [vp, C.c_uint]; L.cudaSortParticles.restype = None
+    L.cudaConstructBGrid.argtypes = [vp, C.c_uint, vp, C.c_uint, vp]; L.cudaConstructBGrid.restype = None
+    L.cudaConstructGridArray.argtypes = [vp, C.c_uint, vp, C.c_uint, C.POINTER(vp), C.POINTER(C.c_uint), vp]
+    L.cudaConstructGridArray.restype = None
+    L.sph_compat_release.argtypes = [vp]; L.sph_compat_release.restype = None
+    L.threadSync.restype = None
+    try:
+        L.cudaMapZIndex(d_aos.data_ptr(), n, d_prm.data_ptr())
+        L.threadSync()
+        assert np.array_equal(d_aos.cpu().numpy().view(np.uint32)[:, 21], want_z)
+        L.cudaSortParticles(d_aos.data_ptr(), n)
+        L.cudaConstructBGrid(d_aos.data_ptr(), n, d_B.data_ptr(), b_size, d_prm.data_ptr())
+        bp, bp_size = vp(d_Bp.data_ptr()), C.c_uint(0)
+        L.cudaConstructGridArray(d_aos.data_ptr(), n, d_B.data_ptr(), b_size, C.byref(bp), C.byref(bp_size), d_prm.data_ptr())
+        L.threadSync()
+        srt = d_aos.cpu().numpy().view(np.uint32)
+        assert np.array_equal(srt[:, 21], want_sorted)
+        assert np.array_equal(np.sort(srt[:, 0]), np.arange(n)) and np.array_equal(srt[:, 21], want_z[srt[:, 0]])
+        assert np.array_equal(d_B.cpu().numpy().view(np.uint32), want_B)
+        assert bp_size.value == want_Bp.shape[0]
+        assert np.array_equal(d_Bp.cpu().numpy().view(np.uint32)[:bp_size.value], want_Bp)
+    finally:
+        L.sph_compat_release(d_aos.data_ptr())
