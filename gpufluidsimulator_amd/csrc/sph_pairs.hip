@@ -837,10 +837,28 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     // padding): one address register serves all four ds_read_b64 through immediate offsets, and the
     // 8-entry (one cell) distance between the lane groups of a wave is 80 dwords = 16 banks, so the four
     // distinct addresses of a half-wave never share a bank.
+    // SPH_FORCE_B128 (round 5): the same 32 bytes as TWO aligned ds_read_b128, {x,y,z,vx} {vy,vz,cp,w}, at a 48-byte stride
+    // (the third float4 is padding; a 32-byte stride puts lanes 8 entries apart on the same banks: 61 ns per candidate
+    // against 37 on the bare device, profiles/r05_force_b128_microbenchmark.txt).  An LDS instruction costs the SIMD that
+    // issues it VALU issue slots whatever it carries (section 3 of DESIGN.md: reads and arithmetic overlap only partly), so
+    // two instructions per candidate instead of four is worth more than the pipe time says: 41.5 -> 36.9 ns per candidate
+    // per SIMD in the bare loop at 5 waves per SIMD.  31 KB of LDS per block instead of 26: five blocks per CU still fit 160 KB.
+#ifndef SPH_FORCE_B128
+#define SPH_FORCE_B128 1
+#endif
+#if SPH_FORCE_B128
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
+    __shared__ __attribute__((aligned(16))) float4 s_q[LDS_ENT * 3];
+    float2* const s_e = reinterpret_cast<float2*>(s_q);                  // (the zero-fill below: 6 float2 per entry)
+    constexpr int E2 = 6;
+#else
+    constexpr int E2 = 5;
     __shared__ float2 s_e[LDS_ENT * 5];
+#endif
     // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
     if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)PAIR_THREADS >= tg.dev[1]) return;
-    for (uint32_t k = threadIdx.x; k < LDS_ENT * 5; k += PAIR_THREADS)   // see LDS_ENT: keep over-reads finite
+    for (uint32_t k = threadIdx.x; k < LDS_ENT * E2; k += PAIR_THREADS)   // see LDS_ENT: keep over-reads finite
         s_e[k] = make_float2(0.f, 0.f);
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1021,6 +1039,16 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             if (FORCE) { e0 = cw[a + lane]; e1 = cw[a + WAVE + lane]; }
         },
         [&]() {
+#if SPH_FORCE_B128
+            float4* a0p = &s_q[(slice + lane) * 3];
+            float4* a1p = &s_q[(slice + WAVE + lane) * 3];
+            a0p[0] = make_float4(q0.x, q0.y, q0.z, w0.x);
+            a1p[0] = make_float4(q1.x, q1.y, q1.z, w1.x);
+            // {cp_j, w_j} as the density pass left them (neighbour_terms); padding entries hold 0: weight 0
+            a0p[1] = make_float4(w0.y, w0.z, FORCE ? e0.x : 0.f, FORCE ? e0.y : 0.f);
+            a1p[1] = make_float4(w1.y, w1.z, FORCE ? e1.x : 0.f, FORCE ? e1.y : 0.f);
+            return;
+#endif
             float2* e0p = &s_e[(slice + lane) * 5];
             float2* e1p = &s_e[(slice + WAVE + lane) * 5];
             e0p[0] = make_float2(q0.x, q0.y);
@@ -1048,11 +1076,17 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             uint32_t near = 0u;
             PAIR_STAT(1, 1); PAIR_STAT(2, T);
             auto pair = [&](int u, bool valid) {
+#if SPH_FORCE_B128
+                const lds_v4f_ptr e = (lds_v4f_ptr)s_q + (idx + u) * 3;
+                const v4f qa = e[0], qb = e[1];
+                const float t = pair_math(qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, valid);
+#else
                 const lds_v2f_ptr e = (lds_v2f_ptr)s_e + (idx + u) * 5;
                 const v2f qa = e[0], qb = e[1];
                 v2f qc = {0.f, 0.f}, qd = {0.f, 0.f};
                 if (FORCE) { qc = e[2]; qd = e[3]; }
                 const float t = pair_math(qa.x, qa.y, qb.x, qb.y, qc.x, qc.y, qd.x, qd.y, valid);
+#endif
                 if (COLL) near = __builtin_amdgcn_alignbit(near, __float_as_uint(t), 31);   // (near << 1) | sign(t)
             };
             for (uint32_t t0 = 0; t0 < T; t0 += 32u) {
@@ -1087,9 +1121,15 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                             const uint32_t hb = 31u - (uint32_t)__clz((int)near);
                             near &= ~(1u << hb);
                             const uint32_t ci = idx0 + (done - 1u - hb);
+#if SPH_FORCE_B128
+                            const float4* e = &s_q[(ci << 1) + ci];          // ci * 3 without v_mul_lo_u32
+                            const float4 qa = e[0], qb = e[1];
+                            collide_math(qa.x, qa.y, qa.z, qa.w, qb.x, qb.y);
+#else
                             const float2* e = &s_e[(ci << 2) + ci];          // ci * 5 without v_mul_lo_u32
                             const float2 qa = e[0], qb = e[1], qc = e[2];
                             collide_math(qa.x, qa.y, qb.x, qb.y, qc.x, qc.y);
+#endif
                         }
                     }
                 }

@@ -76,6 +76,13 @@ __global__ __launch_bounds__(256) void kmix(const int* __restrict__ entry, int s
             if (READS == 4)
                 asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:8\n ds_read_b64 %2, %4 offset:16\n ds_read_b64 %3, %4 offset:24\n s_waitcnt lgkmcnt(0)\n"
                              : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(a) : "memory");
+            if (READS == 42) {     // round 5: the force candidate's 32 bytes as TWO aligned ds_read_b128 (stride must be a multiple of 4 dwords)
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 qa, qb;
+                asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:16\n s_waitcnt lgkmcnt(0)\n"
+                             : "=&v"(qa), "=&v"(qb) : "v"(a & ~15u) : "memory");
+                d0 = ((double*)&qa)[0]; d1 = ((double*)&qa)[1]; d2 = ((double*)&qb)[0]; d3 = ((double*)&qb)[1];
+            }
             if (READS == 2)
                 asm volatile("ds_read_b64 %0, %2\n ds_read_b32 %1, %2 offset:8\n s_waitcnt lgkmcnt(0)\n"
                              : "=&v"(d0), "=&v"(a5) : "v"(a) : "memory");
@@ -158,6 +165,29 @@ void runmix(const char* name, const std::vector<int>& entry) {
     hipFree(d_entry);
 }
 
+template <int READS, int VALU>
+void runmix_stride(const char* name, const std::vector<int>& entry, int stride) {
+    int* d_entry; float* out;
+    hipMalloc(&d_entry, 64 * sizeof(int));
+    hipMemcpy(d_entry, entry.data(), 64 * sizeof(int), hipMemcpyHostToDevice);
+    const int iters = 300;
+    for (int w : {3, 5, 8}) {                   // blocks of 4 waves per CU = waves per SIMD (k_force runs 5, k_density 6)
+        const int blocks = 256 * w;
+        hipMalloc(&out, blocks * 256 * sizeof(float));
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL((kmix<READS, VALU>), dim3(blocks), dim3(256), 19456, 0, d_entry, stride, 4, out);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((kmix<READS, VALU>), dim3(blocks), dim3(256), 19456, 0, d_entry, stride, iters, out);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-44s : %6.2f ns per candidate per SIMD at %d waves per SIMD\n", name, ms * 1e6 / ((double)iters * 16 * w), w);
+        hipFree(out);
+    }
+    hipFree(d_entry);
+}
+
 // The s_waitcnt after every read would measure latency, not throughput, for one wave; with W >= 4 waves per SIMD the
 // LDS pipe is kept full by the other waves and the wall time is the pipe's.
 template <int MODE>
@@ -199,6 +229,22 @@ static std::vector<int> cells(const std::vector<int>& lanes_per_cell, const std:
 int main(int argc, char** argv) {
     const std::vector<int> eight(8, 8);
     const auto rest = cells(eight, eight);                                         // 8 lanes per cell, cells 8 entries apart
+    if (argc > 1 && std::string(argv[1]) == "b128") {
+        // round 5: would the force candidate's four ds_read_b64 be cheaper as two ds_read_b128?  Strides of 8 and 12 dwords (32 / 48 bytes),
+        // lanes as at rest (8 per cell) and in a flow (9 per cell, random cells)
+        const auto flow2 = cells({3, 9, 9, 9, 9, 9, 9, 7}, {9, 9, 9, 9, 9, 9, 9, 9});
+        runmix<4, 24>("4 ds_read_b64 + 24 VALU, stride 10, rest", rest);
+        runmix<4, 24>("4 ds_read_b64 + 24 VALU, stride 10, flow (9 per cell)", flow2);
+        runmix_stride<42, 24>("2 ds_read_b128 + 24 VALU, stride 8, rest", rest, 8);
+        runmix_stride<42, 24>("2 ds_read_b128 + 24 VALU, stride 8, flow (9 per cell)", flow2, 8);
+        runmix_stride<42, 24>("2 ds_read_b128 + 24 VALU, stride 12, rest", rest, 12);
+        runmix_stride<42, 24>("2 ds_read_b128 + 24 VALU, stride 12, flow (9 per cell)", flow2, 12);
+        runmix_stride<42, 0>("2 ds_read_b128, no VALU, stride 8, rest", rest, 8);
+        runmix_stride<42, 0>("2 ds_read_b128, no VALU, stride 8, flow", flow2, 8);
+        runmix<4, 0>("4 ds_read_b64, no VALU, stride 10, rest", rest);
+        runmix<0, 24>("24 VALU, no LDS", rest);
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "two") {
         // round 4: what would two targets per lane buy k_force?  The candidate's four reads feed 48 VALU instead of 24.
         runmix<4, 24>("4 ds_read_b64 + 24 VALU (one target)", rest);
