@@ -837,14 +837,15 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     // padding): one address register serves all four ds_read_b64 through immediate offsets, and the
     // 8-entry (one cell) distance between the lane groups of a wave is 80 dwords = 16 banks, so the four
     // distinct addresses of a half-wave never share a bank.
-    // SPH_FORCE_B128 (round 5): the same 32 bytes as TWO aligned ds_read_b128, {x,y,z,vx} {vy,vz,cp,w}, at a 48-byte stride
-    // (the third float4 is padding; a 32-byte stride puts lanes 8 entries apart on the same banks: 61 ns per candidate
-    // against 37 on the bare device, profiles/r05_force_b128_microbenchmark.txt).  An LDS instruction costs the SIMD that
-    // issues it VALU issue slots whatever it carries (section 3 of DESIGN.md: reads and arithmetic overlap only partly), so
-    // two instructions per candidate instead of four is worth more than the pipe time says: 41.5 -> 36.9 ns per candidate
-    // per SIMD in the bare loop at 5 waves per SIMD.  31 KB of LDS per block instead of 26: five blocks per CU still fit 160 KB.
+    // SPH_FORCE_B128 = 1 (round 5, an experiment that did NOT pay; kept as an A/B knob): the same 32 bytes as TWO aligned
+    // ds_read_b128, {x,y,z,vx} {vy,vz,cp,w}, at a 48-byte stride (the third float4 is padding; a 32-byte stride puts lanes
+    // 8 entries apart on the same banks).  The bare loop liked it -- 41.5 -> 36.9 ns per candidate per SIMD at 5 waves per
+    // SIMD, profiles/r05_force_b128_experiment.txt: an LDS instruction costs the issuing SIMD VALU slots whatever it carries
+    // -- the kernel did not: SQ_INSTS_LDS 1,031 -> 556 per wave, but SQ_BUSY_CYCLES 1.707e8 -> 1.752e8 (+2.6 %) and the same
+    // 2.56 ms (with 85 % of the cells at 8 particles a b128 at any 16-byte-aligned stride is a two-way bank conflict, which
+    // the bare loop's independent fmas hid and the real dependency chain does not).
 #ifndef SPH_FORCE_B128
-#define SPH_FORCE_B128 1
+#define SPH_FORCE_B128 0
 #endif
 #if SPH_FORCE_B128
     typedef float v4f __attribute__((ext_vector_type(4)));
