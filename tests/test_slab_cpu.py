@@ -183,3 +183,23 @@ def test_single_hop_cuts_reach_any_target_one_rank_at_a_time():
             assert all(b - a >= 2 for a, b in zip(step, step[1:])), (old, new, step)
             old, hops = step, hops + 1
             assert hops <= world + 2
+
+
+def test_gather_rows_puts_every_rank_s_numbers_on_every_rank():
+    """slab.gather_rows (what bench_diagnostics uses to print EVERY rank's phases): one all-reduce, NaN = 'none' survives."""
+    import threading
+    world = 4
+    hub = slab.LocalComm.Hub(world)
+    out = [None] * world
+
+    def rank_main(r):
+        comm = slab.LocalComm(hub, r)
+        out[r] = slab.gather_rows(comm, [float(r), 10.0 * r, float("nan") if r % 2 else 1.5])
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=60)
+    for m in out:
+        assert m.shape == (world, 3)
+        assert np.array_equal(m[:, 0], np.arange(world)) and np.array_equal(m[:, 1], 10.0 * np.arange(world))
+        assert np.isnan(m[1, 2]) and np.isnan(m[3, 2]) and m[0, 2] == 1.5 and m[2, 2] == 1.5
