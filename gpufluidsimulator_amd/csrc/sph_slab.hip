@@ -758,6 +758,9 @@ struct sph_slab {
     bool host_staged = false;            // the transport wants host buffers (tests); else device pointers on the comm stream
     hipStream_t comm = nullptr;
     hipEvent_t ev_main = nullptr, ev_comm = nullptr, ev_deep = nullptr;
+    hipStream_t early = nullptr;         // the early force launch's own stream (behind the deep density by event): its tail then runs
+    hipEvent_t ev_early_go = nullptr, ev_early_done = nullptr;   // beside the interior launch instead of in front of it
+    bool early_own_stream = true;        // SPH_SLAB_EARLY_STREAM=0: on the main stream (A/B)
     uint32_t gcap = 0, mcap = 0;         // halo / migrant capacity per side, in records
     uint32_t* d_lb = nullptr;            // DL_* words: layer bounds, deep-interior range, far counts, block counters (device)
     volatile uint32_t* h_lb = nullptr;   // HL_* words (pinned, mapped): what the step's one wait reads
@@ -824,6 +827,9 @@ void slab_free(sph_slab* s) {
     if (s->ev_main) hipEventDestroy(s->ev_main);
     if (s->ev_comm) hipEventDestroy(s->ev_comm);
     if (s->ev_deep) hipEventDestroy(s->ev_deep);
+    if (s->ev_early_go) hipEventDestroy(s->ev_early_go);
+    if (s->ev_early_done) hipEventDestroy(s->ev_early_done);
+    if (s->early) hipStreamDestroy(s->early);
     for (auto& pd : s->pending) { hipEventDestroy(pd.a); hipEventDestroy(pd.b); }
     for (hipEvent_t e : s->ev_free) hipEventDestroy(e);
     if (s->comm) hipStreamDestroy(s->comm);
@@ -990,13 +996,35 @@ int slab_step_body(sph_slab* s, float dt) {
     // the grid: the range's size is on the device; the host sizes the launch from the LAST step's range plus a margin (a range
     // changes by a few slots a step) -- whatever a too small grid leaves out is computed by the interior launch below
     const uint32_t early_grid_slots = s->early_span ? min(n0, ((s->early_span + s->early_span / 64u + 1023u) & ~255u)) : n0;
+    bool early_pending = false;          // the launch runs on its own stream: the main stream has not waited for it yet
     if (deep_valid && s->early_force && c->grid.zl >= 13u) {
-        PhaseTimer t(c, SPH_PH_FORCE);
-        rc = launch_force_dev_range(c, s->d_lb + DL_EARLY, early_grid_slots, dt);
-        if (rc) return rc;
+        if (s->early_own_stream && s->early) {
+            SPH_HIP(hipEventRecord(s->ev_early_go, c->stream));             // behind the deep density
+            SPH_HIP(hipStreamWaitEvent(s->early, s->ev_early_go, 0));
+            hipStream_t saved = c->stream;
+            c->stream = s->early;
+            { PhaseTimer t(c, SPH_PH_FORCE); rc = launch_force_dev_range(c, s->d_lb + DL_EARLY, early_grid_slots, dt); }
+            c->stream = saved;
+            if (rc) return rc;
+            SPH_HIP(hipEventRecord(s->ev_early_done, s->early));
+            early_pending = true;
+        } else {
+            PhaseTimer t(c, SPH_PH_FORCE);
+            rc = launch_force_dev_range(c, s->d_lb + DL_EARLY, early_grid_slots, dt);
+            if (rc) return rc;
+        }
         early_launched = true;
         s->early_launches++;
     }
+    // whoever re-sorts or re-writes the ping-pong arrays on the main stream must come behind the early launch
+    auto join_early = [&]() -> int {
+        if (early_pending) { SPH_HIP(hipStreamWaitEvent(c->stream, s->ev_early_done, 0)); early_pending = false; }
+        return SPH_OK;
+    };
+    struct JoinOnExit {                  // (an error return leaves the step half done: the next sort must still come behind the launch)
+        sph_slab* s; bool* pending;
+        ~JoinOnExit() { if (*pending) hipStreamWaitEvent(s->c->stream, s->ev_early_done, 0); }
+    } join_on_exit{s, &early_pending};
     const uint32_t inl = min(MIG_INLINE, s->mcap);
     const size_t mig_bytes = (size_t)(1 + inl) * rec;
     s->pg.mig_posted = true;                                    // (also when the call fails: the transport is dead then)
@@ -1134,6 +1162,7 @@ int slab_step_body(sph_slab* s, float dt) {
             // the appended slots (launch_merge_arrivals: the first in_lo of them are `front` movers); the full radix
             // sort is stable, so there the lower neighbour's particles are put physically IN FRONT of the owned range.
             deep_valid = false;
+            rc = join_early(); if (rc) return rc;     // every slot moves, through the arrays the early launch writes
             uint32_t appended = 0;
             const bool front_slots = !merge && in_lo <= c->own_off;
             for (int side = 0; side < 2; side++) {
@@ -1286,11 +1315,13 @@ int slab_step_body(sph_slab* s, float dt) {
         if (h1 > h0 && h0 >= a && h1 <= b) {
             rc = launch_force_hole(c, a, b, h0, h1, true, true, true, dt, mark);                     // interior: queued before the transfer
             if (rc) return rc;
+            rc = join_early(); if (rc) return rc;                   // (its tail has run beside the launch above)
             hipLaunchKernelGGL(k_slab_early_finish, dim3(ceil_div(h1 - h0, 256u)), dim3(256), 0, c->stream, c->keyS2, c->keyS, h0, h1,
                                c->own_off, c->k0, mark ? c->mm_mask : (uint64_t*)nullptr, c->mm_tile_cnt);
             SPH_HIP(hipGetLastError());
             s->early_used++;
         } else {
+            rc = join_early(); if (rc) return rc;                   // (both write the same slots of the ping-pong arrays: same values, but in order)
             rc = launch_force_range(c, a, b, true, true, true, dt, mark);
         }
     }
@@ -1570,6 +1601,7 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
     s->has_lo = rank > 0; s->has_hi = rank + 1 < world;
     s->device = ctx->device;
     if (const char* e = getenv("SPH_SLAB_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) s->wait_timeout_s = v; }
+    if (const char* e = getenv("SPH_SLAB_EARLY_STREAM")) s->early_own_stream = atoi(e) != 0;
     s->tr = *transport;
     s->host_staged = transport->host_buffers != 0;
     s->gcap = ctx->gcap;
@@ -1583,6 +1615,9 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
               hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&s->ev_deep, hipEventDisableTiming) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->early, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_early_go, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&s->ev_early_done, hipEventDisableTiming) == hipSuccess &&
               hipMalloc((void**)&s->d_lb, DL_WORDS * sizeof(uint32_t)) == hipSuccess &&
               hipMemset(s->d_lb, 0, DL_WORDS * sizeof(uint32_t)) == hipSuccess &&
               hipHostMalloc((void**)&s->h_lb, HL_WORDS * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
@@ -1633,6 +1668,7 @@ void sph_slab_destroy(sph_slab* s) {
     if (!s) return;
     hipSetDevice(s->device);
     slab_drain_comm(s);
+    if (s->early) hipStreamSynchronize(s->early);
     hipStreamSynchronize(s->c->stream);
     s->c->host_paced = false;
     slab_free(s);
@@ -1659,6 +1695,7 @@ int sph_slab_sync(sph_slab* s) {
     SPH_HIP(hipSetDevice(s->c->device));
     slab_drain_comm(s);
     SPH_HIP(hipStreamQuery(s->comm));
+    if (s->early) SPH_HIP(hipStreamSynchronize(s->early));
     int rc = sph_sync(s->c);
     if (rc) return rc;
     return slab_check_device_flags(s);
