@@ -158,9 +158,9 @@ void rank_main(const SlabJob& j, const Plan& pl, int rank, int world, int device
             if (sph_slab_ping(slab, std::max<size_t>(sizes[k] & ~(size_t)3, 4), 3, o) < 0) { ok = false; fail("sph_slab_ping"); }
             else res.ping_us[k] = o[0];
         }
-        // a migrant message that costs more than ~35 us on an idle device (or a halo-A message more than ~90): the innermost
-        // layers' force pass goes in front of the step's wait (sph_slab_set_early_force)
-        if (ok) sph_slab_set_early_force(slab, (res.ping_us[0] >= 35.0 || res.ping_us[1] >= 90.0) ? 1 : 0);
+        // the innermost layers' force pass goes in front of the step's wait (sph_slab_set_early_force)
+        // unless the links are so fast that it cannot pay (a migrant message under ~12 us and a halo-A message under ~45)
+        if (ok) sph_slab_set_early_force(slab, (res.ping_us[0] >= 12.0 || res.ping_us[1] >= 45.0) ? 1 : 0);
     }
     if (ok && j.warmup && (sph_slab_step(slab, j.dt, (uint32_t)j.substeps) < 0 || sph_slab_sync(slab) < 0)) { ok = false; fail("warm-up step"); }
     gate.wait();

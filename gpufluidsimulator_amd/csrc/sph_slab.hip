@@ -779,8 +779,8 @@ struct sph_slab {
     size_t stage_bytes = 0;
     uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0, inserts = 0, far_steps = 0, rest_msgs = 0;
     uint64_t exchanges = 0;              // transport calls so far (3 in a usual step: migrants, halo A, halo B)
-    bool early_force = false;            // the force pass of the innermost layers runs in front of the step's wait (sph_slab_set_early_force:
-                                         // pays when a message group costs more than ~35 us; the launcher decides from its pings)
+    bool early_force = true;             // the force pass of the innermost layers runs in front of the step's wait, on a stream of its own
+                                         // (sph_slab_set_early_force: ~3 us per step when the links are fast, -30 at 40 us per group)
     uint64_t early_launches = 0, early_used = 0;
     uint32_t early_span = 0;             // slots the last step's early range held: sizes this step's grid (what a grid misses, the interior launch computes)
     uint32_t* recut_blk = nullptr;       // sph_slab_recut: {down, up} counts per 1024-slot block, then their scan

@@ -605,10 +605,11 @@ class NativeSlabSimulation(SlabSimulation):
     call into libsph_hip.so per rank: sph_slab_step queues sort, migrants, halo A, density, halo B and the fused
     force pass on two HIP streams and waits for the device once (csrc/sph_slab.hip)."""
 
-    # a message group that costs more than this on an idle device (the preflight ping of the 8 KB migrant message) makes the
-    # early force launch pay: measured on a slab between its periodic images, DESIGN.md section 6
-    EARLY_FORCE_MIN_PING_US = 35.0
-    EARLY_FORCE_MIN_HALO_PING_US = 90.0      # ... or a halo-A-sized message more than this (a slow link rather than a late one)
+    # the early force launch (sph_slab_set_early_force) costs ~3 us per step when a message group takes less than this on an
+    # idle device (the preflight ping of the 8 KB migrant message) and wins beyond it: measured on a slab between its periodic
+    # images, DESIGN.md section 6.  "auto" switches it off only for such links.
+    EARLY_FORCE_MIN_PING_US = 12.0
+    EARLY_FORCE_MIN_HALO_PING_US = 45.0      # ... unless a halo-A-sized message takes more than this (a slow link rather than a late one)
 
     def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, ping_reps=3, early_force="auto", **kw):
         self._device_index = device_index
@@ -667,7 +668,7 @@ class NativeSlabSimulation(SlabSimulation):
         if self._early_force in (True, False):
             on, why = bool(self._early_force), "set by the caller"
         elif self.ping is None:
-            on, why = False, "no ping taken"
+            on, why = True, "no ping taken: the library's default"
         else:       # the slowest link any rank saw decides for all (a rank's choice is its own scheduling: nothing has to agree)
             worst = self.comm.allreduce_max(self.ping["migrants"]["mean_us"])
             worst_a = self.comm.allreduce_max(self.ping["halo_a"]["mean_us"])

@@ -397,14 +397,13 @@ enum {
 int sph_slab_timing_enable(sph_slab* s, int on);
 int sph_slab_timing_reset(sph_slab* s);
 int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]);
-/* on = 1: the fused force pass of the slab's innermost layers (at least six cell layers from either cut; slabs of 11 owned
- * layers and more) is queued IN FRONT of the step's host wait, behind the deep density: work that needs nothing from a
- * neighbour keeps the main stream busy while the migrant message and halo A are on their way.  It makes the step's time
- * nearly independent of the links' latency at a fixed price (three force launches instead of two: ~+40 us per step at 2 M
- * particles), so it pays when a message group costs more than ~35 us (measured on a slab between its
- * periodic images) -- default 0; a launcher decides from its pings (gpufluidsimulator_amd/slab.py, csrc/sph_headless.cpp).  Same
- * bits either way.  out = {steps that launched it, steps that used its result} (a step whose arrivals re-sort the slab
- * discards it). */
+/* on = 1 (default): the fused force pass of the slab's innermost layers (at least six cell layers from either cut; slabs of
+ * 11 owned layers and more) is queued IN FRONT of the step's host wait, behind the deep density, on a stream of its own: work
+ * that needs nothing from a neighbour keeps the device busy while the migrant message and halo A are on their way, and its
+ * tail runs beside the interior launch.  The step's time becomes nearly independent of the links' latency (DESIGN.md
+ * section 6, measured on a slab between its periodic images: +3 us per step with fast links, -10 at 20 us per message
+ * group, -30 at 40).  Same bits either way.  out = {steps that launched it, steps that used its result} (a step whose
+ * arrivals re-sort the slab discards it). */
 int sph_slab_set_early_force(sph_slab* s, int on);
 int sph_slab_early_force_stats(const sph_slab* s, uint64_t out[2]);
 /* TEST HOOK: raise sticky device-side error word `flag` (0: an arrival outside its boundary layer, 1: an arrival outside
