@@ -12,6 +12,8 @@
 //     from either cut; its slot range is read        into mapped host memory, then a sequence word
 //     from DEVICE memory: the host does not
 //     know the bounds yet)
+//   [early stream, behind the deep density by event: force+collision+integrate of the INNERMOST layers (>= 6 from either
+//    cut; every density they read is the deep launch's) -- keys by absolute slot, no mover marks; k_slab_early_finish]
 //   ............ host polls the sequence word (bounded): the only wait of the step, hidden behind the deep density ...
 //   [more than 255 leavers on a side: the rest of them in a second, exact-size message]
 //   --- a step WITHOUT arrivals (the usual one): the halo work goes to the comm stream at once ---
@@ -32,6 +34,9 @@
 // of its cell, what came down from above behind them): an N-slab run has the bits of the one-context run.
 // A rank that fails still exchanges what the step owes, then sends "abort" in its next migrant header (slab_fail): its
 // neighbours return SPH_E_PEER one step later instead of waiting for a timeout; a dead transport is aborted.
+//
+// Also here: the neighbour ping (sph_slab_ping), per-group and host-wait timing (sph_slab_timing_*), re-balancing on the
+// device (sph_slab_recut), and the loop transport (one slab between its periodic images: a middle rank's whole step on one GPU).
 //
 // The interior layers (all but the first and last owned layer) never look at a ghost, so their passes run while
 // the halos travel.  Messages go point to point to the two z-neighbours only: RCCL ncclSend/ncclRecv in one group
