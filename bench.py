@@ -378,7 +378,7 @@ def main():
                     help="with --force-slab: ONE slab between its own periodic images (loop transport) -- a middle rank's whole step, "
                          "halo work included, on one GPU; default lattice 256,256,32 (an eighth of C3)")
     ap.add_argument("--early-force", default="auto", choices=["auto", "on", "off"],
-                    help="--periodic-z: sph_slab_set_early_force; auto = the rule a real run applies to its pings (on unless a group takes < 12 us and a halo-A message < 45 us)")
+                    help="slab path (--gpus N, --periodic-z): sph_slab_set_early_force; auto = the rule a real run applies to its pings (on unless a group takes < 12 us and a halo-A message < 45 us)")
     ap.add_argument("--link-gbs", type=float, default=153.0, help="--periodic-z: bandwidth a message is held back for (0: no hold)")
     ap.add_argument("--link-latency-us", type=float, default=10.0, help="--periodic-z: latency a message is held back for")
     ap.add_argument("--one-gpu", action="store_true",

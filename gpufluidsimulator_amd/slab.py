@@ -906,8 +906,9 @@ def bench_rank(comm, local, args, transport, log=None):
     rank, world = comm.rank, comm.world
     log = log or (lambda msg: print(msg, file=sys.stderr, flush=True))
     cfg, strong, label = bench_config(args, world)
+    ef = {"on": True, "off": False}.get(getattr(args, "early_force", "auto"), "auto")
     sim = NativeSlabSimulation(comm, cfg["box"], cfg["grid"], device_index=local, transport=transport,
-                               lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"])
+                               lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"], early_force=ef)
     layers = [b - a for a, b in zip(sim.cuts, sim.cuts[1:])]
     assert min(layers) >= MIN_SLAB_LAYERS or world == 1, sim.cuts
     mixed = getattr(args, "precision", "f32") == "mixed"        # BASELINE config 5's arithmetic
