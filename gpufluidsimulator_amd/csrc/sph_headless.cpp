@@ -160,7 +160,8 @@ void rank_main(const SlabJob& j, const Plan& pl, int rank, int world, int device
         }
         // the innermost layers' force pass goes in front of the step's wait (sph_slab_set_early_force)
         // unless the links are so fast that it cannot pay (a migrant message under ~12 us and a halo-A message under ~45)
-        if (ok) sph_slab_set_early_force(slab, (res.ping_us[0] >= 12.0 || res.ping_us[1] >= 45.0) ? 1 : 0);
+        // -- and never when the ranks share a device (-onegpu): their big kernels would evict each other's L2 working sets
+        if (ok) sph_slab_set_early_force(slab, (!hub && (res.ping_us[0] >= 12.0 || res.ping_us[1] >= 45.0)) ? 1 : 0);
     }
     if (ok && j.warmup && (sph_slab_step(slab, j.dt, (uint32_t)j.substeps) < 0 || sph_slab_sync(slab) < 0)) { ok = false; fail("warm-up step"); }
     gate.wait();

@@ -667,6 +667,11 @@ class NativeSlabSimulation(SlabSimulation):
     def _decide_early_force(self):
         if self._early_force in (True, False):
             on, why = bool(self._early_force), "set by the caller"
+        elif self._transport_kind != "rccl":
+            # ranks that SHARE a device (threads over the device-to-device transport, processes over gloo): one rank's early
+            # launch then runs beside the other ranks' big kernels all the time and they evict each other's L2 working sets --
+            # measured 4.81 against 3.86 ms per step for two 8.4 M-particle slabs on one GPU.  It is meant for one rank per GPU.
+            on, why = False, f"transport '{self._transport_kind}': the ranks share a device"
         elif self.ping is None:
             on, why = True, "no ping taken: the library's default"
         else:       # the slowest link any rank saw decides for all (a rank's choice is its own scheduling: nothing has to agree)

@@ -402,7 +402,9 @@ int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]);
  * that needs nothing from a neighbour keeps the device busy while the migrant message and halo A are on their way, and its
  * tail runs beside the interior launch.  The step's time becomes nearly independent of the links' latency (DESIGN.md
  * section 6, measured on a slab between its periodic images: +3 us per step with fast links, -10 at 20 us per message
- * group, -30 at 40).  Same bits either way.  out = {steps that launched it, steps that used its result} (a step whose
+ * group, -30 at 40).  For ONE rank per device: ranks that share a GPU (rehearsals over the local / host transports) should
+ * switch it off -- their big kernels then run beside each other all the time and evict each other's L2 working sets (two
+ * 8.4 M-particle slabs on one GPU: 4.81 against 3.86 ms per step); the launchers do.  Same bits either way.  out = {steps that launched it, steps that used its result} (a step whose
  * arrivals re-sort the slab discards it). */
 int sph_slab_set_early_force(sph_slab* s, int on);
 int sph_slab_early_force_stats(const sph_slab* s, uint64_t out[2]);
