@@ -630,12 +630,12 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
                                                                           const uint2* __restrict__ cells,
                                                                           float2* __restrict__ dp, float2* __restrict__ cw,
                                                                           Targets tg, GridDesc g, Phys ph) {
-    struct XY { h2 x, y; };                                   // 8 bytes: one ds_read_b64 per pair
-    __shared__ XY s_xy[2 * LDS_PAIRS];
-    __shared__ h2 s_z[2 * LDS_PAIRS];
+    // a pair of candidates: x as COARSE + FINE halves (below), y, z -- 16 bytes, two ds_read_b64
+    struct P4 { h2 xh, xl, y, z; };
+    __shared__ __attribute__((aligned(8))) P4 s_p[2 * LDS_PAIRS];
     const h2 zero = h2{(_Float16)0, (_Float16)0}, one = h2{(_Float16)1, (_Float16)1};
     for (uint32_t k = threadIdx.x; k < 2 * LDS_PAIRS; k += PAIR_THREADS) {      // over-reads stay finite
-        s_xy[k].x = zero; s_xy[k].y = zero; s_z[k] = zero;
+        s_p[k].xh = zero; s_p[k].xl = zero; s_p[k].y = zero; s_p[k].z = zero;
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -654,12 +654,23 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
     const float rx = __builtin_amdgcn_readfirstlane(pi.x), ry = __builtin_amdgcn_readfirstlane(pi.y),
                 rz = __builtin_amdgcn_readfirstlane(pi.z);
     const float inv_h = 1.0f / ph.h;
-    const h2 tx = h2_splat((pi.x - rx) * inv_h), ty = h2_splat((pi.y - ry) * inv_h), tz = h2_splat((pi.z - rz) * inv_h);
+    // x is the long axis of a wave (64 sorted particles are ~8 cells of one x-row, but 16+ cells where the fluid is thin, and
+    // a wave that straddles the end of a row holds both ends of the fluid): a single fp16 of (x - rx) / h would lose the
+    // differences of far lanes.  So x travels as TWO halves: a COARSE part, the nearest multiple of h / 2 (exact in fp16 up
+    // to 1024 h), and the FINE rest in [-h / 4, h / 4] (2^-13 h); dx = (coarse_i - coarse_j) + (fine_i - fine_j): the first
+    // difference is exact, the second precise, the sum is a number of a few h.  y and z span a cell or two inside a wave.
+    auto split = [&](float X, _Float16& hi, _Float16& lo) {
+        const float c = rintf(X + X) * 0.5f;
+        hi = (_Float16)c; lo = (_Float16)(X - c);
+    };
+    _Float16 txh_, txl_;
+    split((pi.x - rx) * inv_h, txh_, txl_);
+    const h2 txh = h2{txh_, txh_}, txl = h2{txl_, txl_}, ty = h2_splat((pi.y - ry) * inv_h), tz = h2_splat((pi.z - rz) * inv_h);
     float4 q0, q1, q2;
     float acc = 0.f;
     // one PAIR of candidates (the two halves of every operand)
-    auto pair_math = [&](h2& row, h2 x, h2 y, h2 z, h2 m, bool masked) {
-        const h2 dx = tx - x, dy = ty - y, dz = tz - z;
+    auto pair_math = [&](h2& row, h2 xh, h2 xl, h2 y, h2 z, h2 m, bool masked) {
+        const h2 dx = (txh - xh) + (txl - xl), dy = ty - y, dz = tz - z;
         h2 t = one - dx * dx;                                  // 1 - r'^2: three v_pk_fma_f16
         t = t - dy * dy;
         t = t - dz * dz;
@@ -676,17 +687,15 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
             cw[i] = neighbour_terms(ph, rho, p);
         }
     };
-    // The packed arithmetic works on coordinates RELATIVE to the wave's reference point, and fp16 carries 11 bits: that is
-    // 2^-9 h while everything lies within ~4 h of the reference -- an ordinary wave: 64 sorted particles are ~8 cells of one
-    // x-row, 5 h -- and NOTHING when the wave's 64 particles are far apart: a wave that straddles the end of an x-row (its
-    // second half starts again at the other side of the fluid, tens of h away) or holds the few particles of a nearly empty
-    // cell layer.  Round 5 found densities 33 % off on such waves (config 5 cut into slabs against one context: the cuts
-    // change which particles share a wave).  A wave with a lane further than MIXED_SPAN h from the reference -- and a wave
-    // with a pathological hull, as in the fp32 kernel -- therefore takes the fp32 direct walk: every lane gathers ITS OWN
-    // candidates and sums (h^2 - r^2)^3 in fp32, exactly k_density's arithmetic and order (those particles get the fp32
-    // result, bit for bit).  They are few: one wave in sixteen where a 128-cell row holds 8 particles per cell.
+    // y and z are relative to the wave's first particle in ONE fp16 each: 2^-9 h while the wave's particles lie within ~4 h of
+    // each other in y and z -- one x-row, or two at a row's end.  A wave whose particles are further apart than MIXED_SPAN h in
+    // y or z (the scattered particles of a nearly empty layer) -- and a wave with a pathological hull, as in the fp32 kernel --
+    // takes the fp32 direct walk: every lane gathers ITS OWN candidates and sums (h^2 - r^2)^3 in fp32, k_density's arithmetic
+    // and order.  (Round 5 found densities 33 % off on far-apart waves -- config 5 cut into slabs against one context: the cuts
+    // change which particles share a wave; its first cure sent every wave wider than 8 h in x down this path, which in a
+    // flowing dam is a large share of them: k_density_h 0.88 -> 1.94 ms.  The split x above keeps them on the packed path.)
     constexpr float MIXED_SPAN = 8.0f;
-    const float far = fmaxf(fmaxf(fabsf(pi.x - rx), fabsf(pi.y - ry)), fabsf(pi.z - rz)) * inv_h;
+    const float far = fmaxf(fabsf(pi.y - ry), fabsf(pi.z - rz)) * inv_h;
     if (__ballot(active && far > MIXED_SPAN) != 0ull || wave_has_long_hull(H, my_key, tg.direct_hull)) {
         const uint32_t me = active ? i : tgt_hi - 1u;        // (= ii, derived again: nothing of this branch stays alive in the staged walk)
         const float h2_v = in_vgpr(ph.h2);
@@ -721,15 +730,14 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
             q2 = posi[a + 2u * lane + 2u];
         },
         [&]() {
-            const _Float16 x0 = (_Float16)((q0.x - rx) * inv_h), x1 = (_Float16)((q1.x - rx) * inv_h),
-                           x2 = (_Float16)((q2.x - rx) * inv_h);
+            _Float16 x0, x1, x2, l0_, l1_, l2_;
+            split((q0.x - rx) * inv_h, x0, l0_); split((q1.x - rx) * inv_h, x1, l1_); split((q2.x - rx) * inv_h, x2, l2_);
             const _Float16 y0 = (_Float16)((q0.y - ry) * inv_h), y1 = (_Float16)((q1.y - ry) * inv_h),
                            y2 = (_Float16)((q2.y - ry) * inv_h);
             const _Float16 z0 = (_Float16)((q0.z - rz) * inv_h), z1 = (_Float16)((q1.z - rz) * inv_h),
                            z2 = (_Float16)((q2.z - rz) * inv_h);
-            s_xy[slice + lane].x = h2{x0, x1}; s_xy[slice + lane].y = h2{y0, y1}; s_z[slice + lane] = h2{z0, z1};
-            s_xy[LDS_PAIRS + slice + lane].x = h2{x1, x2}; s_xy[LDS_PAIRS + slice + lane].y = h2{y1, y2};
-            s_z[LDS_PAIRS + slice + lane] = h2{z1, z2};
+            s_p[slice + lane] = P4{h2{x0, x1}, h2{l0_, l1_}, h2{y0, y1}, h2{z0, z1}};
+            s_p[LDS_PAIRS + slice + lane] = P4{h2{x1, x2}, h2{l1_, l2_}, h2{y1, y2}, h2{z1, z2}};
         },
         [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
@@ -737,9 +745,12 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
             uint32_t idx = w.idx;
             h2 row = zero;                                             // this row's sum of W', both halves
             auto pair = [&](int u, h2 m, bool masked) {
-                const h2 x = ((lds_h2_ptr)&s_xy[idx + u].x)[0], y = ((lds_h2_ptr)&s_xy[idx + u].x)[1];
-                const h2 z = ((lds_h2_ptr)s_z)[idx + u];
-                pair_math(row, x, y, z, m, masked);
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                typedef const volatile __attribute__((address_space(3))) h4* lds_h4_ptr;
+                const lds_h4_ptr e = (lds_h4_ptr)&s_p[idx + u];                  // {xh, xl} and {y, z}: two ds_read_b64
+                const h4 a = e[0], b = e[1];
+                pair_math(row, __builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(a, a, 2, 3),
+                          __builtin_shufflevector(b, b, 0, 1), __builtin_shufflevector(b, b, 2, 3), m, masked);
             };
             uint32_t k = 0;
             for (; k < w.kmin; k += HUNROLL) {
