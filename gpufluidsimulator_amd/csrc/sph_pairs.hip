@@ -694,7 +694,10 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
     // and order.  (Round 5 found densities 33 % off on far-apart waves -- config 5 cut into slabs against one context: the cuts
     // change which particles share a wave; its first cure sent every wave wider than 8 h in x down this path, which in a
     // flowing dam is a large share of them: k_density_h 0.88 -> 1.94 ms.  The split x above keeps them on the packed path.)
-    constexpr float MIXED_SPAN = 8.0f;
+#ifndef SPH_MIXED_SPAN
+#define SPH_MIXED_SPAN 8.0f
+#endif
+    constexpr float MIXED_SPAN = SPH_MIXED_SPAN;
     const float far = fmaxf(fabsf(pi.y - ry), fabsf(pi.z - rz)) * inv_h;
     if (__ballot(active && far > MIXED_SPAN) != 0ull || wave_has_long_hull(H, my_key, tg.direct_hull)) {
         const uint32_t me = active ? i : tgt_hi - 1u;        // (= ii, derived again: nothing of this branch stays alive in the staged walk)

@@ -21,6 +21,7 @@ def one():
     n = cfg["lattice"][0] * cfg["lattice"][1] * cfg["lattice"][2]
     dt = float(ic.DEFAULT_DT)
     with capi.Context(n, box=cfg["box"], grid=cfg["grid"]) as c:
+        c.set_precision(bool(os.environ.get("KB_MIXED")))          # KB_MIXED=1: BASELINE config 5's arithmetic (k_density_h)
         if sys.argv[2] == "prepare":
             c.reset_lattice(cfg["lattice"], jitter=True)
             c.step(dt, 6000); c.sync()
