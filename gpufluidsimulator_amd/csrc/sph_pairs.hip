@@ -590,6 +590,8 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
 // row; the physical scale m * POLY6 * h^6 is applied once, in fp32.  Tolerance: DESIGN.md section 4 (mixed).
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef const volatile __attribute__((address_space(3))) h2* lds_h2_ptr;
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) h4* lds_h4_ptr;
 
 __device__ __forceinline__ h2 h2_splat(float x) { const _Float16 v = (_Float16)x; return h2{v, v}; }
 // 1.0 in the halves that are valid, 0.0 in the others
@@ -625,17 +627,49 @@ __device__ __forceinline__ PairWalk pair_walk(uint32_t slice_pairs, uint32_t l0,
     return w;
 }
 
-__global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const float4* __restrict__ posi,
-                                                                          const uint32_t* __restrict__ keyS,
-                                                                          const uint2* __restrict__ cells,
-                                                                          float2* __restrict__ dp, float2* __restrict__ cw,
-                                                                          Targets tg, GridDesc g, Phys ph) {
-    // a pair of candidates: x as COARSE + FINE halves (below), y, z -- 16 bytes, two ds_read_b64
-    struct P4 { h2 xh, xl, y, z; };
-    __shared__ __attribute__((aligned(8))) P4 s_p[2 * LDS_PAIRS];
+#ifndef SPH_DENSH_OCC
+#define SPH_DENSH_OCC 5          // <= 96 VGPRs: at 6 waves (80) the pass loop spills 28 registers, 1.31 ms against 1.16
+#endif
+#ifndef SPH_MIXED_SPAN
+#define SPH_MIXED_SPAN 6.0f      // h: how far from the reference a target may lie for the plain packed walk
+#endif
+#ifndef SPH_MIXED_PASSES
+#define SPH_MIXED_PASSES 3       // reference points tried on a far-apart wave before the rest takes the fp32 walk
+#endif
+
+// The packed arithmetic works on coordinates RELATIVE to a reference point, and fp16 carries 11 bits: that is 2^-9 h while
+// everything lies within ~4 h of the reference, 2^-8 h up to 8 h -- and nothing when the particles are far apart.  An
+// ordinary wave is 64 sorted particles = ~8 cells of one x-row = 5 h, and rounds 3 and 4 took the wave's first particle as the
+// reference for everybody.  That is wrong for a wave that straddles the end of an x-row (its second half starts again at the
+// other side of the fluid, tens of h away), a wave in thin fluid (fewer particles per cell, more cells per wave: wide in x;
+// together 7.5 % of the waves of the flowing C3 dam are wider than 8 h in x), one across the end of a cell layer (the other
+// side in y; 130 waves), or one that holds the scattered particles of a nearly empty region.  Round 5 found densities 33 %
+// off on such waves (config 5 cut into slabs against one context: the cuts change which particles share a wave).  Now:
+//   x is carried as a coarse part (a multiple of h/2: exact in fp16 up to 1024 h) plus a fine part (|.| <= h/4):
+//     dx = (txh - xh) + (txl - xl), two more packed instructions per pair, right at any width;
+//   y and z by PASSES: the first lane not yet served gives the reference, the lanes within MIXED_SPAN h of it in y and z
+//     are served by this pass -- their row ranges staged and walked as ever, everybody else's ranges empty -- and the rest wait
+//     for the next (one pass for an ordinary wave, two for a wave across a layer's end); after MIXED_PASSES passes the lanes
+//     still waiting are scattered particles with short candidate lists: they gather their own candidates and sum in fp32
+//     (k_density's arithmetic), all in one last walk.
+// The price, and what else was tried (profiles/r05_mixed_wide_waves_ab.txt; flowing C3, round 4's kernel 1.08 ms): this form
+// 1.31 ms.  Every far-apart wave down the fp32 gather walk: a wave of DENSE fluid takes ~0.2 ms in it and the 130 waves at
+// the layer ends became the kernel's tail, 1.66 ms.  Passes in x too instead of the split: a thin-fluid wave needs 4-7 of
+// them, 1.47 ms.  Round 4's walk kept for the waves within 6 h of their first particle and this one for the rest, in one
+// kernel: 1.39 ms -- slower than this one for everybody; the two inlined walks no longer share the instruction cache (the
+// same kernel with the second walk never taken: 1.17 ms).
+__global__ __launch_bounds__(PAIR_THREADS, SPH_DENSH_OCC) void k_density_h(const float4* __restrict__ posi,
+                                                                           const uint32_t* __restrict__ keyS,
+                                                                           const uint2* __restrict__ cells,
+                                                                           float2* __restrict__ dp, float2* __restrict__ cw,
+                                                                           Targets tg, GridDesc g, Phys ph) {
+    struct XY { h2 x, y; };                                   // coarse x, y: one ds_read_b64 per pair
+    struct ZL { h2 z, xl; };                                  // z, fine x: another
+    __shared__ XY s_xy[2 * LDS_PAIRS];
+    __shared__ ZL s_zl[2 * LDS_PAIRS];
     const h2 zero = h2{(_Float16)0, (_Float16)0}, one = h2{(_Float16)1, (_Float16)1};
     for (uint32_t k = threadIdx.x; k < 2 * LDS_PAIRS; k += PAIR_THREADS) {      // over-reads stay finite
-        s_p[k].xh = zero; s_p[k].xl = zero; s_p[k].y = zero; s_p[k].z = zero;
+        s_xy[k].x = zero; s_xy[k].y = zero; s_zl[k].z = zero; s_zl[k].xl = zero;
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -645,129 +679,141 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_DENS_OCC) void k_density_h(const 
     const bool active = i < tgt_hi;
     const uint32_t ii = active ? i : tgt_hi - 1;
     const float4 pi = posi[ii];
-    Rows R;
     const uint32_t my_key = keyS[ii];
-    lane_rows(cells, g, my_key, active, R);
-    Hulls H;
-    wave_hulls(R, H);
-    // reference point: the wave's first particle (wave-uniform; every candidate of the wave lies within a few cells)
-    const float rx = __builtin_amdgcn_readfirstlane(pi.x), ry = __builtin_amdgcn_readfirstlane(pi.y),
-                rz = __builtin_amdgcn_readfirstlane(pi.z);
     const float inv_h = 1.0f / ph.h;
-    // x is the long axis of a wave (64 sorted particles are ~8 cells of one x-row, but 16+ cells where the fluid is thin, and
-    // a wave that straddles the end of a row holds both ends of the fluid): a single fp16 of (x - rx) / h would lose the
-    // differences of far lanes.  So x travels as TWO halves: a COARSE part, the nearest multiple of h / 2 (exact in fp16 up
-    // to 1024 h), and the FINE rest in [-h / 4, h / 4] (2^-13 h); dx = (coarse_i - coarse_j) + (fine_i - fine_j): the first
-    // difference is exact, the second precise, the sum is a number of a few h.  y and z span a cell or two inside a wave.
-    auto split = [&](float X, _Float16& hi, _Float16& lo) {
-        const float c = rintf(X + X) * 0.5f;
-        hi = (_Float16)c; lo = (_Float16)(X - c);
-    };
-    _Float16 txh_, txl_;
-    split((pi.x - rx) * inv_h, txh_, txl_);
-    const h2 txh = h2{txh_, txh_}, txl = h2{txl_, txl_}, ty = h2_splat((pi.y - ry) * inv_h), tz = h2_splat((pi.z - rz) * inv_h);
     float4 q0, q1, q2;
-    float acc = 0.f;
-    // one PAIR of candidates (the two halves of every operand)
-    auto pair_math = [&](h2& row, h2 xh, h2 xl, h2 y, h2 z, h2 m, bool masked) {
-        const h2 dx = (txh - xh) + (txl - xl), dy = ty - y, dz = tz - z;
-        h2 t = one - dx * dx;                                  // 1 - r'^2: three v_pk_fma_f16
-        t = t - dy * dy;
-        t = t - dz * dz;
-        t = __builtin_elementwise_max(t, zero);                // r' < 1  <=>  r < h
-        if (masked) t = t * m;
-        row = row + (t * t) * t;
-    };
-    auto finish = [&]() {
-        if (active) {
-            const float h2f = ph.h2;
-            float rho = acc * (ph.poly6_mass * (h2f * h2f * h2f));          // m POLY6 h^6 sum (1 - r'^2)^3
-            float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
-            dp[i] = make_float2(rho, p);
-            cw[i] = neighbour_terms(ph, rho, p);
-        }
-    };
-    // y and z are relative to the wave's first particle in ONE fp16 each: 2^-9 h while the wave's particles lie within ~4 h of
-    // each other in y and z -- one x-row, or two at a row's end.  A wave whose particles are further apart than MIXED_SPAN h in
-    // y or z (the scattered particles of a nearly empty layer) -- and a wave with a pathological hull, as in the fp32 kernel --
-    // takes the fp32 direct walk: every lane gathers ITS OWN candidates and sums (h^2 - r^2)^3 in fp32, k_density's arithmetic
-    // and order.  (Round 5 found densities 33 % off on far-apart waves -- config 5 cut into slabs against one context: the cuts
-    // change which particles share a wave; its first cure sent every wave wider than 8 h in x down this path, which in a
-    // flowing dam is a large share of them: k_density_h 0.88 -> 1.94 ms.  The split x above keeps them on the packed path.)
-#ifndef SPH_MIXED_SPAN
-#define SPH_MIXED_SPAN 8.0f
-#endif
-    constexpr float MIXED_SPAN = SPH_MIXED_SPAN;
-    const float far = fmaxf(fabsf(pi.y - ry), fabsf(pi.z - rz)) * inv_h;
-    if (__ballot(active && far > MIXED_SPAN) != 0ull || wave_has_long_hull(H, my_key, tg.direct_hull)) {
-        const uint32_t me = active ? i : tgt_hi - 1u;        // (= ii, derived again: nothing of this branch stays alive in the staged walk)
-        const float h2_v = in_vgpr(ph.h2);
-        float acc32 = 0.f;
-        direct_rows(cells, g, keyS[me], active, [&](uint32_t l0, uint32_t len, uint32_t T) {      // a lane out of range reads itself (masked)
-            for (uint32_t t = 0; t < T; t += 2u) {
-                float4 q[2];
-#pragma unroll
-                for (uint32_t u = 0; u < 2u; u++) q[u] = posi[t + u < len ? l0 + t + u : me];
-#pragma unroll
-                for (uint32_t u = 0; u < 2u; u++) {
-                    const float dx = pi.x - q[u].x, dy = pi.y - q[u].y, dz = pi.z - q[u].z;
-                    float d = fmaxf(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, h2_v))), 0.f);
-                    d = t + u < len ? d : 0.f;
-                    acc32 = fmaf(d * d, d, acc32);
+    float acc = 0.f;          // sum of the NORMALISED kernel (1 - r'^2)^3 over the rows walked in packed fp16
+    float acc32 = 0.f;        // sum of (h^2 - r^2)^3 over the candidates of the lanes left to the fp32 walk
+
+    // the lanes `in`, relative to (rx, ry, rz): staged hull walk, or the per-lane gather when a hull is long
+    auto serve = [&](bool in, float rx, float ry, float rz) {
+        const float X = (pi.x - rx) * inv_h;
+        const float Xc = rintf(X + X) * 0.5f;
+        const h2 tx = h2_splat(Xc), txl = h2_splat(X - Xc);
+        const h2 ty = h2_splat((pi.y - ry) * inv_h), tz = h2_splat((pi.z - rz) * inv_h);
+        // one PAIR of candidates (the two halves of every operand)
+        auto pair_math = [&](h2& row, h2 x, h2 xl, h2 y, h2 z, h2 m, bool masked) {
+            const h2 dx = (tx - x) + (txl - xl), dy = ty - y, dz = tz - z;
+            h2 t = one - dx * dx;                                  // 1 - r'^2: three v_pk_fma_f16
+            t = t - dy * dy;
+            t = t - dz * dz;
+            t = __builtin_elementwise_max(t, zero);                // r' < 1  <=>  r < h
+            if (masked) t = t * m;
+            row = row + (t * t) * t;
+        };
+        auto x_parts = [&](float qx, _Float16& hi, _Float16& lo) {
+            const float v = (qx - rx) * inv_h;
+            const float c = rintf(v + v) * 0.5f;
+            hi = (_Float16)c;
+            lo = (_Float16)(v - c);
+        };
+        Rows R;
+        lane_rows(cells, g, my_key, in, R);
+        Hulls H;
+        wave_hulls(R, H);
+        if (wave_has_long_hull(H, my_key, tg.direct_hull)) {
+            direct_rows(cells, g, keyS[ii], in, [&](uint32_t l0, uint32_t len, uint32_t) {        // every lane gathers its own candidates, two at a time
+                const uint32_t T = wave_max_u32((len + 1u) >> 1);
+                h2 row = zero;
+                for (uint32_t k = 0; k < T; k++) {
+                    const bool v0 = 2u * k < len, v1 = 2u * k + 1u < len;
+                    const float4 a = posi[v0 ? l0 + 2u * k : ii], b = posi[v1 ? l0 + 2u * k + 1u : ii];
+                    _Float16 xa, xb, la, lb;
+                    x_parts(a.x, xa, la);
+                    x_parts(b.x, xb, lb);
+                    const h2 x = h2{xa, xb}, xl = h2{la, lb};
+                    const h2 y = h2{(_Float16)((a.y - ry) * inv_h), (_Float16)((b.y - ry) * inv_h)};
+                    const h2 z = h2{(_Float16)((a.z - rz) * inv_h), (_Float16)((b.z - rz) * inv_h)};
+                    pair_math(row, x, xl, y, z, h2_mask(v0, v1), true);
                 }
-            }
-        });
-        if (active) {
-            const float rho = acc32 * ph.poly6_mass;
-            const float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
-            dp[i] = make_float2(rho, p);
-            cw[i] = neighbour_terms(ph, rho, p);
+                acc += (float)row.x + (float)row.y;
+            });
+            return;
         }
-        return;
-    }
-    traverse(
-        H,
-        [&](uint32_t a) {   // lane L stages candidates 2L, 2L+1 and 2L+2; the arrays are padded by 2*PIECE
-            q0 = posi[a + 2u * lane];
-            q1 = posi[a + 2u * lane + 1u];
-            q2 = posi[a + 2u * lane + 2u];
-        },
-        [&]() {
-            _Float16 x0, x1, x2, l0_, l1_, l2_;
-            split((q0.x - rx) * inv_h, x0, l0_); split((q1.x - rx) * inv_h, x1, l1_); split((q2.x - rx) * inv_h, x2, l2_);
-            const _Float16 y0 = (_Float16)((q0.y - ry) * inv_h), y1 = (_Float16)((q1.y - ry) * inv_h),
-                           y2 = (_Float16)((q2.y - ry) * inv_h);
-            const _Float16 z0 = (_Float16)((q0.z - rz) * inv_h), z1 = (_Float16)((q1.z - rz) * inv_h),
-                           z2 = (_Float16)((q2.z - rz) * inv_h);
-            s_p[slice + lane] = P4{h2{x0, x1}, h2{l0_, l1_}, h2{y0, y1}, h2{z0, z1}};
-            s_p[LDS_PAIRS + slice + lane] = P4{h2{x1, x2}, h2{l1_, l2_}, h2{y1, y2}, h2{z1, z2}};
-        },
-        [&](int r, uint32_t a, uint32_t b) {
-            const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
-            const PairWalk w = pair_walk(slice, l1 > l0 ? l0 - a : 0u, l1 > l0 ? l1 - a : 0u);
-            uint32_t idx = w.idx;
-            h2 row = zero;                                             // this row's sum of W', both halves
-            auto pair = [&](int u, h2 m, bool masked) {
-                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                typedef const volatile __attribute__((address_space(3))) h4* lds_h4_ptr;
-                const lds_h4_ptr e = (lds_h4_ptr)&s_p[idx + u];                  // {xh, xl} and {y, z}: two ds_read_b64
-                const h4 a = e[0], b = e[1];
-                pair_math(row, __builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(a, a, 2, 3),
-                          __builtin_shufflevector(b, b, 0, 1), __builtin_shufflevector(b, b, 2, 3), m, masked);
-            };
-            uint32_t k = 0;
-            for (; k < w.kmin; k += HUNROLL) {
+        traverse(
+            H,
+            [&](uint32_t a) {   // lane L stages candidates 2L, 2L+1 and 2L+2; the arrays are padded by 2*PIECE
+                q0 = posi[a + 2u * lane];
+                q1 = posi[a + 2u * lane + 1u];
+                q2 = posi[a + 2u * lane + 2u];
+            },
+            [&]() {
+                _Float16 x0, x1, x2, l0, l1, l2;
+                x_parts(q0.x, x0, l0);
+                x_parts(q1.x, x1, l1);
+                x_parts(q2.x, x2, l2);
+                const _Float16 y0 = (_Float16)((q0.y - ry) * inv_h), y1 = (_Float16)((q1.y - ry) * inv_h),
+                               y2 = (_Float16)((q2.y - ry) * inv_h);
+                const _Float16 z0 = (_Float16)((q0.z - rz) * inv_h), z1 = (_Float16)((q1.z - rz) * inv_h),
+                               z2 = (_Float16)((q2.z - rz) * inv_h);
+                s_xy[slice + lane].x = h2{x0, x1}; s_xy[slice + lane].y = h2{y0, y1};
+                s_zl[slice + lane].z = h2{z0, z1}; s_zl[slice + lane].xl = h2{l0, l1};
+                s_xy[LDS_PAIRS + slice + lane].x = h2{x1, x2}; s_xy[LDS_PAIRS + slice + lane].y = h2{y1, y2};
+                s_zl[LDS_PAIRS + slice + lane].z = h2{z1, z2}; s_zl[LDS_PAIRS + slice + lane].xl = h2{l1, l2};
+            },
+            [&](int r, uint32_t a, uint32_t b) {
+                const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
+                const PairWalk w = pair_walk(slice, l1 > l0 ? l0 - a : 0u, l1 > l0 ? l1 - a : 0u);
+                uint32_t idx = w.idx;
+                h2 row = zero;                                             // this row's sum of W', both halves
+                auto pair = [&](int u, h2 m, bool masked) {
+                    const h4 xy = ((lds_h4_ptr)s_xy)[idx + u], zl = ((lds_h4_ptr)s_zl)[idx + u];
+                    pair_math(row, __builtin_shufflevector(xy, xy, 0, 1), __builtin_shufflevector(zl, zl, 2, 3),
+                              __builtin_shufflevector(xy, xy, 2, 3), __builtin_shufflevector(zl, zl, 0, 1), m, masked);
+                };
+                uint32_t k = 0;
+                for (; k < w.kmin; k += HUNROLL) {
 #pragma unroll
-                for (int u = 0; u < HUNROLL; u++) pair(u, one, false);
-                idx += HUNROLL;
-            }
-            for (; k < w.T; k++) {                                     // until every lane is through its range
-                pair(0, h2_mask(k < w.whole + (w.odd ? 1u : 0u), k < w.whole), true);
-                idx++;
-            }
-            acc += (float)row.x + (float)row.y;
-        });
-    finish();
+                    for (int u = 0; u < HUNROLL; u++) pair(u, one, false);
+                    idx += HUNROLL;
+                }
+                for (; k < w.T; k++) {                                     // until every lane is through its range
+                    pair(0, h2_mask(k < w.whole + (w.odd ? 1u : 0u), k < w.whole), true);
+                    idx++;
+                }
+                acc += (float)row.x + (float)row.y;
+            });
+    };
+
+    constexpr float MIXED_SPAN = SPH_MIXED_SPAN;
+    uint64_t todo = __ballot(active);
+    for (int pass = 0; todo != 0ull; pass++) {                // wave-uniform
+        if (pass == SPH_MIXED_PASSES) {
+            const bool in = ((todo >> lane) & 1ull) != 0ull;
+            const float h2_v = in_vgpr(ph.h2);
+            direct_rows(cells, g, keyS[ii], in, [&](uint32_t l0, uint32_t len, uint32_t T) {      // a lane out of range reads itself (masked)
+                for (uint32_t t = 0; t < T; t += 2u) {
+                    float4 q[2];
+#pragma unroll
+                    for (uint32_t u = 0; u < 2u; u++) q[u] = posi[t + u < len ? l0 + t + u : ii];
+#pragma unroll
+                    for (uint32_t u = 0; u < 2u; u++) {
+                        const float dx = pi.x - q[u].x, dy = pi.y - q[u].y, dz = pi.z - q[u].z;
+                        float d = fmaxf(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, h2_v))), 0.f);
+                        d = t + u < len ? d : 0.f;
+                        acc32 = fmaf(d * d, d, acc32);
+                    }
+                }
+            });
+            break;
+        }
+        const int lead = __builtin_ctzll(todo);
+        const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pi.x), lead)),
+                    ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pi.y), lead)),
+                    rz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pi.z), lead));
+        const float far = fmaxf(fabsf(pi.y - ry), fabsf(pi.z - rz)) * inv_h;
+        const bool in = ((todo >> lane) & 1ull) != 0ull && far <= MIXED_SPAN;      // (the lead lane: far = 0)
+        todo &= ~__ballot(in);
+        serve(in, rx, ry, rz);
+    }
+    if (active) {
+        const float h2f = ph.h2;
+        // m POLY6 h^6 sum (1 - r'^2)^3 for the packed walks + m POLY6 sum (h^2 - r^2)^3 for the fp32 walk
+        const float rho = fmaf(acc, ph.poly6_mass * (h2f * h2f * h2f), acc32 * ph.poly6_mass);
+        const float p = fmaxf(0.f, ph.gas_constant * (rho - ph.rest_density));
+        dp[i] = make_float2(rho, p);
+        cw[i] = neighbour_terms(ph, rho, p);
+    }
 }
 
 int launch_density_range(sph_ctx* c, uint32_t lo, uint32_t hi);

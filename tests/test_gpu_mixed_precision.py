@@ -81,8 +81,8 @@ def test_mixed_density_on_waves_whose_particles_are_far_apart():
     while the wave's 64 sorted particles lie within a few h of each other.  A wave that straddles the end of an x-row (its
     second half starts at the other side of the fluid) or holds the scattered particles of a nearly empty layer had
     densities up to 33 % off (found by cutting config 5 into slabs: the cuts change which particles share a wave).  Now x
-    travels as a coarse + a fine fp16 half (exact coarse differences), and waves that are far apart in y or z take the
-    fp32 walk.  A long flat slab of fluid (100 x 3 x 5 lattice: every x-row is 31 h long and no row is a multiple of 64
+    travels as a coarse + a fine fp16 half (exact coarse differences), and a wave that is far apart in y or z is walked
+    in passes, one reference point per group of lanes (the stragglers after three passes gather in fp32).  A long flat slab of fluid (100 x 3 x 5 lattice: every x-row is 31 h long and no row is a multiple of 64
     particles) plus a sprinkle of isolated particles: every density within the mixed tolerance of the oracle."""
     from gpufluidsimulator_amd import ic
     box, grid = (8.0, 8.0, 8.0), (128, 128, 128)
@@ -105,5 +105,4 @@ def test_mixed_density_on_waves_whose_particles_are_far_apart():
     assert np.abs(res[False] / want - 1).max() <= 1e-5
     rel = res[True] / want - 1
     assert np.abs(rel).max() <= RHO_MAX and np.sqrt(np.mean(rel ** 2)) <= RHO_RMS, (np.abs(rel).max(), np.sqrt(np.mean(rel ** 2)))
-    same = res[True].view(np.uint32) == res[False].view(np.uint32)
-    assert same[-300:].all()                                         # the spray (far apart in y and z too) took the fp32 walk
+    assert np.abs(rel[-300:]).max() <= 1e-3                          # the spray: lone particles, far apart in y and z too
