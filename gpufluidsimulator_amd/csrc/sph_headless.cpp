@@ -160,8 +160,14 @@ void rank_main(const SlabJob& j, const Plan& pl, int rank, int world, int device
         }
         // the innermost layers' force pass goes in front of the step's wait (sph_slab_set_early_force)
         // unless the links are so fast that it cannot pay (a migrant message under ~12 us and a halo-A message under ~45)
-        // -- and never when the ranks share a device (-onegpu): their big kernels would evict each other's L2 working sets
-        if (ok) sph_slab_set_early_force(slab, (!hub && (res.ping_us[0] >= 12.0 || res.ping_us[1] >= 45.0)) ? 1 : 0);
+        // -- nor when the slab is so big that the deep density launch, queued in front of the wait anyway, outlasts the two
+        // messages on the path (~half the particles at ~18.8 per us) -- and never when the ranks share a device (-onegpu):
+        // their big kernels would evict each other's L2 working sets.  (gpufluidsimulator_amd/slab.py: early_force_rule)
+        if (ok) {
+            const bool slow = res.ping_us[0] >= 12.0 || res.ping_us[1] >= 45.0;
+            const bool exposed = res.ping_us[0] + res.ping_us[1] + 20.0 > 0.5 * (double)n_own / 18.8;
+            sph_slab_set_early_force(slab, (!hub && slow && exposed) ? 1 : 0);
+        }
     }
     if (ok && j.warmup && (sph_slab_step(slab, j.dt, (uint32_t)j.substeps) < 0 || sph_slab_sync(slab) < 0)) { ok = false; fail("warm-up step"); }
     gate.wait();

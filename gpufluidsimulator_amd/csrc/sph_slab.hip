@@ -126,7 +126,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t* __restrict_
 
 __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __restrict__ keys, const float4* __restrict__ posi,
                                                           const float4* __restrict__ velr, uint32_t n, uint32_t own_off,
-                                                          uint32_t layer, uint32_t cap, GridDesc g,
+                                                          uint32_t layer, uint32_t cap, GridDesc g, uint32_t early_cap,
                                                           uint32_t* __restrict__ dl, float4* __restrict__ out_lo,
                                                           float4* __restrict__ out_hi) {
     __shared__ uint32_t s_lb[12];
@@ -197,9 +197,11 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     dl[DL_FAR] = far_lo; dl[DL_FAR + 1] = far_hi;
     dl[DL_NEAR] = own_off + s_lb[6]; dl[DL_NEAR + 1] = own_off + max(s_lb[7], s_lb[6]);
     {   // empty unless every slot of layer 5 (and so of every layer up to zl-6) lies inside the deep range
+        // and no longer than early_cap slots: the launch is there to fill the links' latency, not to run beside the interior
+        // launch for its whole length (two big k_force grids side by side evict each other's L2 working sets)
         const bool ok = zl >= 13u && s_lb[10] >= deep0 && s_lb[9] <= max(s_lb[5], deep0) && s_lb[9] > s_lb[8];
         dl[DL_EARLY] = own_off + s_lb[8];
-        dl[DL_EARLY + 1] = own_off + (ok ? s_lb[9] : s_lb[8]);
+        dl[DL_EARLY + 1] = own_off + (ok ? min(s_lb[9], s_lb[8] + early_cap) : s_lb[8]);
     }
 }
 
@@ -786,6 +788,7 @@ struct sph_slab {
     uint64_t exchanges = 0;              // transport calls so far (3 in a usual step: migrants, halo A, halo B)
     bool early_force = true;             // the force pass of the innermost layers runs in front of the step's wait, on a stream of its own
                                          // (sph_slab_set_early_force: ~3 us per step when the links are fast, -30 at 40 us per group)
+    uint32_t early_cap = 1u << 20;       // slots of that launch at most (~150 us of k_force): what a link's latency needs, no more
     uint64_t early_launches = 0, early_used = 0;
     uint32_t early_span = 0;             // slots the last step's early range held: sizes this step's grid (what a grid misses, the interior launch computes)
     uint32_t* recut_blk = nullptr;       // sph_slab_recut: {down, up} counts per 1024-slot block, then their scan
@@ -979,7 +982,7 @@ int slab_step_body(sph_slab* s, float dt) {
     s->seq++;
     // a few blocks: every block finds the bounds for itself, the leavers (few, at most mcap) are packed in a grid-stride loop
     hipLaunchKernelGGL(k_slab_bounds_pack, dim3(min(ceil_div(s->mcap, 256u), 16u)), dim3(256), 0, c->stream, c->keyS + off0, c->posi + off0,
-                       c->velr + off0, n0, off0, layer, s->mcap, c->grid, s->d_lb, s->mig_send[0], s->mig_send[1]);
+                       c->velr + off0, n0, off0, layer, s->mcap, c->grid, s->early_cap, s->d_lb, s->mig_send[0], s->mig_send[1]);
     SPH_HIP(hipGetLastError());
     rc = after_main(s); if (rc) return rc;
     // ---- the density of the deep interior goes into the main stream's queue BEFORE the host waits: its slot range
@@ -1607,6 +1610,7 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
     s->device = ctx->device;
     if (const char* e = getenv("SPH_SLAB_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) s->wait_timeout_s = v; }
     if (const char* e = getenv("SPH_SLAB_EARLY_STREAM")) s->early_own_stream = atoi(e) != 0;
+    if (const char* e = getenv("SPH_SLAB_EARLY_SPAN")) { const long v = atol(e); if (v > 0) s->early_cap = (uint32_t)v; }
     s->tr = *transport;
     s->host_staged = transport->host_buffers != 0;
     s->gcap = ctx->gcap;
@@ -1709,6 +1713,7 @@ int sph_slab_sync(sph_slab* s) {
 int sph_slab_set_early_force(sph_slab* s, int on) {
     SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
     s->early_force = on != 0;
+    if (on > 1) s->early_cap = (uint32_t)on;
     return SPH_OK;
 }
 

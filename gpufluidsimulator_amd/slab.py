@@ -610,6 +610,22 @@ class NativeSlabSimulation(SlabSimulation):
     # images, DESIGN.md section 6.  "auto" switches it off only for such links.
     EARLY_FORCE_MIN_PING_US = 12.0
     EARLY_FORCE_MIN_HALO_PING_US = 45.0      # ... unless a halo-A-sized message takes more than this (a slow link rather than a late one)
+    # ... and off again when the slab is so big that the deep density launch (queued in front of the wait anyway) outlasts the
+    # two messages on the path: ~half a slab's particles are "deep", k_density does ~18.8 of them per us (C3, flowing).  A
+    # 16.7 M-particle slab (config 5's rank) behind a 10 us / 153 GB/s link: 3.71 ms per step without, 3.85 with it.
+    EARLY_FORCE_DEEP_PARTICLES_PER_US = 18.8
+    EARLY_FORCE_SLACK_US = 20.0
+
+    @classmethod
+    def early_force_rule(cls, migrants_us, halo_a_us, owned):
+        """(on, why) from the preflight pings of the migrant- and the halo-A-sized message and the rank's particle count."""
+        slow = migrants_us >= cls.EARLY_FORCE_MIN_PING_US or halo_a_us >= cls.EARLY_FORCE_MIN_HALO_PING_US
+        cover = 0.5 * owned / cls.EARLY_FORCE_DEEP_PARTICLES_PER_US
+        exposed = migrants_us + halo_a_us + cls.EARLY_FORCE_SLACK_US > cover
+        why = (f"pings: migrant message {migrants_us:.1f} us (on from {cls.EARLY_FORCE_MIN_PING_US:.0f}), halo A {halo_a_us:.1f} us "
+               f"(on from {cls.EARLY_FORCE_MIN_HALO_PING_US:.0f}); the deep density launch of {owned} particles covers ~{cover:.0f} us "
+               f"(on while the two messages + {cls.EARLY_FORCE_SLACK_US:.0f} us exceed it)")
+        return bool(slow and exposed), why
 
     def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, ping_reps=3, early_force="auto", **kw):
         self._device_index = device_index
@@ -677,9 +693,9 @@ class NativeSlabSimulation(SlabSimulation):
         else:       # the slowest link any rank saw decides for all (a rank's choice is its own scheduling: nothing has to agree)
             worst = self.comm.allreduce_max(self.ping["migrants"]["mean_us"])
             worst_a = self.comm.allreduce_max(self.ping["halo_a"]["mean_us"])
-            on = worst >= self.EARLY_FORCE_MIN_PING_US or worst_a >= self.EARLY_FORCE_MIN_HALO_PING_US
-            why = (f"pings, max over ranks: migrant message {worst:.1f} us (on from {self.EARLY_FORCE_MIN_PING_US:.0f}), halo A "
-                   f"{worst_a:.1f} us (on from {self.EARLY_FORCE_MIN_HALO_PING_US:.0f})")
+            fewest = -self.comm.allreduce_max(-float(self.engine.ctx.n))
+            on, why = self.early_force_rule(worst, worst_a, int(fewest))
+            why = "max over ranks (particles: min): " + why
         self.early_force = {"on": on, "why": why}
         capi._check(capi.load().sph_slab_set_early_force(self._slab, 1 if on else 0))
 
@@ -712,10 +728,11 @@ class NativeSlabSimulation(SlabSimulation):
         return out
 
     def set_early_force(self, on=True):
-        """The force pass of the innermost layers in front of the step's wait (sph_slab_set_early_force); same bits either way."""
+        """The force pass of the innermost layers in front of the step's wait (sph_slab_set_early_force); same bits either way.
+        An integer > 1: on, and that many slots at most (the library's default: 2^20)."""
         self._early_force = bool(on)
         self.early_force = {"on": bool(on), "why": "set by the caller"}
-        capi._check(capi.load().sph_slab_set_early_force(self._slab, 1 if on else 0))
+        capi._check(capi.load().sph_slab_set_early_force(self._slab, int(on)))
 
     def slab_timing_enable(self, on=True):
         capi._check(capi.load().sph_slab_timing_enable(self._slab, 1 if on else 0))
@@ -1056,8 +1073,7 @@ def bench_periodic(args):
     capi._check(L.sph_slab_create(C.byref(h), ctx.h, 1, 3, tr, 0))
     ef_arg = getattr(args, "early_force", "auto")
     halo_us = float(args.link_latency_us) + (per_layer * 32 / (float(args.link_gbs) * 1e3) if float(args.link_gbs) > 0 else 0.0)
-    ef_on = ef_arg == "on" or (ef_arg == "auto" and (float(args.link_latency_us) >= NativeSlabSimulation.EARLY_FORCE_MIN_PING_US
-                                                      or halo_us >= NativeSlabSimulation.EARLY_FORCE_MIN_HALO_PING_US))
+    ef_on = ef_arg == "on" or (ef_arg == "auto" and NativeSlabSimulation.early_force_rule(float(args.link_latency_us), halo_us, n)[0])
     capi._check(L.sph_slab_set_early_force(h, 1 if ef_on else 0))
     dt = float(ic.DEFAULT_DT)
     step = lambda k: capi._check(L.sph_slab_step(h, dt, int(k)))          # noqa: E731

@@ -404,8 +404,11 @@ int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]);
  * section 6, measured on a slab between its periodic images: +3 us per step with fast links, -10 at 20 us per message
  * group, -30 at 40).  For ONE rank per device: ranks that share a GPU (rehearsals over the local / host transports) should
  * switch it off -- their big kernels then run beside each other all the time and evict each other's L2 working sets (two
- * 8.4 M-particle slabs on one GPU: 4.81 against 3.86 ms per step); the launchers do.  Same bits either way.  out = {steps that launched it, steps that used its result} (a step whose
- * arrivals re-sort the slab discards it). */
+ * 8.4 M-particle slabs on one GPU: 4.81 against 3.86 ms per step); the launchers do.  The launch covers at most 2^20 slots
+ * of those layers (~150 us of k_force: what a link's latency needs; a longer one runs beside the interior launch for its whole
+ * length and the two evict each other's L2 working sets -- a 16.7 M-particle slab: 3.90 against 3.69 ms); on > 1 sets that
+ * number of slots (environment: SPH_SLAB_EARLY_SPAN).  Same bits either way.
+ * out = {steps that launched it, steps that used its result} (a step whose arrivals re-sort the slab discards it). */
 int sph_slab_set_early_force(sph_slab* s, int on);
 int sph_slab_early_force_stats(const sph_slab* s, uint64_t out[2]);
 /* TEST HOOK: raise sticky device-side error word `flag` (0: an arrival outside its boundary layer, 1: an arrival outside

@@ -826,13 +826,14 @@ def test_one_slab_between_its_periodic_images_matches_three_stacked_copies():
     assert np.abs(got["density"] / ref["density"][mid] - 1).max() <= 1e-5
 
 
-@pytest.mark.parametrize("early", [True, False])
+@pytest.mark.parametrize("early", [True, False, 700])
 def test_early_force_launch_gives_the_same_bits(early):
     """sph_slab_set_early_force: the fused force pass of a slab's innermost layers (six layers and more from either cut) is
     queued in front of the step's host wait -- keys by absolute slot, movers marked afterwards (k_slab_early_finish).  A dam
     slice 40 cell layers tall in two and three slabs, particles crossing the cuts both ways and changing cell inside the
     early range every step, the merge path of the sort consuming the marks: bit for bit the one-context run, switched on
-    and off; on, every step uses the early result (the in-place merges of arrivals do not disturb it)."""
+    and off; on, every step uses the early result (the in-place merges of arrivals do not disturb it).  700: on, the
+    launch capped at 700 slots (it then ends in the middle of a cell layer; the library's cap is 2^20)."""
     box, grid = (4.0, 4.0, 4.0), (64, 64, 64)
     pos, vel = ic.dam_break_lattice((10, 10, 80), box, jitter=True)
     rng = np.random.default_rng(4)
