@@ -1005,7 +1005,7 @@ int slab_step_body(sph_slab* s, float dt) {
     // changes by a few slots a step) -- whatever a too small grid leaves out is computed by the interior launch below
     const uint32_t early_grid_slots = s->early_span ? min(n0, ((s->early_span + s->early_span / 64u + 1023u) & ~255u)) : n0;
     bool early_pending = false;          // the launch runs on its own stream: the main stream has not waited for it yet
-    if (deep_valid && s->early_force && c->grid.zl >= 13u) {
+    if (deep_valid && s->early_force && s->world > 1 && c->grid.zl >= 13u) {          // (no neighbour, no latency to fill)
         if (s->early_own_stream && s->early) {
             SPH_HIP(hipEventRecord(s->ev_early_go, c->stream));             // behind the deep density
             SPH_HIP(hipStreamWaitEvent(s->early, s->ev_early_go, 0));
