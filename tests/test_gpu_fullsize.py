@@ -1,9 +1,11 @@
-"""GPU: BASELINE config 3 (16,777,216 particles, 512^3 grid) through size-independent properties --
-the oracle needs ~1 minute per step at this size, so full-array comparisons are replaced by
-  * sortedness / permutation / stability / cell-table consistency (integer work, exact),
+"""GPU: BASELINE configs 3, 4 and 5 at their stated sizes (16.7 M / 67 M / 134 M particles).
+  * EVERY particle of one step, phase by phase, against the pinned oracle run on the whole system with its OpenMP team
+    (`_every_particle_against_the_oracle`: 8 s at C3, 35 s at C4, 70 s at C5 on the GPU box's host) -- round 5; before
+    that the oracle was run on sub-blocks only:
   * a corner sub-block of the big system against the oracle run on that sub-block alone
     (interior particles of the sub-block have identical neighbourhoods in both systems),
-  * fused step == phase-by-phase step,
+  * sortedness / permutation / stability / cell-table consistency (integer work, exact),
+  * fused step == phase-by-phase step, merge path == full radix sort, eight slabs == one context (bit for bit),
   * physical sanity (finite, inside the box, positive density)."""
 import numpy as np
 import pytest
@@ -150,6 +152,101 @@ def test_c3_flowing_corner_block_matches_oracle():
     assert np.abs(s1["pos"][g] - so["pos"][inner]).max() <= 1e-6 * 32.0
     assert np.abs(s1["vel"][g] - so["vel"][inner]).max() <= 1e-5 * np.abs(so["vel"][inner]).max()
     assert np.abs(s1["density"][g] / so["density"][inner] - 1).max() <= 1e-5
+
+
+def _oracle_threads():
+    import os
+    return max(1, min(32, os.cpu_count() or 1))
+
+
+def _every_particle_against_the_oracle(cfg, runup, dt, kick=None, also_mixed=False):
+    """One step of a whole configuration, phase by phase, EVERY particle against the pinned oracle (its OpenMP build is the
+    bit-exact one: every particle's sums are formed by one thread in the reference's order; a step of 16.7 M particles takes
+    it ~10-30 s on the GPU box's host).  The device brings the dam into a flowing state first; its state is what the oracle
+    is loaded with.  Bars of tests/test_gpu_parity.py: integer work bit-exact (cell keys of every particle, sortedness, collision counts), densities and pressures 1e-5, forces
+    2e-5 of the largest, positions 1e-6 box, velocities 1e-5 of the largest."""
+    n = cfg["lattice"][0] * cfg["lattice"][1] * cfg["lattice"][2]
+    box, grid = cfg["box"], cfg["grid"]
+    with capi.Context(n, box=box, grid=grid) as c:
+        c.reset_lattice(cfg["lattice"], jitter=True)
+        if kick is not None:                       # random velocities: particles change cell and collide within a few steps
+            c.set_by_index(0, vel=np.random.default_rng(kick).uniform(-80.0, 80.0, (n, 3)).astype(np.float32))
+        c.step(dt, runup)
+        movers = c.sort_stats()["movers_total"]
+        s0 = c.download(want=("pos", "vel"))
+        assert np.isfinite(s0["vel"]).all()
+        c.hash(); c.sort(); c.build_cells()
+        keys, order = c.keys(), c.order()
+        if also_mixed:                             # config 5's arithmetic on the same sorted state: its own, looser bar
+            c.set_precision(True)
+            c.density()
+            dm = c.download(want=("density",))["density"]
+            c.set_precision(False)
+        c.density()
+        d = c.download(want=("density", "pressure"))
+        c.force(); c.collide()
+        f = c.download_forces()
+        c.integrate(dt)
+        s1 = c.download(want=("pos", "vel"))
+    o = oracle.Oracle(s0["pos"], s0["vel"], box, grid, oracle.CELL_LINEAR)
+    o.L.orc_set_num_threads(_oracle_threads())
+    try:
+        o.map_zindex()
+        zo = o.by_index("zindex")
+        assert np.array_equal(zo[order], keys), "cell keys"                     # every particle's key, bit for bit
+        assert np.all(keys[1:] >= keys[:-1]), "not sorted by key"     # (within a cell: the order of the last step, as the reference's stable sort keeps it)
+        del zo
+        o.sort(); o.apply_order(order); o.construct_bgrid()
+        o.compute_densities()
+        rho, prs = o.by_index("density"), o.by_index("pressure")
+        assert np.abs(d["density"] / rho - 1).max() <= 1e-5, np.abs(d["density"] / rho - 1).max()
+        assert np.abs(d["pressure"] - prs).max() <= 1e-5 * np.abs(prs).max()
+        if also_mixed:                             # DESIGN.md section 4 (mixed): every density within 2 %, 0.4 % rms
+            rel = dm / rho - 1
+            assert np.abs(rel).max() <= 2e-2 and np.sqrt(np.mean(rel.astype(np.float64) ** 2)) <= 4e-3, \
+                (np.abs(rel).max(), np.sqrt(np.mean(rel.astype(np.float64) ** 2)))
+            del rel, dm
+        del rho, prs
+        o.compute_forces(); o.particle_collisions()
+        fp, fv = o.by_index("force_press"), o.by_index("force_visc")
+        fscale = float(max(np.abs(fp).max(), np.abs(fv).max()))
+        assert np.abs(f["fpress"] - fp).max() <= 2e-5 * fscale and np.abs(f["fvisc"] - fv).max() <= 2e-5 * fscale
+        del fp, fv
+        count = o.by_index("collision_count")
+        assert np.array_equal(f["count"], count), int((f["count"] != count).sum())
+        dv = o.by_index("delta_velocity")
+        assert np.abs(f["dv"] - dv).max() <= 2e-5 * max(float(np.abs(dv).max()), 1e-12)
+        colliding = int((count > 0).sum())
+        del dv, count
+        o.integrate(dt)
+        so = o.state()
+    finally:
+        o.close()
+    assert np.abs(s1["pos"] - so["pos"]).max() <= 1e-6 * float(max(box))
+    assert np.abs(s1["vel"] - so["vel"]).max() <= 1e-5 * np.abs(so["vel"]).max()
+    return movers, colliding
+
+
+def test_c3_flowing_step_every_particle_against_the_oracle():
+    """BASELINE config 3 in the regime the benchmark times (2600 steps into the fall), all 16,777,216 particles: what the
+    corner-block tests above check on ten thousand particles, on every one."""
+    movers, colliding = _every_particle_against_the_oracle(CFG, 2600, DT)
+    assert movers > 1e6 and colliding > 1e5, (movers, colliding)
+
+
+def test_c4_step_every_particle_against_the_oracle():
+    """BASELINE config 4 at its stated size, all 67,108,864 particles (one context, 1024^3 cells): the lattice kicked with
+    random velocities, twelve steps at 40x the reference's dt (the state of the eight-slab test below), then one step phase
+    by phase against the oracle loaded with that state."""
+    movers, colliding = _every_particle_against_the_oracle(ic.CONFIGS["C4"], 12, 2e-5, kick=41)
+    assert movers > 100000 and colliding > 100000, (movers, colliding)
+
+
+def test_c5_size_step_every_particle_against_the_oracle():
+    """The same for config 5's 2^27 = 134,217,728 particles in fp32 -- and, on the same sorted state, the density pass in
+    config 5's own arithmetic (fp16 neighbour accumulators) for every particle at the mixed tolerance."""
+    movers, colliding = _every_particle_against_the_oracle(ic.CONFIGS["C5"], 12, 2e-5, kick=43, also_mixed=True)
+    assert movers > 100000 and colliding > 100000, (movers, colliding)
 
 
 def test_c4_particle_count_on_one_gpu():
