@@ -159,7 +159,7 @@ def _oracle_threads():
     return max(1, min(32, os.cpu_count() or 1))
 
 
-def _every_particle_against_the_oracle(cfg, runup, dt, kick=None, also_mixed=False):
+def _every_particle_against_the_oracle(cfg, runup, dt, kick=None, also_mixed=False, with_reference=False):
     """One step of a whole configuration, phase by phase, EVERY particle against the pinned oracle (its OpenMP build is the
     bit-exact one: every particle's sums are formed by one thread in the reference's order; a step of 16.7 M particles takes
     it ~10-30 s on the GPU box's host).  The device brings the dam into a flowing state first; its state is what the oracle
@@ -224,13 +224,32 @@ def _every_particle_against_the_oracle(cfg, runup, dt, kick=None, also_mixed=Fal
         o.close()
     assert np.abs(s1["pos"] - so["pos"]).max() <= 1e-6 * float(max(box))
     assert np.abs(s1["vel"] - so["vel"]).max() <= 1e-5 * np.abs(so["vel"]).max()
+    if with_reference:
+        # ... and against the REFERENCE'S OWN CODE (SPH/particleSystem.cpp compiled where it lies: oracle/_ref/sph_ref, OpenMP
+        # mode) run on the same state, every particle, phase by phase -- the oracle is pinned to it bit for bit on small
+        # systems (tests/test_oracle_vs_ref.py); here the whole configuration goes through the reference itself.
+        from oracle import refio
+        assert refio.available(), "oracle/_ref/sph_ref did not travel with the snapshot"
+        del so
+        recs, _ = refio.run_ref(s0["pos"], s0["vel"], box, grid[0], dt, 1, phases=True, threads=_oracle_threads())
+        dens, frc, coll, st = recs[("dens", 1)], recs[("force", 1)], recs[("coll", 1)], recs[("state", 1)]
+        assert np.abs(d["density"] / dens[:, 0] - 1).max() <= 1e-5
+        assert np.abs(d["pressure"] - dens[:, 1]).max() <= 1e-5 * np.abs(dens[:, 1]).max()
+        fscale = float(np.abs(frc).max())
+        assert np.abs(f["fpress"] - frc[:, 0:3]).max() <= 2e-5 * fscale and np.abs(f["fvisc"] - frc[:, 3:6]).max() <= 2e-5 * fscale
+        assert np.array_equal(f["count"], coll[:, 3].astype(np.int32)), "collision counts against the reference"
+        assert np.abs(f["dv"] - coll[:, 0:3]).max() <= 2e-5 * max(float(np.abs(coll[:, 0:3]).max()), 1e-12)
+        assert np.abs(s1["pos"] - st[:, 0:3]).max() <= 1e-6 * float(max(box))
+        assert np.abs(s1["vel"] - st[:, 3:6]).max() <= 1e-5 * np.abs(st[:, 3:6]).max()
     return movers, colliding
 
 
-def test_c3_flowing_step_every_particle_against_the_oracle():
+def test_c3_flowing_step_every_particle_against_the_oracle_and_the_reference_itself():
     """BASELINE config 3 in the regime the benchmark times (2600 steps into the fall), all 16,777,216 particles: what the
-    corner-block tests above check on ten thousand particles, on every one."""
-    movers, colliding = _every_particle_against_the_oracle(CFG, 2600, DT)
+    corner-block tests above check on ten thousand particles, on every one -- against the oracle and, where its binary
+    travelled with the snapshot, against the reference's own code run on the same 16.7 M particles."""
+    from oracle import refio
+    movers, colliding = _every_particle_against_the_oracle(CFG, 2600, DT, with_reference=refio.available())
     assert movers > 1e6 and colliding > 1e5, (movers, colliding)
 
 
