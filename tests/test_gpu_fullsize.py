@@ -241,6 +241,29 @@ def _every_particle_against_the_oracle(cfg, runup, dt, kick=None, also_mixed=Fal
         assert np.abs(f["dv"] - coll[:, 0:3]).max() <= 2e-5 * max(float(np.abs(coll[:, 0:3]).max()), 1e-12)
         assert np.abs(s1["pos"] - st[:, 0:3]).max() <= 1e-6 * float(max(box))
         assert np.abs(s1["vel"] - st[:, 3:6]).max() <= 1e-5 * np.abs(st[:, 3:6]).max()
+        assert refio.dropin_available(), "oracle/_ref/sph_ref_dropin is built by the same recipe as sph_ref"
+        if True:
+            # ... and the drop-in claim at this size: the reference's own host class, linked against libsph_hip.so, runs ITS
+            # update() in CUDA mode on the same state (oracle/_ref/sph_ref_dropin: its 19 extern "C" kernel wrappers are the
+            # HIP library's) -- what it reads back against what its CPU mode produced above: the integers `array_equal`
+            # (Particle::zindex = the Morton code of every particle, the array sorted by it, dev_B, dev_B_prime), the state
+            # at the fp32 bars.
+            del dens, frc, coll
+            sz, od, bc, bp = recs[("sorted_z", 1)], recs[("order", 1)], recs[("bcells", 1)], recs[("bprime", 1)]
+            del recs
+            drp, _ = refio.run_ref(s0["pos"], s0["vel"], box, grid[0], dt, 1, phases=True, binary=refio.DROPIN_BIN)
+            assert np.array_equal(drp[("sorted_z", 1)], sz), "the sorted z-indices"
+            z_ref, z_got = np.empty(n, np.uint32), np.empty(n, np.uint32)
+            z_ref[od] = sz
+            z_got[drp[("order", 1)]] = drp[("sorted_z", 1)]
+            assert np.array_equal(z_got, z_ref), "Particle::zindex by creation index"
+            assert np.array_equal(drp[("bcells", 1)], bc), "dev_B"
+            assert np.array_equal(drp[("bprime", 1)], bp), "dev_B_prime"
+            ds = drp[("state", 1)]
+            assert np.abs(ds[:, 0:3] - st[:, 0:3]).max() <= 1e-6 * float(max(box))
+            assert np.abs(ds[:, 3:6] - st[:, 3:6]).max() <= 1e-5 * np.abs(st[:, 3:6]).max()
+            assert np.abs(ds[:, 6] / st[:, 6] - 1).max() <= 1e-5
+            assert np.abs(ds[:, 7] - st[:, 7]).max() <= 1e-5 * np.abs(st[:, 7]).max()
     return movers, colliding
 
 
