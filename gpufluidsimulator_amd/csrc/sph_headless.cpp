@@ -25,6 +25,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -239,6 +240,13 @@ int run_slabs(const SlabJob& j, int world, bool onegpu, int device0) {
             kids[r] = fork();
             if (kids[r] < 0) { perror("fork"); return EXIT_FAILURE; }
             if (kids[r] == 0) {
+                // keep only this rank's ends of the pipes: a pipe whose other end is still open somewhere never reports that
+                // its owner died (the parent's read would block for ever on a rank that crashed)
+                for (int q = 0; q < world; q++) {
+                    close(up[2 * q]); close(down[2 * q + 1]); close(out_pipe[2 * q]);
+                    if (q != r) { close(up[2 * q + 1]); close(down[2 * q]); close(out_pipe[2 * q + 1]); close(id_pipe[2 * q]); }
+                    if (r != 0 || q == 0) close(id_pipe[2 * q + 1]);
+                }
                 RankResult rr;
                 uint8_t id[128] = {0};
                 int ndev = sph_device_count(nullptr);
@@ -255,10 +263,14 @@ int run_slabs(const SlabJob& j, int world, bool onegpu, int device0) {
                 _exit(rr.rc ? 1 : 0);
             }
         }
+        signal(SIGPIPE, SIG_IGN);                      // (a write to a rank that died must be an error code, not this process's end)
+        for (int r = 0; r < world; r++) { close(up[2 * r + 1]); close(down[2 * r]); close(out_pipe[2 * r + 1]); close(id_pipe[2 * r]); close(id_pipe[2 * r + 1]); }
+        std::vector<bool> dead(world, false);
         for (int round = 0; round < 2; round++) {      // the two barriers of rank_main
-            char b;
-            for (int r = 0; r < world; r++) if (read(up[2 * r], &b, 1) != 1) { fprintf(stderr, "rank %d died\n", r); }
-            for (int r = 0; r < world; r++) if (write(down[2 * r + 1], &b, 1) != 1) {}
+            char b = 1;
+            for (int r = 0; r < world; r++)
+                if (!dead[r] && read(up[2 * r], &b, 1) != 1) { dead[r] = true; fprintf(stderr, "rank %d died\n", r); }      // (end of file: it closed its end)
+            for (int r = 0; r < world; r++) if (!dead[r] && write(down[2 * r + 1], &b, 1) != 1) dead[r] = true;
         }
         for (int r = 0; r < world; r++) { if (!read_all(out_pipe[2 * r], &res[r], sizeof(RankResult))) { res[r].rc = -1; snprintf(res[r].err, sizeof res[r].err, "rank %d: no result", r); } }
         for (int r = 0; r < world; r++) { int st = 0; waitpid(kids[r], &st, 0); }
