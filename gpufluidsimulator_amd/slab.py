@@ -611,9 +611,9 @@ class NativeSlabSimulation(SlabSimulation):
     EARLY_FORCE_MIN_PING_US = 12.0
     EARLY_FORCE_MIN_HALO_PING_US = 45.0      # ... unless a halo-A-sized message takes more than this (a slow link rather than a late one)
     # ... and off again when the slab is so big that the deep density launch (queued in front of the wait anyway) outlasts the
-    # two messages on the path: ~half a slab's particles are "deep", k_density does ~18.8 of them per us (C3, flowing).  A
+    # two messages on the path: ~half a slab's particles are "deep", k_density does ~18,800 of them per us (C3, flowing).  A
     # 16.7 M-particle slab (config 5's rank) behind a 10 us / 153 GB/s link: 3.71 ms per step without, 3.85 with it.
-    EARLY_FORCE_DEEP_PARTICLES_PER_US = 18.8
+    EARLY_FORCE_DEEP_PARTICLES_PER_US = 18.8e3
     EARLY_FORCE_SLACK_US = 20.0
 
     @classmethod

@@ -203,3 +203,18 @@ def test_gather_rows_puts_every_rank_s_numbers_on_every_rank():
         assert m.shape == (world, 3)
         assert np.array_equal(m[:, 0], np.arange(world)) and np.array_equal(m[:, 1], 10.0 * np.arange(world))
         assert np.isnan(m[1, 2]) and np.isnan(m[3, 2]) and m[0, 2] == 1.5 and m[2, 2] == 1.5
+
+
+def test_early_force_rule_follows_the_measured_crossovers():
+    """slab.NativeSlabSimulation.early_force_rule: the launchers' "auto" for sph_slab_set_early_force, from the preflight pings and
+    the rank's particle count.  The cases are the measured ones (periodic-slab harness)."""
+    rule = slab.NativeSlabSimulation.early_force_rule
+    n8 = 2097152                                    # an eighth of config 3
+    assert rule(16.0, 16.0, n8)[0] is False         # device copies only: +6 us per step with it
+    assert rule(19.0, 47.0, n8)[0] is True          # 10 us + 153 GB/s: break-even, on
+    assert rule(48.0, 79.0, n8)[0] is True          # 40 us per group: -30 us per step
+    assert rule(5.0, 130.0, n8)[0] is True          # a slow link rather than a late one
+    assert rule(22.0, 147.0, 16777216)[0] is False  # a config-5 rank: its deep density launch outlasts the messages
+    assert rule(91.0, 214.0, 16777216)[0] is False
+    on, why = rule(19.0, 47.0, n8)
+    assert "covers" in why and "19.0" in why
