@@ -873,6 +873,9 @@ enum { SORT_FORM_BOTH = 0, SORT_FORM_SMALL = 1, SORT_FORM_BIG = 2 };
 #ifndef SPH_OS_SMALL
 #define SPH_OS_SMALL 1          // 0: never take the one-block sort (A/B runs)
 #endif
+#ifndef SPH_OS_FORM_HINT
+#define SPH_OS_FORM_HINT 1      // 0: a whole-domain context always launches both forms of the movers' sort (A/B runs)
+#endif
 template <int BITS>
 static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, bool first, uint32_t passes,
                            uint32_t*& kin, uint32_t*& vin, uint32_t*& kout, uint32_t*& vout, const SmallTail& tail) {
@@ -884,8 +887,14 @@ static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32
     // (a slab: its host waits for the device once per step) knows the count of the PREVIOUS sort exactly, and the movers
     // of a flow change slowly except at the first step of a burst: there only the form that count asks for is launched.
     // Each form is correct for any count on its own (k_os_small: `alone`); a wrong guess costs time once per burst.
+    // A whole-domain context is not host-paced, but its host never runs more than four sorts ahead of the device
+    // (launch_sort: the mm_done ring), so the count it reads is at most four steps old: it picks one form as well, with a
+    // quarter of the one-block sort's capacity as the margin for what four steps can change, and both forms in between.
     int form = SORT_FORM_BOTH;
     if (small_max && c->host_paced) form = tail.hint <= OS_SMALL_MAX ? SORT_FORM_SMALL : SORT_FORM_BIG;
+    else if (small_max && SPH_OS_FORM_HINT && tail.hint != 0xFFFFFFFFu)
+        form = tail.hint <= OS_SMALL_MAX - OS_SMALL_MAX / 4u ? SORT_FORM_SMALL
+             : (tail.hint > OS_SMALL_MAX + OS_SMALL_MAX / 4u ? SORT_FORM_BIG : SORT_FORM_BOTH);
     if (tail.form) *tail.form = form;
     if (small_max) c->sort_forms[form]++;
     if (form == SORT_FORM_BIG) small_max = 0u;               // the multi-block kernels do not look for a small count
