@@ -117,10 +117,12 @@ uint32_t sph_capacity(const sph_ctx* c);
 
 /* Arithmetic of the neighbour passes.  SPH_PRECISION_F32 (default): everything in fp32, the reference's
  * precision.  SPH_PRECISION_MIXED_F16 (BASELINE config 5): positions, velocities, densities and forces are
- * stored and integrated in fp32; inside the density and force traversals the per-pair arithmetic and the per-row
- * accumulators are packed fp16 (two candidates per lane-instruction) on coordinates relative to a wave-local
- * reference in units of h, with NORMALISED kernel sums (the reference's densities ~2e6 do not fit fp16); row sums
- * are added up in fp32 and scaled once.  The collision pass stays fp32.  Looser tolerance: DESIGN.md section 4. */
+ * stored and integrated in fp32; inside the DENSITY traversal the per-pair arithmetic and the per-row
+ * accumulators are packed fp16 (two candidates per lane-instruction) on coordinates relative to a reference point
+ * of the wave in units of h (x as a coarse + a fine half, one reference per group of lanes that lie within 6 h in
+ * y and z: exact at any extent of the wave), with NORMALISED kernel sums (the reference's densities ~2e6 do not
+ * fit fp16); row sums are added up in fp32 and scaled once.  The force and collision passes stay fp32 (decided on
+ * a device measurement).  Looser tolerance: DESIGN.md section 4. */
 enum { SPH_PRECISION_F32 = 0, SPH_PRECISION_MIXED_F16 = 1 };
 int sph_set_precision(sph_ctx* c, int precision);
 int sph_get_precision(const sph_ctx* c);
@@ -216,7 +218,9 @@ int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skip
                    uint64_t* movers_total);
 /* How the movers' sorts of the merge path were launched so far: out[0] both forms (the count lives on the device, each
  * kernel looks at it and leaves if it is not its turn), out[1] the one-block sort alone, out[2] the multi-block passes
- * alone -- the last two only in host-paced (slab) contexts, from the previous sort's count.  No synchronisation. */
+ * alone -- the last two from the count the device last reported: the previous sort's in a host-paced (slab) context, at most
+ * four sorts old in a whole-domain one (there with a margin: both forms while the count is within a quarter of the one-block
+ * sort's capacity).  No synchronisation. */
 int sph_sort_forms(const sph_ctx* c, uint64_t out[3]);
 /* merge = 1 (default): the sort takes the merge path while few particles change cell (up to 1/8 of them, by
  * the count the device last reported); 0: the full radix sort every step (what SPH_SORT_MERGE=0 in the
@@ -407,7 +411,7 @@ int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]);
  * 8.4 M-particle slabs on one GPU: 4.81 against 3.86 ms per step); the launchers do.  The launch covers at most 2^20 slots
  * of those layers (~150 us of k_force: what a link's latency needs; a longer one runs beside the interior launch for its whole
  * length and the two evict each other's L2 working sets -- a 16.7 M-particle slab: 3.90 against 3.69 ms); on > 1 sets that
- * number of slots (environment: SPH_SLAB_EARLY_SPAN).  Same bits either way.
+ * number of slots (environment: SPH_SLAB_EARLY_SPAN).  A slab without neighbours (world 1) never launches it.  Same bits either way.
  * out = {steps that launched it, steps that used its result} (a step whose arrivals re-sort the slab discards it). */
 int sph_slab_set_early_force(sph_slab* s, int on);
 int sph_slab_early_force_stats(const sph_slab* s, uint64_t out[2]);
