@@ -615,15 +615,20 @@ int rccl_exchange(void* self, int, const void* send_lo, size_t send_lo_bytes, vo
     hipStream_t s = (hipStream_t)stream;
     const int ncclChar = 0;
     SPH_NCCL(g_rccl.GroupStart());
+    // a call that fails inside the group must not leave the group open (the thread's next RCCL call -- ncclCommAbort among
+    // them -- would be queued into it): remember the first error, close the group, then report
+    int err = 0; const char* what = "";
+    auto op = [&](int r, const char* name) { if (r != 0 && err == 0) { err = r; what = name; } };
     if (L->rank > 0) {
-        if (send_lo_bytes) SPH_NCCL(g_rccl.Send(send_lo, send_lo_bytes, ncclChar, L->rank - 1, L->comm, s));
-        if (recv_lo_bytes) SPH_NCCL(g_rccl.Recv(recv_lo, recv_lo_bytes, ncclChar, L->rank - 1, L->comm, s));
+        if (send_lo_bytes) op(g_rccl.Send(send_lo, send_lo_bytes, ncclChar, L->rank - 1, L->comm, s), "ncclSend to rank - 1");
+        if (recv_lo_bytes) op(g_rccl.Recv(recv_lo, recv_lo_bytes, ncclChar, L->rank - 1, L->comm, s), "ncclRecv from rank - 1");
     }
     if (L->rank + 1 < L->world) {
-        if (send_hi_bytes) SPH_NCCL(g_rccl.Send(send_hi, send_hi_bytes, ncclChar, L->rank + 1, L->comm, s));
-        if (recv_hi_bytes) SPH_NCCL(g_rccl.Recv(recv_hi, recv_hi_bytes, ncclChar, L->rank + 1, L->comm, s));
+        if (send_hi_bytes) op(g_rccl.Send(send_hi, send_hi_bytes, ncclChar, L->rank + 1, L->comm, s), "ncclSend to rank + 1");
+        if (recv_hi_bytes) op(g_rccl.Recv(recv_hi, recv_hi_bytes, ncclChar, L->rank + 1, L->comm, s), "ncclRecv from rank + 1");
     }
-    SPH_NCCL(g_rccl.GroupEnd());
+    op(g_rccl.GroupEnd(), "ncclGroupEnd");
+    if (err) { set_error("RCCL error %d (%s): %s (rank %d of %d)", err, g_rccl.GetErrorString(err), what, L->rank, L->world); return SPH_E_DEVICE; }
     return SPH_OK;
 }
 

@@ -654,7 +654,10 @@ class NativeSlabSimulation(SlabSimulation):
         if self._transport_kind == "rccl":
             if self._tr is None:       # one communicator for the life of the run (re-balancing keeps it)
                 self._tr = rccl_transport(self.rank, self.world, self._device_index, self.comm.broadcast_bytes)
-                capi._check(L.sph_rccl_transport_selftest(self._tr, 1 << 16))    # fail here, loudly, not inside a step
+                # fail here, loudly, not inside a step: with neighbours the preflight ping below is that check (the step's own
+                # message pattern, contents verified); a chain of one -- or a caller that switched the ping off -- sends to itself
+                if self.world == 1 or self._ping_reps <= 0:
+                    capi._check(L.sph_rccl_transport_selftest(self._tr, 1 << 16))
             tr = self._tr
         elif self._transport_kind == "local":
             # device pointers between the streams of this process (csrc/sph_slab.hip: local_exchange); the ranks share
