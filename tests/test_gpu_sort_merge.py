@@ -233,3 +233,40 @@ def test_mover_counts_around_the_one_block_sort(movers):
             assert np.array_equal(x, y)
     finally:
         a.close(); b.close()
+
+
+def test_a_whole_domain_context_guesses_the_sort_form_and_a_wrong_guess_is_still_exact():
+    """Round 5: a whole-domain context, too, launches only the form of the movers' sort that the last reported count asks for
+    (its host runs at most four sorts ahead of the device).  Each form is exact for any count on its own: 5 movers (the
+    one-block sort alone), then 20000 at once (the guess says "few": the one-block sort works through them tile by tile),
+    then 5 again (the guess says "many": the multi-block passes sort five pairs) -- the order of the full radix sort every
+    time, and the counters show which forms ran."""
+    cfg = ic.CONFIGS["C2"]
+    pos, vel = ic.dam_break_lattice(cfg["lattice"], cfg["box"], jitter=False)
+    n = pos.shape[0]
+    rng = np.random.default_rng(11)
+    a, b = _ctx(n, cfg["box"], cfg["grid"], False), _ctx(n, cfg["box"], cfg["grid"], True)
+    b.set_sort_mode(2)
+    try:
+        for c in (a, b):
+            c.upload(pos, vel)
+            c.hash(); c.sort()
+        cur = pos.copy()
+        forms = [b.sort_forms()]
+        for movers in (5, 5, 20000, 5, 5):
+            pick = rng.choice(n, size=movers, replace=False)
+            step = np.where(cur[pick, 0] < 0.0, 1.0, -1.0).astype(np.float32) / np.float32(16.0)      # one cell, staying in the box
+            cur[pick, 0] += step
+            for c in (a, b):
+                c.set_by_index(0, pos=cur)
+                c.hash(); c.sort()
+            assert np.array_equal(a.keys(), b.keys()) and np.array_equal(a.order(), b.order()), movers
+            assert b.sort_stats()["last_movers"] == movers
+            forms.append(b.sort_forms())
+        d = [tuple(y - x for x, y in zip(f0, f1)) for f0, f1 in zip(forms, forms[1:])]      # (both, small alone, passes alone) per sort
+        assert d[1] == (0, 1, 0), d          # count 5 known: the one-block sort alone
+        assert d[2] == (0, 1, 0), d          # 20000 movers behind a count of 5: still the one-block sort, alone and exact
+        assert d[3] == (0, 0, 1), d          # 5 movers behind a count of 20000: the passes alone
+        assert d[4] == (0, 1, 0), d
+    finally:
+        a.close(); b.close()
