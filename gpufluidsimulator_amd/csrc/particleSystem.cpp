@@ -89,7 +89,7 @@ ParticleSystem::ParticleSystem(uint numParticles, float3 boxDims, ParticleComput
 
 ParticleSystem::ParticleSystem(uint numParticles, float3 boxDims, ParticleComputeMode mode, uint3 gridDims)
     : m_bInitialized(false), m_numParticles(numParticles), m_boxDims(boxDims), m_solverIterations(1),
-      m_compute_mode(mode), m_ctx(nullptr), m_hostStale(false), m_log(nullptr), m_logLastMs(0), m_logGlobalMs(0), m_logFreqMs(2000.0) {
+      m_compute_mode(mode), m_ctx(nullptr), m_hostStale(false), m_log(nullptr), m_logLastMs(0), m_logGlobalMs(0), m_logFreqMs(2000.0), m_logStyle(0), m_logFrames(0) {
     if (mode != CUDA_PARALLEL) {
         fprintf(stderr, "ParticleSystem: only the GPU compute mode exists in this build "
                         "(SEQUENTIAL / OMP_PARALLEL are the reference's CPU paths; there is no CPU fallback)\n");
@@ -167,7 +167,12 @@ void ParticleSystem::update(float deltaTime, float fps) {
         using clk = std::chrono::steady_clock;
         const double now = std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
         if (m_logLastMs == 0) m_logLastMs = now;
+        m_logFrames++;
         if (now - m_logLastMs > m_logFreqMs) {
+            // LOG_OSCAR's FPS field is a RATE (the committed logs: updates per second as the window title showed them); the
+            // current source passes a frame COUNT in `fps` and prints that (LOG_FRAMES)
+            const double rate = now > m_logLastMs ? 1e3 * (double)m_logFrames / (now - m_logLastMs) : 0.0;
+            m_logFrames = 0;
             float ms[SPH_PH_COUNT]; uint32_t steps = 0;
             SPH_CHECK(sph_timing_get(m_ctx, ms, &steps));
             SPH_CHECK(sph_timing_reset(m_ctx));
@@ -176,14 +181,17 @@ void ParticleSystem::update(float deltaTime, float fps) {
             const double k = steps ? 1e6 / steps : 0.0;     // ms sums -> ns per step
             double total = 0;
             for (int i = 0; i < SPH_PH_COUNT; i++) total += ms[i];
-            fprintf((FILE*)m_log,
-                    "%gsec\ttotal:%lldns,\t\tcopying:%lldns,\t\tz-index:%lldns,\t\tsort:%lldns,\t\tb-grid:%lldns,\t\t"
-                    "b'-grid:%lldns,\t\tdens:%lldns,\t\tforce:%lldns,\t\tcollision:%lldns,\t\tintegrate:%lldns,\t\t"
-                    "frames:%lldframes\n",
-                    m_logGlobalMs / 1000, (long long)(total * k), 0LL, (long long)(ms[SPH_PH_ZINDEX] * k),
-                    (long long)(ms[SPH_PH_SORT] * k), (long long)(ms[SPH_PH_BGRID] * k), 0LL,
-                    (long long)(ms[SPH_PH_DENS] * k), (long long)(ms[SPH_PH_FORCE] * k),
-                    (long long)(ms[SPH_PH_COLLISION] * k), (long long)(ms[SPH_PH_INTEGRATE] * k), (long long)fps);
+            const long long t_ns = (long long)(total * k), z_ns = (long long)(ms[SPH_PH_ZINDEX] * k), s_ns = (long long)(ms[SPH_PH_SORT] * k),
+                            b_ns = (long long)(ms[SPH_PH_BGRID] * k), d_ns = (long long)(ms[SPH_PH_DENS] * k),
+                            f_ns = (long long)(ms[SPH_PH_FORCE] * k), c_ns = (long long)(ms[SPH_PH_COLLISION] * k),
+                            i_ns = (long long)(ms[SPH_PH_INTEGRATE] * k);
+            const char* body = "\ttotal:%lldns,\t\tcopying:%lldns,\t\tz-index:%lldns,\t\tsort:%lldns,\t\tb-grid:%lldns,\t\t"
+                               "b'-grid:%lldns,\t\tdens:%lldns,\t\tforce:%lldns,\t\tcollision:%lldns,\t\tintegrate:%lldns,\t\t";
+            if (m_logStyle == LOG_OSCAR) fprintf((FILE*)m_log, "%.3fsec", m_logGlobalMs / 1000);    // always a decimal point: benchmark.py:12
+            else fprintf((FILE*)m_log, "%gsec", m_logGlobalMs / 1000);
+            fprintf((FILE*)m_log, body, t_ns, 0LL, z_ns, s_ns, b_ns, 0LL, d_ns, f_ns, c_ns, i_ns);
+            if (m_logStyle == LOG_OSCAR) fprintf((FILE*)m_log, "FPS:%.3ffps\n", rate);
+            else fprintf((FILE*)m_log, "frames:%lldframes\n", (long long)fps);
             fflush((FILE*)m_log);
         }
     }
@@ -332,8 +340,9 @@ bool ParticleSystem::phaseTimings(float ms[SPH_PH_COUNT], uint* steps) {
     return s > 0;
 }
 
-void ParticleSystem::setBenchmarkLog(const std::string& path, double min_interval_ms) {
+void ParticleSystem::setBenchmarkLog(const std::string& path, double min_interval_ms, BenchmarkLogStyle style) {
     m_logFreqMs = min_interval_ms;
+    m_logStyle = (int)style;
     if (m_log) { fclose((FILE*)m_log); m_log = nullptr; }
     m_logPath = path;
     if (path.empty()) { SPH_CHECK(sph_timing_enable(m_ctx, 0)); return; }

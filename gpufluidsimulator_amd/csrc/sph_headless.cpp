@@ -2,7 +2,7 @@
 // (SPH/particles.cpp:676-706: -n= -box= -i= -benchmark -device= -file=) and its runBenchmark()
 // output line (:176-192), on top of include/particleSystem.h.  No GLUT / OpenGL.
 //   sph_headless -benchmark -n=262144 -box=8 -i=100 [-device=0] [-grid=128] [-ic=grid|random] [-steps=1] [-dump=8]
-//                [-log=benchmark.txt] [-file=<snapshot>]
+//                [-log=benchmark.txt [-logstyle=oscar|frames]] [-file=<snapshot>]
 // Several GPUs (no counterpart in the reference, which is a single-device program): -gpus=N cuts the dam into N
 // z-slabs and steps them with sph_slab_step through the C ABI --
 //   -gpus=N            N child PROCESSES, forked before anything touches a GPU, rank r on device r (+ -device=), messages
@@ -325,7 +325,7 @@ int main(int argc, char** argv) {
     if (flag(argc, argv, "help")) {
         printf("usage: sph_headless [-benchmark] [-n=<particles>] [-box=<edge>] [-i=<iterations>] [-device=<id>] [-grid=<cells per axis>] "
                "[-ic=grid|random] [-steps=<per update>] [-gpus=<N> [-onegpu] [-slab] [-lattice=nx,ny,nz]] "
-               "[-dump=<count>] [-log=<file>] [-sphere=<update>[,<radius>]] [-out=<file>] [-save=<file>] [-load=<file>] [-file=<file>]\n");
+               "[-dump=<count>] [-log=<file> [-logfreq=<ms>] [-logstyle=oscar|frames]] [-sphere=<update>[,<radius>]] [-out=<file>] [-save=<file>] [-load=<file>] [-file=<file>]\n");
         return 0;
     }
     const int gpus = value(argc, argv, "gpus") ? atoi(value(argc, argv, "gpus")) : 1;
@@ -368,7 +368,11 @@ int main(int argc, char** argv) {
     psystem->setIterations(substeps);
     if (const char* v = value(argc, argv, "log")) {
         const char* fq = value(argc, argv, "logfreq");
-        psystem->setBenchmarkLog(v, fq ? atof(fq) : 2000.0);
+        // -logstyle=oscar: the line form of the reference's committed logs (benchmarks/oscar/, what its benchmark.py reads);
+        // default: what its current source writes (particleSystem.cpp:703-714)
+        const char* st = value(argc, argv, "logstyle");
+        if (st && strcmp(st, "oscar") && strcmp(st, "frames")) { fprintf(stderr, "-logstyle=%s: expected oscar or frames\n", st); return EXIT_FAILURE; }
+        psystem->setBenchmarkLog(v, fq ? atof(fq) : 2000.0, st && !strcmp(st, "oscar") ? ParticleSystem::LOG_OSCAR : ParticleSystem::LOG_FRAMES);
     }
     uint3 g = psystem->getGridSize();
     printf("Run %u particles simulation for %d iterations... (grid %ux%ux%u, box %g)\n\n", numParticles, iterations, g.x, g.y, g.z, box);

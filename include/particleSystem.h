@@ -104,8 +104,14 @@ public:
     // checkpoint / resume (sph_snapshot_save / sph_snapshot_load); a resumed run is bit-identical
     void saveState(const std::string& path);
     void loadState(const std::string& path);
-    // opt-in text log in the reference's dumpBenchmark format (particleSystem.cpp:697-716)
-    void setBenchmarkLog(const std::string& path, double min_interval_ms = 2000.0 /* BENCHMARK_FREQ */);
+    // opt-in text log in the reference's dumpBenchmark format (particleSystem.cpp:697-716).  Two line styles, because the
+    // reference has two: LOG_FRAMES is what its current source writes ("<int>sec ... frames:<n>frames"), LOG_OSCAR is the
+    // form of its 18 committed logs (benchmarks/oscar/<N>/*.txt: "2.005sec ... FPS:189.322fps"), which is the only form its
+    // benchmark.py:12 regex reads -- so a log written in that style can be summarised next to the published ones
+    // (tools/bench_log_summary.py reads both).
+    enum BenchmarkLogStyle { LOG_FRAMES = 0, LOG_OSCAR = 1 };
+    void setBenchmarkLog(const std::string& path, double min_interval_ms = 2000.0 /* BENCHMARK_FREQ */,
+                         BenchmarkLogStyle style = LOG_FRAMES);
 
 protected:
     void _initialize(int numParticles);
@@ -127,6 +133,8 @@ protected:
     std::string m_logPath;
     void* m_log;
     double m_logLastMs, m_logGlobalMs, m_logFreqMs;
+    int m_logStyle;
+    unsigned long long m_logFrames;
 };
 
 extern "C" {
