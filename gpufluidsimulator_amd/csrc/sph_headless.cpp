@@ -24,7 +24,9 @@
 #include <thread>
 #include <vector>
 
+#include <cerrno>
 #include <fcntl.h>
+#include <poll.h>
 #include <signal.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
@@ -100,21 +102,29 @@ bool plan_slabs(const SlabJob& j, int world, Plan& pl, std::string& err) {
 
 struct RankResult { double seconds = 0.0; uint32_t owned = 0; double ping_us[3] = {0, 0, 0}; int rc = 0; char err[256] = {0}; };
 
-// a barrier between the ranks: threads share a counter, processes talk to the parent through pipes
+// a barrier between the ranks: threads share a counter, processes talk to the parent through pipes.  vote(ok) is the same
+// barrier carrying one bit each way: every rank says whether it is fine, everybody learns whether ALL are (the parent --
+// or the last thread to arrive -- forms the AND).  The "ready" round in front of the transport uses it: a rank whose
+// context, lattice or device set-up failed must stop the others BEFORE they enter ncclCommInitRank, where they would wait
+// for it for ever (no time-out of the library covers that call).
 struct Gate {
     std::mutex mu; std::condition_variable cv; int world = 1, waiting = 0; uint64_t round = 0;
+    bool all_ok = true, result = true;
     int to_parent = -1, from_parent = -1;        // process mode
-    void wait() {
+    bool vote(bool ok) {
         if (to_parent >= 0) {
-            char b = 1;
-            if (write(to_parent, &b, 1) != 1 || read(from_parent, &b, 1) != 1) _exit(3);
-            return;
+            char b = ok ? 1 : 0;
+            if (write(to_parent, &b, 1) != 1 || read(from_parent, &b, 1) != 1) _exit(3);      // the parent is gone
+            return b == 1;
         }
         std::unique_lock<std::mutex> g(mu);
         const uint64_t my = round;
-        if (++waiting == world) { waiting = 0; round++; cv.notify_all(); }
+        all_ok = all_ok && ok;
+        if (++waiting == world) { waiting = 0; result = all_ok; all_ok = true; round++; cv.notify_all(); }
         else cv.wait(g, [&] { return round != my; });
+        return result;
     }
+    void wait() { (void)vote(true); }
 };
 
 void rank_main(const SlabJob& j, const Plan& pl, int rank, int world, int device, sph_local_hub* hub, const uint8_t* rccl_id, Gate& gate,
@@ -147,6 +157,16 @@ void rank_main(const SlabJob& j, const Plan& pl, int rank, int world, int device
     bool ok = sph_create_slab(&ctx, device, cap, &prm, z_lo, z_hi, gcap) == 0;
     if (!ok) fail("sph_create_slab");
     if (ok && n_own && sph_reset_lattice(ctx, j.lattice, 1, nullptr, first, (uint32_t)n_own) < 0) { ok = false; fail("sph_reset_lattice"); }
+    if (ok && sph_sync(ctx) < 0) { ok = false; fail("set-up"); }
+    // test hooks (tests/test_gpu_host_class.py): this rank fails its set-up / never reaches the READY round
+    if (const char* e = getenv("SPH_HEADLESS_TEST_FAIL_SETUP")) if (ok && atoi(e) == rank) { ok = false; res.rc = -1; snprintf(res.err, sizeof res.err, "rank %d: set-up failed (test hook)", rank); }
+    if (const char* e = getenv("SPH_HEADLESS_TEST_HANG_RANK")) if (atoi(e) == rank) for (;;) pause();
+    // READY round: nobody creates its transport unless every rank has its context and particles (see Gate::vote)
+    if (!gate.vote(ok)) {
+        if (ok) { res.rc = -1; snprintf(res.err, sizeof res.err, "rank %d: stopped before the transport was created: another rank failed its set-up", rank); }
+        if (ctx) sph_destroy(ctx);
+        return;
+    }
     if (ok && (hub ? sph_local_transport_create(&tr, hub, rank) : sph_rccl_transport_create(&tr, rccl_id, rank, world, device)) < 0) {
         ok = false; fail("transport");
     }
@@ -203,6 +223,8 @@ void rank_main(const SlabJob& j, const Plan& pl, int rank, int world, int device
     if (ctx) sph_destroy(ctx);
 }
 
+// a per-round deadline of the -gpus=N parent, in seconds (environment override for tests)
+double deadline_for(const char* env, double dflt) { const char* e = getenv(env); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : dflt; }
 bool read_all(int fd, void* p, size_t n) { char* c = (char*)p; while (n) { ssize_t k = read(fd, c, n); if (k <= 0) return false; c += k; n -= (size_t)k; } return true; }
 bool write_all(int fd, const void* p, size_t n) { const char* c = (const char*)p; while (n) { ssize_t k = write(fd, c, n); if (k <= 0) return false; c += k; n -= (size_t)k; } return true; }
 
@@ -248,31 +270,72 @@ int run_slabs(const SlabJob& j, int world, bool onegpu, int device0) {
                     if (r != 0 || q == 0) close(id_pipe[2 * q + 1]);
                 }
                 RankResult rr;
-                uint8_t id[128] = {0};
+                uint8_t msg[129] = {0};                    // [0]: 1 = an RCCL id follows, 0 = rank 0 has none (abort)
                 int ndev = sph_device_count(nullptr);
                 if (ndev < device0 + world) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank %d: %d GPUs asked for, %d visible (one GPU: -onegpu)", r, device0 + world, ndev); }
                 if (!rr.rc && sph_select_device(device0 + r) < 0) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank %d: %s", r, sph_last_error()); }
                 if (r == 0) {
-                    if (!rr.rc && sph_rccl_unique_id(id) < 0) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank 0: %s", sph_last_error()); }
-                    for (int q = 1; q < world; q++) write_all(id_pipe[2 * q + 1], id, 128);       // (zeros on failure: the others fail too)
-                } else if (!read_all(id_pipe[2 * r], id, 128)) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank %d: no RCCL id from rank 0", r); }
+                    if (!rr.rc && sph_rccl_unique_id(msg + 1) < 0) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank 0: %s", sph_last_error()); }
+                    msg[0] = rr.rc ? 0 : 1;                // an explicit "no id" instead of 128 zeros the others would try to connect with
+                    for (int q = 1; q < world; q++) write_all(id_pipe[2 * q + 1], msg, sizeof msg);
+                } else if (!read_all(id_pipe[2 * r], msg, sizeof msg)) { if (!rr.rc) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank %d: no RCCL id from rank 0", r); } }
+                else if (msg[0] != 1 && !rr.rc) { rr.rc = -1; snprintf(rr.err, sizeof rr.err, "rank %d: rank 0 could not make an RCCL id", r); }
                 Gate gate; gate.to_parent = up[2 * r + 1]; gate.from_parent = down[2 * r];
-                if (!rr.rc) rank_main(j, pl, r, world, device0 + r, nullptr, id, gate, rr);
-                else { gate.wait(); gate.wait(); }
+                if (!rr.rc) rank_main(j, pl, r, world, device0 + r, nullptr, msg + 1, gate, rr);
+                else (void)gate.vote(false);               // the READY round: the parent tells everybody to stop
                 write_all(out_pipe[2 * r + 1], &rr, sizeof rr);
                 _exit(rr.rc ? 1 : 0);
             }
         }
         signal(SIGPIPE, SIG_IGN);                      // (a write to a rank that died must be an error code, not this process's end)
         for (int r = 0; r < world; r++) { close(up[2 * r + 1]); close(down[2 * r]); close(out_pipe[2 * r + 1]); close(id_pipe[2 * r]); close(id_pipe[2 * r + 1]); }
+        // The parent never blocks on one rank: it polls every live rank's pipe with a DEADLINE per round.  A rank that hangs
+        // where no time-out of the library reaches (ncclCommInitRank waiting for a rank that never comes, a wedged device)
+        // would otherwise hold the whole job for ever: on expiry the children are killed, reaped, and the run fails.
         std::vector<bool> dead(world, false);
-        for (int round = 0; round < 2; round++) {      // the two barriers of rank_main
-            char b = 1;
-            for (int r = 0; r < world; r++)
-                if (!dead[r] && read(up[2 * r], &b, 1) != 1) { dead[r] = true; fprintf(stderr, "rank %d died\n", r); }      // (end of file: it closed its end)
+        auto kill_all = [&](const char* why) {
+            fprintf(stderr, "-gpus=%d: %s: killing the ranks\n", world, why);
+            for (int r = 0; r < world; r++) kill(kids[r], SIGKILL);
+            for (int r = 0; r < world; r++) { int st = 0; waitpid(kids[r], &st, 0); }
+        };
+        // one byte from every live rank (0/1), then the AND of them back to every live rank; false: deadline expired
+        auto round_trip = [&](const char* name, double deadline_s, bool& all_ok) -> bool {
+            std::vector<int> got(world, -1);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                std::vector<pollfd> fds; std::vector<int> who;
+                for (int r = 0; r < world; r++) if (!dead[r] && got[r] < 0) { fds.push_back(pollfd{up[2 * r], POLLIN, 0}); who.push_back(r); }
+                if (fds.empty()) break;
+                const double left = deadline_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (left <= 0.0) {
+                    std::string late;
+                    for (int r : who) late += " " + std::to_string(r);
+                    fprintf(stderr, "-gpus=%d: no answer at the '%s' barrier from rank(s)%s after %.0f s\n", world, name, late.c_str(), deadline_s);
+                    return false;
+                }
+                const int k = poll(fds.data(), (nfds_t)fds.size(), (int)std::min(left * 1e3 + 1.0, 1000.0));
+                if (k < 0 && errno != EINTR) { perror("poll"); return false; }
+                for (size_t i = 0; k > 0 && i < fds.size(); i++) {
+                    if (!(fds[i].revents & (POLLIN | POLLHUP | POLLERR))) continue;
+                    char b = 0;
+                    if (read(fds[i].fd, &b, 1) == 1) got[who[i]] = b ? 1 : 0;
+                    else { dead[who[i]] = true; fprintf(stderr, "rank %d died\n", who[i]); }      // (end of file: it closed its end)
+                }
+            }
+            all_ok = true;
+            for (int r = 0; r < world; r++) all_ok = all_ok && !dead[r] && got[r] == 1;
+            const char b = all_ok ? 1 : 0;
             for (int r = 0; r < world; r++) if (!dead[r] && write(down[2 * r + 1], &b, 1) != 1) dead[r] = true;
+            return true;
+        };
+        const double d_setup = deadline_for("SPH_HEADLESS_SETUP_S", 300.0), d_run = deadline_for("SPH_HEADLESS_RUN_S", 3600.0);
+        bool go = false, dummy = false;
+        if (!round_trip("ready", d_setup, go)) { kill_all("set-up did not finish"); return EXIT_FAILURE; }
+        if (go) {                                      // the two barriers of rank_main: in front of and behind the timed steps
+            if (!round_trip("start", d_setup, dummy)) { kill_all("transport set-up / warm-up did not finish"); return EXIT_FAILURE; }
+            if (!round_trip("end", d_run, dummy)) { kill_all("the timed steps did not finish"); return EXIT_FAILURE; }
         }
-        for (int r = 0; r < world; r++) { if (!read_all(out_pipe[2 * r], &res[r], sizeof(RankResult))) { res[r].rc = -1; snprintf(res[r].err, sizeof res[r].err, "rank %d: no result", r); } }
+        for (int r = 0; r < world; r++) { if (dead[r] || !read_all(out_pipe[2 * r], &res[r], sizeof(RankResult))) { res[r].rc = -1; snprintf(res[r].err, sizeof res[r].err, "rank %d: no result", r); } }
         for (int r = 0; r < world; r++) { int st = 0; waitpid(kids[r], &st, 0); }
     }
     double secs = 0.0; uint64_t owned = 0; bool bad = false;

@@ -4,6 +4,7 @@ import os
 import re
 import subprocess
 import tempfile
+import time
 
 import numpy as np
 import pytest
@@ -223,6 +224,17 @@ def test_driver_gpus_flag_runs_z_slabs_through_the_c_abi():
     assert a.size == b.size == 2 * 32768 * 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
     bad = subprocess.run([EXE, "-benchmark", "-n=32768", "-box=4", "-i=2", "-gpus=2"], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "GPUs asked for" in bad.stderr
+    # a rank whose set-up fails stops EVERY rank before anybody creates its transport (the READY round), at once
+    t0 = time.time()
+    bad = subprocess.run([EXE, "-benchmark", "-n=32768", "-box=4", "-i=2", "-gpus=3", "-onegpu"], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, SPH_HEADLESS_TEST_FAIL_SETUP="1"))
+    assert bad.returncode != 0 and "rank 1: set-up failed" in bad.stderr and "another rank failed its set-up" in bad.stderr
+    # ... and a rank that never answers does not hold the job for ever: the parent polls the ranks' pipes with a deadline,
+    # kills them and exits non-zero (process mode; ADVICE r5: the old parent sat in a blocking read)
+    bad = subprocess.run([EXE, "-benchmark", "-n=32768", "-box=4", "-i=2", "-gpus=1", "-slab"], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, SPH_HEADLESS_TEST_HANG_RANK="0", SPH_HEADLESS_SETUP_S="3"))
+    assert bad.returncode != 0 and "no answer at the 'ready' barrier from rank(s) 0" in bad.stderr and "killing the ranks" in bad.stderr
+    assert time.time() - t0 < 120
     # the process path with ONE rank (-gpus=1 -slab): a child forked before any GPU call, its RCCL communicator (of one), the slab
     # step, the result through the pipe, the rows through the shared mapping -- everything of -gpus=N but the neighbours
     with tempfile.TemporaryDirectory() as d:
