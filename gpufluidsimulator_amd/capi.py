@@ -98,6 +98,7 @@ SIGNATURES = {
     "sph_set_direct_hull": (C.c_int, [_P, C.c_uint32]),
     "sph_set_block_order": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint32]),
     "sph_sort_forms": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "sph_test_trust_mover_hint": (C.c_int, [_P]),
     "sph_set_precision": (C.c_int, [_P, C.c_int]),
     "sph_get_precision": (C.c_int, [_P]),
     "sph_migrants_count": (C.c_int, [_P, C.POINTER(_U32)]),
@@ -414,6 +415,10 @@ class Context:
         """merge=False/0: full radix sort every step (the SPH_SORT_MERGE=0 behaviour); True/1: merge while few
         particles change cell; 2: merge whatever the count (tests)."""
         _check(self.L.sph_set_sort_mode(self.h, int(merge)))
+
+    def trust_mover_hint(self):
+        """Test hook: after set_by_index / upload the next movers' sorts launch both forms; this takes that back."""
+        _check(self.L.sph_test_trust_mover_hint(self.h))
 
     def sort_forms(self):
         """Movers' sorts launched as (both forms, one-block sort alone, multi-block passes alone)."""

@@ -494,6 +494,7 @@ int sph_set_params(sph_ctx* c, const sph_params* p) {
     c->params = tmp.params; c->grid = tmp.grid; c->phys = tmp.phys;
     c->keys_fresh = false;      // the box may have moved: keys of the old box are stale
     c->order_valid = false;
+    c->sort_form_both_until = c->sort_calls + 5;
     return SPH_OK;
 }
 
@@ -553,6 +554,7 @@ int sph_upload(sph_ctx* c, uint32_t n, const float* pos, const float* vel, const
     c->stage = sph_ctx::ST_LOADED;
     c->keys_fresh = false;
     c->order_valid = false;     // the slots no longer follow the last sort
+    c->sort_form_both_until = c->sort_calls + 5;
     c->have_dens = c->have_force = c->have_coll = false;
     return SPH_OK;
 }
@@ -586,6 +588,7 @@ int sph_set_by_index(sph_ctx* c, uint32_t first_index, uint32_t count, const flo
     // positions moved under the keys: hash again; the slots still follow the last sort (order_valid stays)
     mm_drop_marks(c);
     c->keys_fresh = false;
+    c->sort_form_both_until = c->sort_calls + 5;      // the last reported mover count says nothing about these particles
     c->stage = sph_ctx::ST_LOADED;
     c->have_dens = c->have_force = c->have_coll = false;
     return SPH_OK;
@@ -612,6 +615,7 @@ int sph_reset_lattice(sph_ctx* c, const uint32_t lattice[3], int jitter, const f
     c->stage = sph_ctx::ST_LOADED;
     c->keys_fresh = false;
     c->order_valid = false;     // the slots no longer follow the last sort
+    c->sort_form_both_until = c->sort_calls + 5;
     c->have_dens = c->have_force = c->have_coll = false;
     return SPH_OK;
 }
@@ -1002,6 +1006,12 @@ int sph_set_sort_mode(sph_ctx* c, int merge) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     c->sort_merge = merge != 0;
     c->sort_merge_always = merge == 2;
+    return SPH_OK;
+}
+
+int sph_test_trust_mover_hint(sph_ctx* c) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    c->sort_form_both_until = 0;
     return SPH_OK;
 }
 

@@ -135,6 +135,12 @@ struct sph_ctx {
     bool host_paced = false;
     bool mm_counted_valid = false;  // mm_counted was recorded behind the scan of the CURRENT marks
     uint64_t sort_merges = 0, sort_calls = 0, sort_skips = 0;   // skips: merges with no mover at all (nothing done)
+    // A whole-domain context picks ONE form of the movers' sort from a count up to four steps old (radix_sort_bits).  A flow
+    // changes that count slowly; the caller can change it at once (new positions or velocities for everybody: an upload, a
+    // kick through sph_set_by_index, another box): for the sorts up to this call number both forms are launched again, or
+    // a count that went from 0 to millions would go through the one-block sort's tile-by-tile fallback (~8 ms per sort at
+    // 2 M movers, four times).
+    uint64_t sort_form_both_until = 0;
     uint64_t sort_forms[3] = {0, 0, 0};   // movers' sorts launched as: both forms / the one-block sort alone / the multi-block passes alone
     uint64_t* mm_mask = nullptr;    // one bit per slot: key changed since the last sort
     uint32_t* mm_M64 = nullptr;     // movers before each 64-slot chunk

@@ -199,7 +199,11 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     {   // empty unless every slot of layer 5 (and so of every layer up to zl-6) lies inside the deep range
         // and no longer than early_cap slots: the launch is there to fill the links' latency, not to run beside the interior
         // launch for its whole length (two big k_force grids side by side evict each other's L2 working sets)
-        const bool ok = zl >= 13u && s_lb[10] >= deep0 && s_lb[9] <= max(s_lb[5], deep0) && s_lb[9] > s_lb[8];
+        // (+ 64: on a step whose arrivals are merged in place the owned range's start shifts by a count that is no multiple of
+        // 64, and the launch over "everything that is not deep" then re-rounds the hole's start -- it recomputes up to 63
+        // slots at the head of the deep range on ANOTHER stream.  Same bits in fp32, but in mixed precision a density depends on
+        // which particles share a wave: no slot the early launch reads -- layer 5 onwards -- may lie in that head.)
+        const bool ok = zl >= 13u && s_lb[10] >= deep0 + 64u && s_lb[9] <= max(s_lb[5], deep0) && s_lb[9] > s_lb[8];
         dl[DL_EARLY] = own_off + s_lb[8];
         dl[DL_EARLY + 1] = own_off + (ok ? min(s_lb[9], s_lb[8] + early_cap) : s_lb[8]);
     }
@@ -796,6 +800,7 @@ struct sph_slab {
     uint32_t early_cap = 1u << 20;       // slots of that launch at most (~150 us of k_force): what a link's latency needs, no more
     uint64_t early_launches = 0, early_used = 0;
     uint32_t early_span = 0;             // slots the last step's early range held: sizes this step's grid (what a grid misses, the interior launch computes)
+    bool early_span_known = false;       // false: no step has reported a range yet (the first launch is sized for the whole slab)
     uint32_t* recut_blk = nullptr;       // sph_slab_recut: {down, up} counts per 1024-slot block, then their scan
     uint64_t recuts = 0, recut_moved = 0;
     // failure: the first error of this slab (sticky), its message, and whether the transport may still be used
@@ -1008,9 +1013,13 @@ int slab_step_body(sph_slab* s, float dt) {
     bool early_launched = false;
     // the grid: the range's size is on the device; the host sizes the launch from the LAST step's range plus a margin (a range
     // changes by a few slots a step) -- whatever a too small grid leaves out is computed by the interior launch below
-    const uint32_t early_grid_slots = s->early_span ? min(n0, ((s->early_span + s->early_span / 64u + 1023u) & ~255u)) : n0;
+    const uint32_t early_grid_slots = s->early_span_known ? min(n0, ((s->early_span + s->early_span / 64u + 1023u) & ~255u)) : n0;
     bool early_pending = false;          // the launch runs on its own stream: the main stream has not waited for it yet
-    if (deep_valid && s->early_force && s->world > 1 && c->grid.zl >= 13u) {          // (no neighbour, no latency to fill)
+    // "the last step's range was EMPTY" (layer 5 not inside the deep range, a sparse slab) is not "unknown": no launch then --
+    // a full-size grid of blocks that leave at once, two events and a stream hop bought nothing, every step.  The bounds
+    // kernel reports the range whether or not a launch used it, so the launch comes back one step after the range does.
+    const bool early_empty = s->early_span_known && s->early_span == 0u;
+    if (deep_valid && s->early_force && s->world > 1 && c->grid.zl >= 13u && !early_empty) {          // (no neighbour, no latency to fill)
         if (s->early_own_stream && s->early) {
             SPH_HIP(hipEventRecord(s->ev_early_go, c->stream));             // behind the deep density
             SPH_HIP(hipStreamWaitEvent(s->early, s->ev_early_go, 0));
@@ -1058,6 +1067,7 @@ int slab_step_body(sph_slab* s, float dt) {
     const uint32_t early_lo = s->h_lb[HL_EARLY];                                       // what the early force launch covered:
     const uint32_t early_hi = min(s->h_lb[HL_EARLY + 1], early_lo + early_grid_slots);      // its range, as far as its grid reached
     s->early_span = s->h_lb[HL_EARLY + 1] - early_lo;
+    s->early_span_known = true;
     const uint32_t far_lo = s->has_lo ? s->h_lb[HL_FAR] : 0u, far_hi = s->has_hi ? s->h_lb[HL_FAR + 1] : 0u;
     const uint32_t m_lo = lb0, m_hi = n0 - lb3;
     uint32_t own_lo = lb1 - lb0, own_hi = lb3 - lb2;
@@ -1892,11 +1902,15 @@ static int slab_recut_body(sph_slab* s, uint32_t new_lo, uint32_t new_hi) {
     if (s->has_lo) in_lo = s->h_lb[HL_RECUT + 2];
     if (s->has_hi) in_hi = s->h_lb[HL_RECUT + 3];
     const uint64_t n_new = (uint64_t)keep + in_lo + in_hi;
-    SPH_REQUIRE(n_new <= c->cap, SPH_E_CAPACITY, "rank %d: the layers [%u, %u) hold %llu particles, the capacity is %u", s->rank, new_lo,
-                new_hi, (unsigned long long)n_new, c->cap);
+    // A rank that cannot hold what is coming does NOT simply return: its neighbours have sized the particle rounds from the
+    // counts and are about to post them -- they would sit in their bounded waits and abort their transports.  It takes part
+    // in every round (its leaving runs go out, what arrives is received and dropped), THEN reports the error and is failed;
+    // its neighbours complete their re-cut and hear of the failure in the header of its next migrant message, as after a
+    // failed step (slab_fail).
+    const bool over = n_new > c->cap;
     // what stays goes to its final place in the (now free) primary arrays: behind what comes from below
     const uint32_t base = c->gcap;
-    if (keep)
+    if (keep && !over)
         hipLaunchKernelGGL(k_recut_copy, dim3(ceil_div(keep, 256u)), dim3(256), 0, c->stream, c->posi2, c->velr2, keep0, c->posi, c->velr,
                            base + in_lo, keep);
     // the two leaving runs, chunk by chunk; both ends of a link know both counts, so they agree on every size
@@ -1913,7 +1927,7 @@ static int slab_recut_body(sph_slab* s, uint32_t new_lo, uint32_t new_hi) {
         rc = slab_exchange(s, SPH_TAG_RECUT, s->halo_send[0], s_lo * rec, s->halo_recv[0], r_lo * rec, s->halo_send[1], s_hi * rec,
                            s->halo_recv[1], r_hi * rec);
         if (rc) return rc;
-        if (r_lo + r_hi)
+        if (r_lo + r_hi && !over)
             hipLaunchKernelGGL(k_recut_unpack, dim3(ceil_div(r_lo + r_hi, 256u)), dim3(256), 0, s->comm, s->halo_recv[0], r_lo,
                                base + j * chunk, s->halo_recv[1], r_hi, base + in_lo + keep + j * chunk, c->posi, c->velr);
         SPH_HIP(hipGetLastError());
@@ -1921,6 +1935,8 @@ static int slab_recut_body(sph_slab* s, uint32_t new_lo, uint32_t new_hi) {
     }
     rc = slab_wait_stream(s, s->comm, "re-cut (particles)"); if (rc) return rc;
     SPH_HIP(hipStreamSynchronize(c->stream));
+    SPH_REQUIRE(!over, SPH_E_CAPACITY, "rank %d: the layers [%u, %u) hold %llu particles, the capacity is %u (the neighbours' re-cut "
+                "went through; this rank's particles are lost: the slab is failed)", s->rank, new_lo, new_hi, (unsigned long long)n_new, c->cap);
     c->own_off = base;
     c->n = (uint32_t)n_new;
     rc = set_slab_range(c, new_lo, new_hi); if (rc) return rc;
@@ -1936,6 +1952,12 @@ int sph_slab_recut(sph_slab* s, uint32_t new_z_lo, uint32_t new_z_hi) {
     SPH_REQUIRE(s->world == 1 || new_z_hi - new_z_lo >= 2, SPH_E_INVALID, "a slab needs at least two cell layers");
     SPH_REQUIRE((s->has_lo || new_z_lo == 0u) && (s->has_hi || new_z_hi == s->c->params.grid[2]), SPH_E_INVALID,
                 "rank %d of %d: the outer slabs reach to the ends of the grid", s->rank, s->world);
+    // a particle moves ONE rank per call: a new range that does not even touch the old one would hand particles to a
+    // neighbour that does not own their layer either (the full single-hop rule -- new cut r within [old cut r-1, old cut
+    // r+1] -- needs the neighbours' old cuts: slab.py single_hop_cuts; this is the part one rank can see)
+    SPH_REQUIRE(new_z_lo <= s->c->z_hi && new_z_hi >= s->c->z_lo, SPH_E_INVALID,
+                "rank %d: the new layers [%u, %u) do not touch the old ones [%u, %u): move the cuts one hop at a time", s->rank, new_z_lo,
+                new_z_hi, s->c->z_lo, s->c->z_hi);
     SPH_HIP(hipSetDevice(s->c->device));
     const uint64_t exchanges0 = s->exchanges;
     const bool timed0 = s->time_groups;

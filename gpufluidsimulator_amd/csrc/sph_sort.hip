@@ -892,7 +892,7 @@ static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32
     // quarter of the one-block sort's capacity as the margin for what four steps can change, and both forms in between.
     int form = SORT_FORM_BOTH;
     if (small_max && c->host_paced) form = tail.hint <= OS_SMALL_MAX ? SORT_FORM_SMALL : SORT_FORM_BIG;
-    else if (small_max && SPH_OS_FORM_HINT && tail.hint != 0xFFFFFFFFu)
+    else if (small_max && SPH_OS_FORM_HINT && tail.hint != 0xFFFFFFFFu && c->sort_calls > c->sort_form_both_until)
         form = tail.hint <= OS_SMALL_MAX - OS_SMALL_MAX / 4u ? SORT_FORM_SMALL
              : (tail.hint > OS_SMALL_MAX + OS_SMALL_MAX / 4u ? SORT_FORM_BIG : SORT_FORM_BOTH);
     if (tail.form) *tail.form = form;

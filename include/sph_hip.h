@@ -415,6 +415,10 @@ int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]);
  * out = {steps that launched it, steps that used its result} (a step whose arrivals re-sort the slab discards it). */
 int sph_slab_set_early_force(sph_slab* s, int on);
 int sph_slab_early_force_stats(const sph_slab* s, uint64_t out[2]);
+/* TEST HOOK: sph_upload / sph_set_by_index / sph_reset_lattice / sph_set_params make the next five movers' sorts of a
+ * whole-domain context launch BOTH forms (the caller may have changed every particle: the count the device last reported says
+ * nothing).  This takes that back, so that a test can put a changed state in front of a sort launched on the old count. */
+int sph_test_trust_mover_hint(sph_ctx* c);
 /* TEST HOOK: raise sticky device-side error word `flag` (0: an arrival outside its boundary layer, 1: an arrival outside
  * the slab) as the insert / unpack kernels would; the next sph_slab_step then fails before it has sent anything. */
 int sph_slab_test_raise_flag(sph_slab* s, int flag);

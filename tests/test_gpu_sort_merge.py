@@ -259,6 +259,7 @@ def test_a_whole_domain_context_guesses_the_sort_form_and_a_wrong_guess_is_still
             cur[pick, 0] += step
             for c in (a, b):
                 c.set_by_index(0, pos=cur)
+                c.trust_mover_hint()       # (a caller that rewrites particles gets both forms for five sorts: here the FLOW is meant to have moved them)
                 c.hash(); c.sort()
             assert np.array_equal(a.keys(), b.keys()) and np.array_equal(a.order(), b.order()), movers
             assert b.sort_stats()["last_movers"] == movers
@@ -268,5 +269,15 @@ def test_a_whole_domain_context_guesses_the_sort_form_and_a_wrong_guess_is_still
         assert d[2] == (0, 1, 0), d          # 20000 movers behind a count of 5: still the one-block sort, alone and exact
         assert d[3] == (0, 0, 1), d          # 5 movers behind a count of 20000: the passes alone
         assert d[4] == (0, 1, 0), d
+        # without the hook: new particle data from the caller -> both forms for the next five sorts (the count the device
+        # last reported says nothing about them: a kick of every particle must not go through the one-block fallback)
+        f0 = b.sort_forms()
+        pick = rng.choice(n, size=30000, replace=False)
+        cur[pick, 0] += np.where(cur[pick, 0] < 0.0, 1.0, -1.0).astype(np.float32) / np.float32(16.0)
+        for c in (a, b):
+            c.set_by_index(0, pos=cur)
+            c.hash(); c.sort()
+        assert np.array_equal(a.keys(), b.keys()) and np.array_equal(a.order(), b.order())
+        assert tuple(y - x for x, y in zip(f0, b.sort_forms())) == (1, 0, 0)
     finally:
         a.close(); b.close()
