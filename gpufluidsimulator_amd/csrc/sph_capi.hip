@@ -113,9 +113,7 @@ static void free_all(sph_ctx* c) {
     hipFree(c->d_scratch);
     hipFree(c->mm_mask); hipFree(c->mm_M64); hipFree(c->mm_tile_cnt); hipFree(c->mm_tile_off);
     hipFree(c->mm_k0); hipFree(c->mm_k1); hipFree(c->mm_v1); hipFree(c->mm_count); hipFree(c->mm_total);
-    if (c->mm_counted) hipEventDestroy(c->mm_counted);
     if (c->mm_count_host) hipHostFree(c->mm_count_host);
-    for (hipEvent_t e : c->mm_done) if (e) hipEventDestroy(e);
     if (c->h_scratch) hipHostFree(c->h_scratch);
 }
 
@@ -221,24 +219,15 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
         if (!rc) rc = dev_alloc(&c->mm_v1, (size_t)capacity);
         if (!rc) rc = dev_alloc(&c->mm_count, (size_t)1);
         if (!rc) rc = dev_alloc(&c->mm_total, (size_t)1);
-        if (!rc && hipEventCreateWithFlags(&c->mm_counted, hipEventDisableTiming) != hipSuccess) {
-            set_error("hipEventCreate failed");
-            rc = SPH_E_DEVICE;
-        }
-        if (!rc && (hipHostMalloc((void**)&c->mm_count_host, 4 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        if (!rc && (hipHostMalloc((void**)&c->mm_count_host, 8 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
                     hipHostGetDevicePointer((void**)&c->mm_count_host_dev, c->mm_count_host, 0) != hipSuccess)) {
             set_error("hipHostMalloc(mapped) failed");
             rc = SPH_E_NOMEM;
         }
-        for (int k = 0; k < 4 && !rc; k++)
-            if (hipEventCreateWithFlags(&c->mm_done[k], hipEventDisableTiming) != hipSuccess) {
-                set_error("hipEventCreate failed");
-                rc = SPH_E_DEVICE;
-            }
         if (!rc) {
             c->mm_count_host[0] = 0;
             c->mm_count_host[1] = 1; c->mm_count_host[2] = 0;          // "no estimate yet" (first key > last key)
-            c->mm_count_host[3] = 0;
+            for (int k = 3; k < 8; k++) c->mm_count_host[k] = 0;
             if (hipMemset(c->mm_tile_cnt, 0, ntiles * sizeof(uint32_t)) != hipSuccess ||
                 hipMemset(c->mm_count, 0, sizeof(uint32_t)) != hipSuccess ||
                 hipMemset(c->mm_total, 0, sizeof(unsigned long long)) != hipSuccess) {

@@ -104,6 +104,9 @@ struct sph_ctx {
     uint32_t cells_lo = 0, cells_hi = 0;   // slot range the table was built from
     bool cells_valid = false;
     bool cells_clear_deferred = false;   // sph_hash left the clearing of the old table to the sort (merge path)
+    // the slab step builds the table of the owned slots INSIDE its bounds kernel (one dispatch less on every rank's critical
+    // path): it sets `owned_cells_in_bounds` around its sort, the sort then leaves the build `pending` instead of launching it
+    bool owned_cells_in_bounds = false, owned_cells_pending = false;
     bool keys_fresh = false;   // k0 already holds the keys of the current positions (written by the integrate epilogue)
 
     // radix sort scratch
@@ -129,11 +132,18 @@ struct sph_ctx {
     bool order_valid = false;       // [own_off, own_off+n) is still in the order of the last sort, keyS = its keys
     bool last_sort_skipped = false;
     // A slab context is stepped by sph_slab_step, whose host waits for the device once per step: the host cannot run
-    // ahead, so the event ring that bounds the run-ahead (mm_done) is not needed, and the "count is ready" event
-    // (mm_counted) only while the fluid is at rest (the skip it serves needs a count of 0).  Every event recorded on
-    // the stream costs the device ~5 us of idle at the next dispatch: 10 us per step at 2 M particles per GPU.
+    // ahead, so its run-ahead needs no bound.
     bool host_paced = false;
-    bool mm_counted_valid = false;  // mm_counted was recorded behind the scan of the CURRENT marks
+    // What the host learns from the device about the sorts WITHOUT events (every event recorded on a stream costs the device
+    // ~5.5 us of idle at its next dispatch; rounds 1-5 recorded two per step in a whole-domain context: 11 us of a 92 us step
+    // at 131,072 particles, profiles/r06base_headless_n131072_kernel_stats.csv): the kernels echo sequence numbers into the
+    // mapped host block mm_count_host -- [3] the number of the last sort whose table build has started (bounds the host's
+    // run-ahead to four sorts), [4] the number of the last mover count, stored AFTER the count [0] (the skip of a sort with
+    // nothing to do needs the count of the CURRENT marks: it is looked at, never waited for).
+    uint32_t sort_seq_issued = 0;   // sorts that queued a table build so far
+    uint32_t scan_seq_issued = 0;   // mover counts queued so far (k_mm_tilescan; k_mm_compact when it counts itself)
+    uint32_t cells_seq_next = 0;    // what the next whole-range table build echoes into mm_count_host[3] (0: nothing)
+    bool mm_counted_valid = false;  // the last count queued (scan_seq_issued) is that of the CURRENT marks
     uint64_t sort_merges = 0, sort_calls = 0, sort_skips = 0;   // skips: merges with no mover at all (nothing done)
     // A whole-domain context picks ONE form of the movers' sort from a count up to four steps old (radix_sort_bits).  A flow
     // changes that count slowly; the caller can change it at once (new positions or velocities for everybody: an upload, a
@@ -148,11 +158,10 @@ struct sph_ctx {
     uint32_t* mm_k0 = nullptr; uint32_t* mm_k1 = nullptr; uint32_t* mm_v1 = nullptr;   // mover (key, slot) ping-pong (+ v0)
     uint32_t* mm_count = nullptr;           // movers of the current sort (device)
     uint32_t* mm_count_host = nullptr;      // pinned, written by the device: [0] last known count (a hint), [1], [2] the keys of
-                                            // the first / last owned slot after the last table build (block_order's estimate)
+                                            // the first / last owned slot after the last table build (block_order's estimate),
+                                            // [3] / [4] sequence numbers of the last table build / the last count (above); 8 words
     uint32_t* mm_count_host_dev = nullptr;  // device view of the same word
     unsigned long long* mm_total = nullptr; // movers of all sorts so far (device; sph_sort_stats)
-    hipEvent_t mm_done[4] = {nullptr, nullptr, nullptr, nullptr};   // end of the last four sorts: bounds the host's run-ahead
-    hipEvent_t mm_counted = nullptr;        // after the mover count of the current sort (queried, never waited for)
     // the fused integrate epilogue already wrote mm_mask / mm_tile_cnt for the range it was launched on
     bool mm_marked = false;
     bool mm_scanned = false;        // ... and the scan that counts them is already queued (mm_scan_marks)
@@ -206,6 +215,8 @@ int launch_cells_build_range(sph_ctx* c, uint32_t lo, uint32_t hi);
 int launch_cells_clear_2ranges(sph_ctx* c, uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1);
 int launch_cells_build_2ranges(sph_ctx* c, uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1);
 int launch_cells_build(sph_ctx* c);
+constexpr uint32_t CELLS_SPT = 4;                     // slots per thread of the table build (sph_device.hpp: cells_build_thread)
+inline uint32_t cells_build_blocks(uint32_t count) { return (count + 256u * CELLS_SPT - 1u) / (256u * CELLS_SPT); }
 int launch_density(sph_ctx* c);
 int launch_force(sph_ctx* c, bool force, bool collide, bool integrate, float dt);
 // sub-range forms for the slab driver (interior first, boundary layers once the ghosts are in)

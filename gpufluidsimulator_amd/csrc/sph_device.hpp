@@ -92,6 +92,35 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// ---- cell table: {start, end} per occupied cell from boundary flags on the sorted keys (k_cells_build, sph_pairs.hip; the slab
+//      step's bounds kernel runs the same build in its spare blocks, sph_slab.hip) ------------------------------------------------
+// Thread t of the build takes CELLS_SPT = 4 consecutive slots from lo + 4 t: six key reads for four slots instead of twelve, a
+// quarter of the threads (one slot per thread took 51 us for 16.7 M slots: far from any bandwidth).  No atomics: the first /
+// last slot of a cell's run writes .x / .y.  ends_host (the whole owned range only): the first and the last key, and the sort's
+// sequence number, into mapped host memory (block_order's estimate; launch_sort's throttle).
+__device__ __forceinline__ void cells_build_thread(const uint32_t* __restrict__ key, uint32_t lo, uint32_t hi, uint2* __restrict__ cells,
+                                                   volatile uint32_t* __restrict__ ends_host, uint32_t seq, uint32_t t) {
+    const uint32_t s0 = lo + t * CELLS_SPT;
+    if (s0 >= hi) return;
+    if (ends_host && s0 == lo) {
+        ends_host[0] = key[lo]; ends_host[1] = key[hi - 1u];
+        if (seq) ends_host[2] = seq;
+    }
+    uint32_t kk[CELLS_SPT + 2];                          // key[s0 - 1 .. s0 + 4]
+    kk[1] = key[s0];
+    kk[0] = s0 > lo ? key[s0 - 1] : ~kk[1];
+#pragma unroll
+    for (uint32_t j = 1; j <= CELLS_SPT; j++) kk[j + 1] = s0 + j < hi ? key[s0 + j] : ~kk[j];
+#pragma unroll
+    for (uint32_t j = 0; j < CELLS_SPT; j++) {
+        const uint32_t s = s0 + j;
+        if (s >= hi) break;
+        const uint32_t k = kk[j + 1];
+        if (kk[j] != k) cells[k].x = s;
+        if (kk[j + 2] != k) cells[k].y = s + 1;
+    }
+}
+
 // ---- what the force pass needs of a neighbour j (sph_pairs.hip: k_force) --------------------------------------------
 // cp_j = (spiky/visc) * p_j and w_j = visc * 1/rho_j (v_rcp_f32), so that the pair loop needs w = w_j * (h - r) for the
 // viscosity and (cp_i + cp_j) * w * (h - r) / r for the pressure.  rho = 0 (padding entries) -> weight 0.  Computed ONCE

@@ -54,27 +54,9 @@ __global__ __launch_bounds__(256) void k_cells_clear(const uint32_t* __restrict_
     if (s == lo || key[s - 1] != k) cells[k] = make_uint2(0u, 0u);
 }
 
-// a thread takes FOUR consecutive slots: six key reads for four slots instead of twelve, a quarter of the threads
-// (one slot per thread took 51 us for 16.7 M slots: far from any bandwidth)
-constexpr uint32_t CELLS_SPT = 4;
 __global__ __launch_bounds__(256) void k_cells_build(const uint32_t* __restrict__ key, uint32_t lo, uint32_t hi,
-                                                     uint2* __restrict__ cells, volatile uint32_t* __restrict__ ends_host) {
-    const uint32_t s0 = lo + (blockIdx.x * 256u + threadIdx.x) * CELLS_SPT;
-    if (s0 >= hi) return;
-    if (ends_host && s0 == lo) { ends_host[0] = key[lo]; ends_host[1] = key[hi - 1u]; }    // for the host's block order (block_order)
-    uint32_t kk[CELLS_SPT + 2];                          // key[s0 - 1 .. s0 + 4]
-    kk[1] = key[s0];
-    kk[0] = s0 > lo ? key[s0 - 1] : ~kk[1];
-#pragma unroll
-    for (uint32_t j = 1; j <= CELLS_SPT; j++) kk[j + 1] = s0 + j < hi ? key[s0 + j] : ~kk[j];
-#pragma unroll
-    for (uint32_t j = 0; j < CELLS_SPT; j++) {
-        const uint32_t s = s0 + j;
-        if (s >= hi) break;
-        const uint32_t k = kk[j + 1];
-        if (kk[j] != k) cells[k].x = s;
-        if (kk[j + 2] != k) cells[k].y = s + 1;
-    }
+                                                     uint2* __restrict__ cells, volatile uint32_t* __restrict__ ends_host, uint32_t seq) {
+    cells_build_thread(key, lo, hi, cells, ends_host, seq, blockIdx.x * 256u + threadIdx.x);      // sph_device.hpp
 }
 
 // the same two kernels over TWO slot ranges in one launch (a slab's two ghost ranges, the leavers at both ends)
@@ -140,7 +122,9 @@ int launch_cells_build_range(sph_ctx* c, uint32_t lo, uint32_t hi) {
     if (hi <= lo) return SPH_OK;
     // (the whole owned range: the sort's table build -- also tells the host the first and the last key)
     uint32_t* ends = (lo == c->own_off && hi == c->own_off + c->n) ? c->mm_count_host_dev + 1 : (uint32_t*)nullptr;
-    hipLaunchKernelGGL(k_cells_build, dim3(ceil_div(hi - lo, 256u * CELLS_SPT)), dim3(256), 0, c->stream, c->keyS, lo, hi, c->cells, ends);
+    const uint32_t seq = ends ? c->cells_seq_next : 0u;
+    if (ends) c->cells_seq_next = 0u;
+    hipLaunchKernelGGL(k_cells_build, dim3(cells_build_blocks(hi - lo)), dim3(256), 0, c->stream, c->keyS, lo, hi, c->cells, ends, seq);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
 }

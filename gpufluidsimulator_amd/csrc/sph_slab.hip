@@ -124,11 +124,20 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t* __restrict_
     return lo;
 }
 
+// Round 6: the blocks from `pack_blocks` on build the cell table of the owned slots [own_off, own_off + n) (the sort leaves that
+// to this kernel in a slab step: sph_ctx::owned_cells_in_bounds) -- the build and the bounds / leavers work read the same sorted
+// keys and nobody needs either before the other, so they share one dispatch on every rank's critical path (~5 us).
 __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __restrict__ keys, const float4* __restrict__ posi,
                                                           const float4* __restrict__ velr, uint32_t n, uint32_t own_off,
                                                           uint32_t layer, uint32_t cap, GridDesc g, uint32_t early_cap,
                                                           uint32_t* __restrict__ dl, float4* __restrict__ out_lo,
-                                                          float4* __restrict__ out_hi) {
+                                                          float4* __restrict__ out_hi, uint32_t pack_blocks,
+                                                          const uint32_t* __restrict__ keys_abs, uint2* __restrict__ cells,
+                                                          volatile uint32_t* __restrict__ ends_host) {
+    if (blockIdx.x >= pack_blocks) {                   // (block-uniform; no barrier on this path)
+        cells_build_thread(keys_abs, own_off, own_off + n, cells, ends_host, 0u, (blockIdx.x - pack_blocks) * 256u + threadIdx.x);
+        return;
+    }
     __shared__ uint32_t s_lb[12];
     __shared__ uint32_t s_last;
     const uint32_t zl = g.zl;
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     const uint32_t lb0 = s_lb[0], lb3 = s_lb[3];
     const uint32_t m_lo = lb0, m_hi = n - lb3;
     uint32_t far_l = 0, far_h = 0;                     // per thread (a thread packs several leavers when there are many)
-    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < cap && (k < m_lo || k < m_hi); k += gridDim.x * 256u) {
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < cap && (k < m_lo || k < m_hi); k += pack_blocks * 256u) {
         if (k < m_lo) {
             const float4 p = posi[k];
             out_lo[2 + 2 * k] = p; out_lo[3 + 2 * k] = velr[k];
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     }
     asm volatile("" :: "v"(seen));                                        // keep the returns (and their waits)
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&dl[DL_CTR + 2], 1u) == gridDim.x - 1u ? 1u : 0u;
+    if (threadIdx.x == 0) s_last = atomicAdd(&dl[DL_CTR + 2], 1u) == pack_blocks - 1u ? 1u : 0u;
     __syncthreads();
     if (!s_last || threadIdx.x != 0) return;
     const uint32_t far_lo = atomicExch(&dl[DL_CTR + 0], 0u), far_hi = atomicExch(&dl[DL_CTR + 1], 0u);
@@ -984,15 +993,23 @@ int slab_step_body(sph_slab* s, float dt) {
     rc = slab_check_device_flags(s); if (rc) return rc;
     // ---- hash + sort the owned particles (leavers end up at the two ends of the owned range) -----------------------
     rc = step_hash(c); if (rc) return rc;
-    rc = step_sort(c); if (rc) return rc;
+    c->owned_cells_in_bounds = true;              // the sort leaves the table of the owned slots to the bounds kernel below
+    c->owned_cells_pending = false;
+    rc = step_sort(c);
+    c->owned_cells_in_bounds = false;
+    if (rc) return rc;
     const uint32_t layer = c->grid.g[0] * c->grid.g[1];
     const uint32_t n0 = c->n, off0 = c->own_off;
     const size_t rec = 2 * sizeof(float4);
     // ---- layer bounds, leavers and headers in ONE kernel; the comm stream ships the fixed-size part ------------------
     s->seq++;
-    // a few blocks: every block finds the bounds for itself, the leavers (few, at most mcap) are packed in a grid-stride loop
-    hipLaunchKernelGGL(k_slab_bounds_pack, dim3(min(ceil_div(s->mcap, 256u), 16u)), dim3(256), 0, c->stream, c->keyS + off0, c->posi + off0,
-                       c->velr + off0, n0, off0, layer, s->mcap, c->grid, s->early_cap, s->d_lb, s->mig_send[0], s->mig_send[1]);
+    // a few blocks: every block finds the bounds for itself, the leavers (few, at most mcap) are packed in a grid-stride loop;
+    // behind them the blocks that build the cell table of the owned slots when the sort left it pending (not on a skipped sort)
+    const uint32_t pack_blocks = min(ceil_div(s->mcap, 256u), 16u), build_blocks = c->owned_cells_pending ? cells_build_blocks(n0) : 0u;
+    c->owned_cells_pending = false;
+    hipLaunchKernelGGL(k_slab_bounds_pack, dim3(pack_blocks + build_blocks), dim3(256), 0, c->stream, c->keyS + off0, c->posi + off0,
+                       c->velr + off0, n0, off0, layer, s->mcap, c->grid, s->early_cap, s->d_lb, s->mig_send[0], s->mig_send[1], pack_blocks,
+                       c->keyS, c->cells, c->mm_count_host_dev + 1);
     SPH_HIP(hipGetLastError());
     rc = after_main(s); if (rc) return rc;
     // ---- the density of the deep interior goes into the main stream's queue BEFORE the host waits: its slot range

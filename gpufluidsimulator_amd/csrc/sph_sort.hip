@@ -7,6 +7,9 @@
 // The sort is stable, so the order of particles inside a cell is deterministic.
 #include "sph_device.hpp"
 
+#include <atomic>
+#include <chrono>
+
 namespace sph {
 
 constexpr int SORT_THREADS = 256;            // 4 waves
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(256) void k_mm_mark(const uint32_t* __restrict__ A,
 __global__ __launch_bounds__(1024) void k_mm_tilescan(uint32_t* __restrict__ tile_cnt, uint32_t nt,
                                                       uint32_t* __restrict__ tile_off, uint32_t* __restrict__ m_dev,
                                                       volatile uint32_t* __restrict__ m_host,
-                                                      unsigned long long* __restrict__ m_total) {
+                                                      unsigned long long* __restrict__ m_total, uint32_t seq) {
     __shared__ uint32_t part[1024];
     const uint32_t per = (nt + 1023u) / 1024u;
     const uint32_t lo = min(threadIdx.x * per, nt), hi = min(lo + per, nt);
@@ -1019,16 +1022,42 @@ __global__ __launch_bounds__(1024) void k_mm_tilescan(uint32_t* __restrict__ til
     if (threadIdx.x == 1023) {
         *m_dev = part[1023]; *m_host = part[1023];
         if (m_total) *m_total += part[1023];          // one block: no atomic needed (sph_sort_stats: movers_total)
+        if (seq) { __threadfence_system(); m_host[4] = seq; }     // "the count of scan number seq is in [0]" (launch_sort's skip)
     }
 }
 
-// thread per chunk: movers before the chunk (M64) and the stable list of movers (new key, slot)
+// thread per chunk: movers before the chunk (M64) and the stable list of movers (new key, slot).
+// Where a block's movers start: tile_off[block] when k_mm_tilescan ran (a fluid at rest: the count is wanted at the END of the
+// step, so that a lockstep caller can skip the sort), else -- tile_cnt != null -- every block adds up the per-tile counts in front
+// of it ITSELF (nt <= MM_FUSED_SCAN_TILES words out of the L2: cheaper than the one-block scan kernel it replaces, ~4.5 us per
+// step), block 0 publishes the total, and k_mm_move, the next kernel to run whatever the sort form, re-zeroes the counts.
+constexpr uint32_t MM_FUSED_SCAN_TILES = 2048;       // up to 33.5 M slots; beyond that nt^2 reads would cost more than the scan kernel
 __global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__ mask, uint32_t nchunks, uint32_t n_old,
-                                                    const uint32_t* __restrict__ tile_off,
+                                                    const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ tile_cnt,
+                                                    uint32_t nt, uint32_t* __restrict__ m_dev, volatile uint32_t* __restrict__ m_host,
+                                                    unsigned long long* __restrict__ m_total,
                                                     const uint32_t* __restrict__ A, const uint32_t* __restrict__ B,
                                                     uint32_t* __restrict__ M64, uint32_t* __restrict__ mk,
                                                     uint32_t* __restrict__ mi, uint2* __restrict__ cells) {
     __shared__ uint32_t part[256];
+    uint32_t tile_start;
+    if (tile_cnt) {
+        uint32_t below = 0, all = 0;
+        for (uint32_t t = threadIdx.x; t < nt; t += 256u) { const uint32_t v = tile_cnt[t]; all += v; below += t < blockIdx.x ? v : 0u; }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) { below += (uint32_t)__shfl_xor((int)below, off); all += (uint32_t)__shfl_xor((int)all, off); }
+        if ((threadIdx.x & 63u) == 0u) { part[threadIdx.x >> 6] = below; part[4 + (threadIdx.x >> 6)] = all; }
+        __syncthreads();
+        tile_start = part[0] + part[1] + part[2] + part[3];
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const uint32_t m = part[4] + part[5] + part[6] + part[7];
+            *m_dev = m; *m_host = m;
+            if (m_total) *m_total += m;               // one writer: no atomic needed (sph_sort_stats: movers_total)
+        }
+        __syncthreads();                              // part is reused below
+    } else {
+        tile_start = tile_off[blockIdx.x];
+    }
     const uint32_t chunk = blockIdx.x * MM_TILE_CHUNKS + threadIdx.x;
     uint64_t m = chunk < nchunks ? mask[chunk] : 0ull;
     const uint32_t cnt = (uint32_t)__popcll(m);
@@ -1041,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__
         __syncthreads();
     }
     if (chunk >= nchunks) return;
-    uint32_t at = tile_off[blockIdx.x] + part[threadIdx.x] - cnt;
+    uint32_t at = tile_start + part[threadIdx.x] - cnt;
     M64[chunk] = at;
     while (m) {
         const uint32_t i = chunk * 64u + (uint32_t)__builtin_ctzll(m);
@@ -1177,7 +1206,8 @@ __device__ __forceinline__ void mm_place_body(uint32_t bid, uint32_t nblocks, co
 // ONE launch moves everybody: the first `place_blocks` blocks place the movers (few, latency-bound: dependent
 // searches), the others stream the non-movers -- the two read the same old arrays and write disjoint slots of the new
 // ones, so the movers' placement hides behind the stream instead of running in front of it (26 us at C3).
-__global__ __launch_bounds__(256) void k_mm_move(uint32_t place_blocks, const uint32_t* __restrict__ A, uint32_t n,
+__global__ __launch_bounds__(256) void k_mm_move(uint32_t place_blocks, uint32_t* __restrict__ zero_cnt, uint32_t zero_n,
+                                                 const uint32_t* __restrict__ A, uint32_t n,
                                                  uint32_t nchunks, const uint64_t* __restrict__ mask,
                                                  const uint32_t* __restrict__ M64, const uint32_t* __restrict__ mk,
                                                  const uint32_t* __restrict__ mi, const uint32_t* __restrict__ m_dev,
@@ -1186,6 +1216,8 @@ __global__ __launch_bounds__(256) void k_mm_move(uint32_t place_blocks, const ui
                                                  const float4* __restrict__ posi, const float4* __restrict__ velr,
                                                  float4* __restrict__ posi_out, float4* __restrict__ velr_out,
                                                  uint32_t* __restrict__ key_out, uint32_t* __restrict__ perm_out, Front front) {
+    // the per-tile mover counts k_mm_compact added up itself (every block of it has read them: it ran in front of this kernel)
+    if (zero_cnt && blockIdx.x * 256u + threadIdx.x < zero_n) zero_cnt[blockIdx.x * 256u + threadIdx.x] = 0u;
     if (blockIdx.x < place_blocks)
         mm_place_body(blockIdx.x, place_blocks, A, n, nchunks, mask, M64, mk, mi, m_dev, tileA, cells, slot_base, posi, velr,
                       posi_out, velr_out, key_out, perm_out, front);
@@ -1206,22 +1238,26 @@ static uint32_t merge_grid_for(uint32_t movers_hint, uint32_t n) {
 // `counted`: the movers belong to a sort (they add to the running total), not to marks being dropped
 static void mm_tilescan(sph_ctx* c, uint32_t n, bool counted) {
     const uint32_t nt = ceil_div(ceil_div(n, 64u), MM_TILE_CHUNKS);
+    // `counted`: the kernel echoes the scan's number behind the count, so that launch_sort can tell "the count of the CURRENT
+    // marks is there" by looking at two words of mapped host memory (no event: see sph_ctx::scan_seq_issued)
+    uint32_t seq = 0u;
+    if (counted) { if (++c->scan_seq_issued == 0u) c->scan_seq_issued = 1u; seq = c->scan_seq_issued; }     // (never 0: that is "no echo")
     hipLaunchKernelGGL(k_mm_tilescan, dim3(1), dim3(1024), 0, c->stream, c->mm_tile_cnt, nt, c->mm_tile_off, c->mm_count,
-                       c->mm_count_host_dev, counted ? c->mm_total : (unsigned long long*)nullptr);
+                       c->mm_count_host_dev, counted ? c->mm_total : (unsigned long long*)nullptr, seq);
+    c->mm_counted_valid = counted;
 }
 
-// Called right after the integrate epilogue has marked the movers: count them at the END of the step, so that
-// the next sort finds the number ready (a caller in lockstep with the device can then skip a sort that has
-// nothing to do without ever waiting for the device).
-static void mm_record_counted(sph_ctx* c) {
-    c->mm_counted_valid = !c->host_paced || *c->mm_count_host == 0u;
-    if (c->mm_counted_valid) hipEventRecord(c->mm_counted, c->stream);
-}
+static uint32_t mm_tiles(uint32_t n) { return ceil_div(ceil_div(n, 64u), MM_TILE_CHUNKS); }
 
+// Called right after the integrate epilogue has marked the movers.  While the fluid is AT REST (the last count the device
+// reported is 0) they are counted at the END of the step, so that the next sort finds the number ready: a caller in lockstep
+// with the device can then skip a sort that has nothing to do without ever waiting for the device.  Once particles change
+// cell no sort is skipped, and the count is left to the sort itself (k_mm_compact adds the per-tile counts up: one dispatch
+// less per step, ~4.5 us); a range of more than MM_FUSED_SCAN_TILES tiles keeps the scan kernel.
 void mm_scan_marks(sph_ctx* c) {
     if (!c->mm_marked || c->mm_scanned) return;
+    if (*c->mm_count_host != 0u && mm_tiles(c->mm_marked_n) <= MM_FUSED_SCAN_TILES) return;     // the sort will count them
     mm_tilescan(c, c->mm_marked_n, true);
-    mm_record_counted(c);
     c->mm_scanned = true;
 }
 
@@ -1233,20 +1269,23 @@ void mm_drop_marks(sph_ctx* c) {
     c->mm_scanned = false;
 }
 
-// step 1 of the merge: the movers are marked (by the integrate epilogue, or here) and counted
-static void launch_merge_count(sph_ctx* c, uint32_t n) {
+// step 1 of the merge: the movers are marked (by the integrate epilogue, or here) and counted -- by the scan kernel, or, when
+// this returns true, by k_mm_compact itself (launch_sort_merge: `count_in_compact`)
+static bool launch_merge_count(sph_ctx* c, uint32_t n) {
     if (c->mm_marked && !(c->mm_marked_off == c->own_off && c->mm_marked_n == n)) mm_drop_marks(c);   // another range
     if (!c->mm_marked) {                         // else: the fused integrate epilogue compared the keys already
         hipLaunchKernelGGL(k_mm_mark, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, c->keyS + c->own_off, c->k0, n,
                            c->mm_mask, c->mm_tile_cnt);
         c->mm_scanned = false;
     }
+    bool in_compact = false;
     if (!c->mm_scanned) {
-        mm_tilescan(c, n, true);
-        mm_record_counted(c);
+        if (mm_tiles(n) <= MM_FUSED_SCAN_TILES) { in_compact = true; c->mm_counted_valid = false; }
+        else mm_tilescan(c, n, true);
     }
     c->mm_marked = false;
     c->mm_scanned = false;
+    return in_compact;
 }
 
 // every slot from n_old on is a mover, none below (particles appended behind a sorted range)
@@ -1267,12 +1306,14 @@ __global__ __launch_bounds__(256) void k_mm_mark_tail(uint32_t n_old, uint32_t n
 // The merged order, written straight into posi2 / velr2 / keyS2 at the canonical offset gcap.  Slots [0, n) carry
 // an old key (A) and a new one (B); slots [n, n_tot) -- particles that arrived from a neighbouring slab -- only a
 // new one, and all of them are movers.
-static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_live, uint32_t hint, Front front = Front{0u, 0u}) {
+static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_live, uint32_t hint, Front front = Front{0u, 0u},
+                             bool count_in_compact = false) {
     const uint32_t* A = c->keyS + c->own_off;
     const uint32_t* B = c->k0;
     const uint32_t nchunks = ceil_div(n_tot, 64u), nt = ceil_div(nchunks, MM_TILE_CHUNKS);
     uint32_t* mk = c->mm_k0; uint32_t* mi = c->v0; uint32_t* mk2 = c->mm_k1; uint32_t* mi2 = c->mm_v1;
-    hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, n, c->mm_tile_off, A, B,
+    hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, n, c->mm_tile_off,
+                       count_in_compact ? c->mm_tile_cnt : (const uint32_t*)nullptr, nt, c->mm_count, c->mm_count_host_dev, c->mm_total, A, B,
                        c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr);
     SPH_HIP(hipGetLastError());
     SmallTail tail;
@@ -1291,11 +1332,33 @@ static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_
     float4* po = c->posi2 + c->gcap; float4* vo = c->velr2 + c->gcap; uint32_t* ko = c->keyS2 + c->gcap;
     // generous grid for the movers (grid-stride loop over the device-side count): a burst is not left to a handful of blocks
     const uint32_t place_blocks = min(max(ceil_div(2u * hint + 1u, 256u) + 15u, 512u), 65535u);
-    hipLaunchKernelGGL(k_mm_move, dim3(place_blocks + ceil_div(n, 256)), dim3(256), 0, c->stream, place_blocks, A, n, nchunks,
+    hipLaunchKernelGGL(k_mm_move, dim3(place_blocks + ceil_div(n, 256)), dim3(256), 0, c->stream, place_blocks,
+                       count_in_compact ? c->mm_tile_cnt : (uint32_t*)nullptr, nt, A, n, nchunks,
                        c->mm_mask, c->mm_M64, mk, mi, c->mm_count, c->mm_tileL, c->mm_tileA,
                        table_live ? c->cells : (const uint2*)nullptr, c->own_off, ps, vs, po, vo, ko, perm, front);
     SPH_HIP(hipGetLastError());
     c->last_perm = perm;
+    return SPH_OK;
+}
+
+// The mover count the host reads is whatever the device last reported: a caller that queues many steps without
+// synchronising would decide all of them on one stale value, so the host never runs more than four sorts ahead of the
+// device (the queue stays several steps deep: the device never waits).  The device's progress is the sort number the table
+// build echoes into mapped host memory (rounds 1-5: a ring of four events, each ~5.5 us of device idle at the next dispatch).
+static int sort_throttle(sph_ctx* c) {
+    volatile const uint32_t* hw = c->mm_count_host;
+    if ((int32_t)(c->sort_seq_issued - hw[3]) < 4) return SPH_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 1; (int32_t)(c->sort_seq_issued - hw[3]) >= 4; spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFu) == 0u) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) break;                            // nothing queued any more (the echo of a build that never ran: upload, re-cut)
+            if (q != hipErrorNotReady) SPH_HIP(q);                 // a device fault shows up here, not in the mapped word
+            SPH_REQUIRE(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 300.0, SPH_E_DEVICE,
+                        "sort: the device has not reached the table build of sort %u after 300 s", c->sort_seq_issued - 3u);
+        }
+    }
     return SPH_OK;
 }
 
@@ -1310,8 +1373,7 @@ int launch_sort(sph_ctx* c) {
     // The mover count the host reads below is whatever the device last reported.  A caller that queues many
     // steps without synchronising would decide all of them on one stale value, so the host never runs more
     // than four sorts ahead of the device (the queue stays several steps deep: the device never waits).
-    const uint32_t ring = (uint32_t)(c->sort_calls & 3u);
-    if (c->sort_merge && !c->host_paced && c->sort_calls >= 4) SPH_HIP(hipEventSynchronize(c->mm_done[ring]));
+    if (c->sort_merge && !c->host_paced) { const int rc = sort_throttle(c); if (rc) return rc; }
     c->sort_calls++;
     c->last_sort_skipped = false;
     const bool can_merge = c->sort_merge && c->order_valid;
@@ -1321,8 +1383,8 @@ int launch_sort(sph_ctx* c) {
     c->cells_clear_deferred = false;
     if (can_merge && (*c->mm_count_host <= n / 8u || c->sort_merge_always)) {
         const bool was_still = *c->mm_count_host == 0u;
-        launch_merge_count(c, n);
-        if (was_still && table_live && c->own_off == c->gcap) {
+        const bool count_in_compact = launch_merge_count(c, n);
+        if (was_still && table_live && c->own_off == c->gcap && !count_in_compact) {
             // Nothing moved last time (a fluid at rest: no particle crosses a cell face for many steps).  If that
             // is still so, the order, the keys and the cell table are already those of this step and the whole
             // sort -- 0.25 ms of copying at C3 -- can be left out.  Only the device knows, and the host does not
@@ -1330,17 +1392,17 @@ int launch_sort(sph_ctx* c) {
             // end of the previous step, so a caller in lockstep with the device -- one update() per frame --
             // finds it); a host that runs ahead of the device queues the merge, which does the same job for 0
             // movers.  sph_step stays asynchronous.
-            if (c->mm_counted_valid && hipEventQuery(c->mm_counted) == hipSuccess && *c->mm_count_host == 0u) {
+            volatile const uint32_t* hw = c->mm_count_host;
+            if (c->mm_counted_valid && hw[4] == c->scan_seq_issued && (std::atomic_thread_fence(std::memory_order_acquire), hw[0] == 0u)) {
                 c->sort_merges++;
                 c->sort_skips++;
                 c->last_sort_skipped = true;
-                if (!c->host_paced) SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
                 c->last_perm = nullptr;            // identity
                 c->order_valid = true;             // cells_valid / cells_lo / cells_hi: unchanged and still true
                 return SPH_OK;
             }
         }
-        int rc = launch_sort_merge(c, n, n, table_live, *c->mm_count_host);   // hint: whatever step last reported
+        int rc = launch_sort_merge(c, n, n, table_live, *c->mm_count_host, Front{0u, 0u}, count_in_compact);   // hint: whatever step last reported
         if (rc) return rc;
         c->sort_merges++;
         if (c->cells_valid && !table_live) {       // a table nobody cleared (e.g. sph_sort without sph_hash): start clean
@@ -1383,9 +1445,15 @@ int launch_sort(sph_ctx* c) {
     // A slab context adds the cells of its ghost layers later (launch_cells_build), and drops those of the
     // particles that leave (sph_migrants_pack).
     c->cells_valid = false;
-    int rc = launch_cells_build_range(c, c->gcap, c->gcap + n);
-    if (rc) return rc;
-    if (c->sort_merge && !c->host_paced) SPH_HIP(hipEventRecord(c->mm_done[ring], c->stream));
+    if (++c->sort_seq_issued == 0u) c->sort_seq_issued = 1u;       // the table build echoes the sort's number (sort_throttle)
+    c->cells_seq_next = c->sort_seq_issued;
+    if (c->owned_cells_in_bounds) {
+        c->owned_cells_pending = true;             // the slab step's bounds kernel, queued next, builds it (sph_slab.hip)
+        c->cells_seq_next = 0u;
+    } else {
+        int rc = launch_cells_build_range(c, c->gcap, c->gcap + n);
+        if (rc) return rc;
+    }
     c->order_valid = true;
     c->cells_lo = c->gcap; c->cells_hi = c->gcap + n; c->cells_valid = true;
     return SPH_OK;
@@ -1408,7 +1476,8 @@ int launch_merge_arrivals(sph_ctx* c, uint32_t n_in, uint32_t n_front) {
                        c->mm_tile_cnt);
     const uint32_t nt = ceil_div(nchunks, MM_TILE_CHUNKS);
     hipLaunchKernelGGL(k_mm_tilescan, dim3(1), dim3(1024), 0, c->stream, c->mm_tile_cnt, nt, c->mm_tile_off, c->mm_count,
-                       c->mm_count_host_dev, (unsigned long long*)nullptr);
+                       c->mm_count_host_dev, (unsigned long long*)nullptr, 0u);
+    c->mm_counted_valid = false;
     SPH_HIP(hipGetLastError());
     int rc = launch_sort_merge(c, n, n_tot, true, n_in, Front{n, n_front < n_in ? n_front : n_in});
     if (rc) return rc;
