@@ -55,6 +55,10 @@ SIGNATURES = {
     "sph_grid_dim_for_edge": (_U32, [C.c_float, C.c_float]),
     "sph_create": (C.c_int, [C.POINTER(_P), C.c_int, _U32, C.POINTER(Params)]),
     "sph_create_slab": (C.c_int, [C.POINTER(_P), C.c_int, _U32, C.POINTER(Params), _U32, _U32, _U32]),
+    "sph_create_slab_layers": (C.c_int, [C.POINTER(_P), C.c_int, _U32, C.POINTER(Params), _U32, _U32, _U32, _U32]),
+    "sph_ghost_layers": (_U32, [_P]),
+    "sph_slab_set_protocol": (C.c_int, [_P, C.c_int]),
+    "sph_slab_protocol": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "sph_destroy": (None, [_P]),
     "sph_set_stream": (C.c_int, [_P, _P]),
     "sph_set_params": (C.c_int, [_P, C.POINTER(Params)]),
@@ -229,15 +233,15 @@ class Context:
     """One `sph_ctx`: the device state of a particle system (or of one z-slab of it)."""
 
     def __init__(self, capacity, box=None, grid=None, params: Params | None = None, device=0,
-                 slab=None, ghost_capacity=0):
+                 slab=None, ghost_capacity=0, ghost_layers=1):
         self.L = load()
         self.params = params if params is not None else default_params(box, grid)
         h = _P()
         if slab is None:
             _check(self.L.sph_create(C.byref(h), device, int(capacity), C.byref(self.params)))
-        else:
-            _check(self.L.sph_create_slab(C.byref(h), device, int(capacity), C.byref(self.params),
-                                          int(slab[0]), int(slab[1]), int(ghost_capacity)))
+        else:       # ghost_layers = 2: what the one-message slab step needs (sph_slab_set_protocol)
+            _check(self.L.sph_create_slab_layers(C.byref(h), device, int(capacity), C.byref(self.params),
+                                                 int(slab[0]), int(slab[1]), int(ghost_capacity), int(ghost_layers)))
         self.h = h
         self.capacity = int(capacity)
         self.index_base = 0

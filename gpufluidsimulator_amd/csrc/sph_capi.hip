@@ -54,8 +54,10 @@ static int derive(sph_ctx* c, const sph_params* p, uint32_t z_lo, uint32_t z_hi,
         g.gf[a] = (float)p->grid[a];
     }
     c->z_lo = z_lo; c->z_hi = z_hi;
-    g.z_off = slab ? (int32_t)z_lo - 1 : 0;
-    g.zl = slab ? z_hi - z_lo + 2 : p->grid[2];
+    const uint32_t G = c->ghost_layers;
+    SPH_REQUIRE(G == 1u || G == 2u, SPH_E_INVALID, "a slab keeps 1 or 2 ghost layers per side, not %u", G);
+    g.z_off = slab ? (int32_t)z_lo - (int32_t)G : 0;
+    g.zl = slab ? z_hi - z_lo + 2u * G : p->grid[2];
     SPH_REQUIRE(slab || (z_lo == 0 && z_hi == p->grid[2]), SPH_E_INVALID, "a whole-domain context owns every layer");
     uint64_t nc = (uint64_t)g.g[0] * g.g[1] * g.zl;
     SPH_REQUIRE(nc < (1ull << 32), SPH_E_INVALID, "cell table too large (%llu cells)", (unsigned long long)nc);
@@ -118,7 +120,7 @@ static void free_all(sph_ctx* c) {
 }
 
 static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_params* p, uint32_t z_lo, uint32_t z_hi,
-                       uint32_t gcap, bool slab) {
+                       uint32_t gcap, bool slab, uint32_t ghost_layers = 1) {
     SPH_REQUIRE(out && p, SPH_E_INVALID, "null argument");
     *out = nullptr;
     SPH_REQUIRE(capacity > 0 && (uint64_t)capacity + 2ull * gcap < (1ull << 31), SPH_E_INVALID, "bad capacity");
@@ -140,6 +142,7 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
     sph_ctx* c = new (std::nothrow) sph_ctx();
     SPH_REQUIRE(c, SPH_E_NOMEM, "out of host memory");
     c->device = device;
+    c->ghost_layers = slab ? ghost_layers : 1u;
     int rc = derive(c, p, z_lo, z_hi, slab);
     if (rc) { delete c; return rc; }
     c->cap = capacity; c->gcap = gcap; c->tot = capacity + 2 * gcap; c->slab = slab;
@@ -335,6 +338,7 @@ int set_slab_range(sph_ctx* c, uint32_t z_lo, uint32_t z_hi) {
     SPH_REQUIRE(c && c->slab, SPH_E_INVALID, "set_slab_range needs a slab context");
     sph_ctx tmp;
     tmp.params = c->params;
+    tmp.ghost_layers = c->ghost_layers;
     int rc = derive(&tmp, &c->params, z_lo, z_hi, true);
     if (rc) return rc;
     if (tmp.grid.ncells > c->cells_alloc) {
@@ -457,6 +461,15 @@ int sph_create_slab(sph_ctx** out, int device, uint32_t capacity, const sph_para
     return create_impl(out, device, capacity, p, z_lo, z_hi, ghost_capacity, true);
 }
 
+int sph_create_slab_layers(sph_ctx** out, int device, uint32_t capacity, const sph_params* p, uint32_t z_lo, uint32_t z_hi,
+                           uint32_t ghost_capacity, uint32_t ghost_layers) {
+    if (!p) { set_error("null params"); return SPH_E_INVALID; }
+    if (ghost_layers != 1u && ghost_layers != 2u) { set_error("a slab keeps 1 or 2 ghost layers per side, not %u", ghost_layers); return SPH_E_INVALID; }
+    return create_impl(out, device, capacity, p, z_lo, z_hi, ghost_capacity, true, ghost_layers);
+}
+
+uint32_t sph_ghost_layers(const sph_ctx* c) { return c ? (c->slab ? c->ghost_layers : 0u) : 0u; }
+
 void sph_destroy(sph_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
@@ -478,6 +491,7 @@ int sph_set_params(sph_ctx* c, const sph_params* p) {
         SPH_REQUIRE(p->grid[a] == c->params.grid[a], SPH_E_INVALID, "the grid cannot change after sph_create");
     sph_ctx tmp;   // validate first
     tmp.params = c->params;
+    tmp.ghost_layers = c->ghost_layers;
     int rc = derive(&tmp, p, c->z_lo, c->z_hi, c->slab);
     if (rc) return rc;
     c->params = tmp.params; c->grid = tmp.grid; c->phys = tmp.phys;

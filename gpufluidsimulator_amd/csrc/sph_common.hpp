@@ -28,8 +28,8 @@ struct GridDesc {
     float inv_dims[3];     // 1 / box_dims where that is a power of two (the division is then an exact scaling), else 0
     uint32_t g[3];         // global cells per axis
     float gf[3];           // (float)g
-    int32_t z_off;         // local z layer = global z layer - z_off (slab: z_lo - 1; whole domain: 0)
-    uint32_t zl;           // local z layers (slab: owned + 2 ghost layers; whole domain: g[2])
+    int32_t z_off;         // local z layer = global z layer - z_off (slab: z_lo - ghost layers; whole domain: 0)
+    uint32_t zl;           // local z layers (slab: owned + 2 x ghost layers; whole domain: g[2])
     uint32_t ncells;       // g[0]*g[1]*zl
 };
 
@@ -64,6 +64,10 @@ struct sph_ctx {
     uint32_t tot = 0;        // gcap + cap + gcap
     bool slab = false;
     uint32_t z_lo = 0, z_hi = 0;   // owned global cell layers
+    // ghost cell layers a slab context keeps on either side of its owned layers: 1 (the three-message step: the neighbours'
+    // boundary layers, whose densities arrive in a message of their own) or 2 (the one-message step: two layers of the
+    // neighbour's particles, the densities of the inner one recomputed here) -- sph_create_slab_layers
+    uint32_t ghost_layers = 1;
 
     // counts
     uint32_t n = 0;          // owned particles

@@ -87,7 +87,8 @@ int sph_migrants_count(sph_ctx* c, uint32_t count[2]) {
     SPH_REQUIRE(c && count, SPH_E_INVALID, "null argument");
     SPH_REQUIRE(c->stage == sph_ctx::ST_SORTED, SPH_E_STATE, "sph_migrants_count needs sph_sort first");
     const uint32_t layer = c->grid.g[0] * c->grid.g[1];
-    uint32_t tg[2] = {layer, (c->grid.zl - 1) * layer}, lb[2];
+    const uint32_t G = c->ghost_layers;
+    uint32_t tg[2] = {G * layer, (c->grid.zl - G) * layer}, lb[2];
     int rc = lower_bounds(c, tg, 2, lb);
     if (rc) return rc;
     count[0] = lb[0];
@@ -99,7 +100,8 @@ int sph_slab_counts(sph_ctx* c, uint32_t count[4]) {
     SPH_REQUIRE(c && count, SPH_E_INVALID, "null argument");
     SPH_REQUIRE(c->stage == sph_ctx::ST_SORTED, SPH_E_STATE, "sph_slab_counts needs sph_sort first");
     const uint32_t layer = c->grid.g[0] * c->grid.g[1];
-    uint32_t tg[4] = {layer, 2 * layer, (c->grid.zl - 2) * layer, (c->grid.zl - 1) * layer}, lb[4];
+    const uint32_t G = c->ghost_layers;
+    uint32_t tg[4] = {G * layer, (G + 1) * layer, (c->grid.zl - G - 1) * layer, (c->grid.zl - G) * layer}, lb[4];
     int rc = lower_bounds(c, tg, 4, lb);
     if (rc) return rc;
     count[0] = lb[0];
@@ -153,7 +155,8 @@ int sph_halo_count(sph_ctx* c, uint32_t count[2]) {
     SPH_REQUIRE(c && count, SPH_E_INVALID, "null argument");
     SPH_REQUIRE(c->stage >= sph_ctx::ST_SORTED, SPH_E_STATE, "sph_halo_count needs sph_sort first");
     const uint32_t layer = c->grid.g[0] * c->grid.g[1];
-    uint32_t tg[2] = {2 * layer, (c->grid.zl - 2) * layer}, lb[2];
+    const uint32_t G = c->ghost_layers;
+    uint32_t tg[2] = {(G + 1) * layer, (c->grid.zl - G - 1) * layer}, lb[2];
     int rc = lower_bounds(c, tg, 2, lb);
     if (rc) return rc;
     count[0] = lb[0];

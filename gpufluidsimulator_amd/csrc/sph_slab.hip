@@ -71,22 +71,25 @@ enum {
     HL_NEAR = 20,     // [20..21] first slot of local layer 3 / of local layer zl-3 (ABSOLUTE): the layers next to the deep interior
     HL_EARLY = 22,    // [22..23] the slots whose force pass may run in front of the wait: local layers [6, zl-6) (ABSOLUTE; empty: equal)
     HL_RECUT = 24,    // [24..25] sph_slab_recut: particles that go down / up ; [26..27] what the neighbours send (from below, from above)
-    HL_WORDS = 32
+    HL_HDR2_LO = 32,  // [32..35] second header word group from the lower neighbour {#its second layer, #very far leavers, 0, 0}
+    HL_HDR2_HI = 36,  // [36..39] ... from the upper neighbour
+    HL_VFAR = 40,     // [40..41] my leavers (down, up) that are not even in the neighbour's SECOND layer (crossed > 2 layers)
+    HL_WORDS = 48
 };
 enum { SLAB_ERR_INSERT_LAYER = 0, SLAB_ERR_ARRIVAL_OUTSIDE = 1 };
 // device words (sph_slab::d_lb): [0..3] bounds, [4..5] deep range (absolute), [6..7] far counts, [8..10] the
 // fused kernel's block counters {far down, far up, blocks done}
-enum { DL_DEEP = 4, DL_FAR = 6, DL_CTR = 8, DL_NEAR = 12, DL_PING = 14, DL_EARLY = 16, DL_WORDS = 24 };
+enum { DL_DEEP = 4, DL_FAR = 6, DL_CTR = 8, DL_NEAR = 12, DL_PING = 14, DL_EARLY = 16, DL_VFAR = 18, DL_CTR2 = 20, DL_WORDS = 24 };
 
 constexpr uint32_t MIG_INLINE = 255;   // leavers per side that ride in the first (fixed-size, 8 KB) migrant message
 
 // slot of the first key >= target, for 4 targets (one thread each): the layer bounds of the owned range (used
 // after the rare pass over all particles that takes in far arrivals)
-__global__ void k_slab_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t layer, uint32_t zl,
+__global__ void k_slab_bounds(const uint32_t* __restrict__ keys, uint32_t n, uint32_t layer, uint32_t zl, uint32_t G,
                               uint32_t* __restrict__ out, volatile uint32_t* __restrict__ out_host) {
     const uint32_t t = threadIdx.x;
     if (t >= 4) return;
-    const uint32_t targets[4] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer};
+    const uint32_t targets[4] = {G * layer, (G + 1u) * layer, (zl - G - 1u) * layer, (zl - G) * layer};      // G ghost layers per side
     uint32_t v = targets[t], lo = 0, hi = n;
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
                                                           uint32_t* __restrict__ dl, float4* __restrict__ out_lo,
                                                           float4* __restrict__ out_hi, uint32_t pack_blocks,
                                                           const uint32_t* __restrict__ keys_abs, uint2* __restrict__ cells,
-                                                          volatile uint32_t* __restrict__ ends_host) {
+                                                          volatile uint32_t* __restrict__ ends_host, uint32_t G, uint32_t two_layers,
+                                                          uint32_t cap2) {
     if (blockIdx.x >= pack_blocks) {                   // (block-uniform; no barrier on this path)
         cells_build_thread(keys_abs, own_off, own_off + n, cells, ends_host, 0u, (blockIdx.x - pack_blocks) * 256u + threadIdx.x);
         return;
@@ -147,14 +151,16 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
         // layer, the ghosts beyond it); the third lets the boundary layers' force launch -- which, rounded to whole
         // 64-slot chunks, reaches into the second layer and so reads densities of the third -- run on the comm stream
         // without waiting for the deep launch (the host checks that it really stays inside: targets 6 and 7)
-        const uint32_t d0 = min(4u, zl - 1u), d1 = zl >= 8u ? zl - 4u : d0;
-        const uint32_t e0 = min(3u, zl - 1u), e1 = zl >= 6u ? zl - 3u : e0;
+        // (G = ghost layers per side: the owned layers are the local layers [G, zl - G); "layer k" in these comments counts from
+        // the first owned layer = 1, as with one ghost layer)
+        const uint32_t d0 = min(G + 3u, zl - 1u), d1 = zl >= 2u * G + 6u ? zl - G - 3u : d0;
+        const uint32_t e0 = min(G + 2u, zl - 1u), e1 = zl >= 2u * G + 4u ? zl - G - 2u : e0;
         // [8..10]: the EARLY force range, local layers [6, zl-6) -- particles whose 27 cells lie in layers 5 .. zl-6, all of
         // whose densities the deep launch (layers >= 4, from a chunk boundary inside layer 4) has written: their force pass
         // needs nothing that comes over a link or moves before it.  [10] = first slot of layer 5, to check exactly that.
-        const uint32_t f0 = min(6u, zl - 1u), f1 = zl >= 13u ? zl - 6u : f0;
-        const uint32_t targets[11] = {layer, 2u * layer, (zl - 2u) * layer, (zl - 1u) * layer, d0 * layer, max(d1, d0) * layer,
-                                      e0 * layer, max(e1, e0) * layer, f0 * layer, max(f1, f0) * layer, min(5u, zl - 1u) * layer};
+        const uint32_t f0 = min(G + 5u, zl - 1u), f1 = zl >= 2u * G + 11u ? zl - G - 5u : f0;
+        const uint32_t targets[11] = {G * layer, (G + 1u) * layer, (zl - G - 1u) * layer, (zl - G) * layer, d0 * layer, max(d1, d0) * layer,
+                                      e0 * layer, max(e1, e0) * layer, f0 * layer, max(f1, f0) * layer, min(G + 4u, zl - 1u) * layer};
         const uint32_t wave = threadIdx.x >> 6;
         for (uint32_t t = wave; t < 11u; t += 4u) {                         // wave w: targets w, w + 4, w + 8
             const uint32_t r = wave_lower_bound(keys, n, targets[t]);
@@ -165,16 +171,35 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     const uint32_t lb0 = s_lb[0], lb3 = s_lb[3];
     const uint32_t m_lo = lb0, m_hi = n - lb3;
     uint32_t far_l = 0, far_h = 0;                     // per thread (a thread packs several leavers when there are many)
+    uint32_t vfar = 0;                                 // leavers of either side beyond the neighbour's SECOND layer
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < cap && (k < m_lo || k < m_hi); k += pack_blocks * 256u) {
         if (k < m_lo) {
             const float4 p = posi[k];
             out_lo[2 + 2 * k] = p; out_lo[3 + 2 * k] = velr[k];
-            far_l += (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]) != g.z_off ? 1u : 0u;              // global layer z_lo - 1
+            const int lz = (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]);
+            far_l += lz != g.z_off + (int)G - 1 ? 1u : 0u;    // not global layer z_lo - 1
+            vfar += lz < g.z_off + (int)G - 2 ? 1u : 0u;
         }
         if (k < m_hi) {
             const float4 p = posi[lb3 + k];
             out_hi[2 + 2 * k] = p; out_hi[3 + 2 * k] = velr[lb3 + k];
-            far_h += (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]) != g.z_off + (int)zl - 1 ? 1u : 0u;   // global layer z_hi
+            const int lz = (int)cell_coord(p.z, g.box_min[2], g.box_dims[2], g.gf[2], g.g[2]);
+            far_h += lz != g.z_off + (int)zl - (int)G ? 1u : 0u;   // not global layer z_hi
+            vfar += lz > g.z_off + (int)zl - (int)G + 1 ? 1u : 0u;
+        }
+    }
+    if (two_layers) {
+        // The ONE-MESSAGE step: behind the leavers of a side go the RESIDENTS of the two owned layers next to that cut, in slot
+        // order -- [first layer | second layer] towards the lower neighbour, [second-last | last] towards the upper one: for the
+        // receiver both are two of ITS ghost layers in ascending key order.  Slices that have been final since the sort: the
+        // receiver merges its own leavers in (k_slab_unpack_ghosts_merge), so nothing waits for this rank's arrivals.
+        const uint32_t r_lo0 = lb0, r_lo1 = max(s_lb[6], lb0), r_hi0 = min(s_lb[7], lb3), r_hi1 = lb3;
+        const uint32_t n_rl = min(r_lo1 - r_lo0, cap2), n_rh = min(r_hi1 - r_hi0, cap2);
+        float4* const dl_ = out_lo + 2u * (1u + min(m_lo, cap));
+        float4* const dh_ = out_hi + 2u * (1u + min(m_hi, cap));
+        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n_rl + n_rh; k += pack_blocks * 256u) {
+            if (k < n_rl) { dl_[2 * k] = posi[r_lo0 + k]; dl_[2 * k + 1] = velr[r_lo0 + k]; }
+            else { const uint32_t j = k - n_rl; dh_[2 * j] = posi[r_hi0 + j]; dh_[2 * j + 1] = velr[r_hi0 + j]; }
         }
     }
     // far counts and the "last block" ticket: RETURNING device-scope atomics (performed at the memory side; the
@@ -183,6 +208,7 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     if (__ballot(far_l | far_h) != 0ull) {            // rare: somebody crossed more than one layer
         if (far_l) seen += atomicAdd(&dl[DL_CTR + 0], far_l);
         if (far_h) seen += atomicAdd(&dl[DL_CTR + 1], far_h);
+        if (vfar) seen += atomicAdd(&dl[DL_CTR2], vfar);
     }
     asm volatile("" :: "v"(seen));                                        // keep the returns (and their waits)
     __syncthreads();
@@ -190,11 +216,15 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
     __syncthreads();
     if (!s_last || threadIdx.x != 0) return;
     const uint32_t far_lo = atomicExch(&dl[DL_CTR + 0], 0u), far_hi = atomicExch(&dl[DL_CTR + 1], 0u);
+    const uint32_t vfar_all = atomicExch(&dl[DL_CTR2], 0u);                            // (either side: any of them fails the one-message step)
     atomicExch(&dl[DL_CTR + 2], 0u);                                                   // re-armed for the next step
+    // header, 8 words: {#leavers, #my boundary layer on that side, #far leavers, abort} {#my SECOND layer on that side, #very far, 0, 0}
+    const uint32_t n2_lo = max(s_lb[6], s_lb[1]) - s_lb[1], n2_hi = s_lb[2] - min(s_lb[7], s_lb[2]);
     out_lo[0] = make_float4(__uint_as_float(m_lo), __uint_as_float(s_lb[1] - lb0), __uint_as_float(far_lo), 0.f);
-    out_lo[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    out_lo[1] = make_float4(__uint_as_float(n2_lo), __uint_as_float(vfar_all), 0.f, 0.f);
     out_hi[0] = make_float4(__uint_as_float(m_hi), __uint_as_float(lb3 - s_lb[2]), __uint_as_float(far_hi), 0.f);
-    out_hi[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    out_hi[1] = make_float4(__uint_as_float(n2_hi), __uint_as_float(vfar_all), 0.f, 0.f);
+    dl[DL_VFAR] = vfar_all; dl[DL_VFAR + 1] = vfar_all;
     for (int t = 0; t < 4; t++) dl[t] = s_lb[t];
     // the deep range starts on a 64-slot chunk of what will be the owned range once the lower leavers are gone (the usual
     // step: no arrivals): the launch over "everything that is not deep" cuts its hole on whole waves from there
@@ -212,7 +242,7 @@ __global__ __launch_bounds__(256) void k_slab_bounds_pack(const uint32_t* __rest
         // 64, and the launch over "everything that is not deep" then re-rounds the hole's start -- it recomputes up to 63
         // slots at the head of the deep range on ANOTHER stream.  Same bits in fp32, but in mixed precision a density depends on
         // which particles share a wave: no slot the early launch reads -- layer 5 onwards -- may lie in that head.)
-        const bool ok = zl >= 13u && s_lb[10] >= deep0 + 64u && s_lb[9] <= max(s_lb[5], deep0) && s_lb[9] > s_lb[8];
+        const bool ok = zl >= 2u * G + 11u && s_lb[10] >= deep0 + 64u && s_lb[9] <= max(s_lb[5], deep0) && s_lb[9] > s_lb[8];
         dl[DL_EARLY] = own_off + s_lb[8];
         dl[DL_EARLY + 1] = own_off + (ok ? min(s_lb[9], s_lb[8] + early_cap) : s_lb[8]);
     }
@@ -252,6 +282,12 @@ __global__ void k_slab_post_headers(const uint32_t* __restrict__ dl, const float
     if (t < 8u) host[t] = dl[t];
     else if (t == 16u || t == 17u) host[HL_NEAR + (t - 16u)] = dl[DL_NEAR + (t - 16u)];
     else if (t == 18u || t == 19u) host[HL_EARLY + (t - 18u)] = dl[DL_EARLY + (t - 18u)];
+    else if (t == 20u || t == 21u) host[HL_VFAR + (t - 20u)] = dl[DL_VFAR + (t - 20u)];
+    else if (t >= 32u && t < 40u) {                           // words 4..7 of the neighbours' headers
+        const float4* h = t < 36u ? hdr_lo : hdr_hi;
+        const uint32_t* hw = reinterpret_cast<const uint32_t*>(h);
+        host[t] = h ? hw[4u + ((t - 32u) & 3u)] : 0u;         // {#its second layer, #very far leavers, 0, 0}
+    }
     else if (t < 16u) {
         const float4* h = t < 12u ? hdr_lo : hdr_hi;
         const uint32_t w = (t - 8u) & 3u;
@@ -318,11 +354,56 @@ __global__ __launch_bounds__(256) void k_slab_unpack_ghosts(const float4* __rest
     if (last) cells[k].y = s + 1;
 }
 
+// The one-message step (two ghost layers): the neighbour sent the RESIDENTS of its two layers next to the cut as they were right
+// after its sort; what this rank itself sent INTO those layers this step -- its own leavers towards that side, still in its
+// send buffer -- completes them.  Residents and leavers are both in ascending key order (this rank's numbering); equal keys as
+// the neighbour will order them when it merges its arrivals (k_slab_insert / launch_merge_arrivals, i.e. the whole-domain
+// stable sort): below this slab (side 0) the leavers arrive at the neighbour from ABOVE and go behind the residents of their
+// cell, above it (side 1) they arrive from BELOW and go in front.  A thread per record: a resident counts the leavers in front
+// of it, a leaver the residents (binary searches on keys recomputed from the records' positions; with no leavers on a side the
+// count is 0 and this is a plain unpack).  The cell table of the ghost slots is built by k_cells_build2 afterwards.
+__device__ __forceinline__ uint32_t rec_key(const float4* __restrict__ rec, uint32_t i, const GridDesc& g) {
+    const float4 p = rec[2 * i];
+    return cell_key(g, p.x, p.y, p.z);
+}
+__device__ __forceinline__ uint32_t rec_count_below(const float4* __restrict__ rec, uint32_t n, uint32_t bound, const GridDesc& g) {
+    uint32_t lo = 0, hi = n;                                      // first record with key >= bound
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (rec_key(rec, mid, g) < bound) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_slab_unpack_ghosts_merge(const float4* __restrict__ res_lo, uint32_t nr_lo, const float4* __restrict__ lv_lo,
+                                                                  uint32_t k_lo, uint32_t slot_lo, const float4* __restrict__ res_hi,
+                                                                  uint32_t nr_hi, const float4* __restrict__ lv_hi, uint32_t k_hi,
+                                                                  uint32_t slot_hi, float4* __restrict__ posi, float4* __restrict__ velr,
+                                                                  uint32_t* __restrict__ key, GridDesc g) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const bool high = t >= nr_lo + k_lo;
+    const uint32_t u = high ? t - (nr_lo + k_lo) : t;
+    const uint32_t nr = high ? nr_hi : nr_lo, k = high ? k_hi : k_lo;
+    if (u >= nr + k) return;
+    const float4* res = high ? res_hi : res_lo;
+    const float4* lv = high ? lv_hi : lv_lo;
+    const uint32_t first = high ? 1u : 0u;                        // leavers first among equal keys (above this slab)
+    const bool resident = u < nr;
+    const uint32_t j = resident ? u : u - nr;
+    const float4* rec = (resident ? res : lv) + 2 * (size_t)j;
+    const float4 p = rec[0];
+    const uint32_t kk = cell_key(g, p.x, p.y, p.z);
+    const uint32_t ahead = resident ? rec_count_below(lv, k, kk + first, g) : rec_count_below(res, nr, kk + 1u - first, g);
+    const uint32_t dst = (high ? slot_hi : slot_lo) + j + ahead;
+    posi[dst] = p;
+    velr[dst] = rec[1];
+    key[dst] = kk;
+}
+
 // arrivals appended behind the owned range for the pass over all particles (launch_merge_arrivals): any owned layer
 // is fine there, but a particle that is not inside this slab at all cannot be represented (its key is clamped into a
 // ghost layer): flagged, the step reports SPH_E_STATE
 __global__ __launch_bounds__(256) void k_slab_unpack(const float4* __restrict__ rec, uint32_t n, float4* __restrict__ posi,
-                                                     float4* __restrict__ velr, uint32_t* __restrict__ key, GridDesc g,
+                                                     float4* __restrict__ velr, uint32_t* __restrict__ key, GridDesc g, uint32_t G,
                                                      volatile uint32_t* __restrict__ err_host) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -332,7 +413,7 @@ __global__ __launch_bounds__(256) void k_slab_unpack(const float4* __restrict__ 
     const uint32_t k = cell_key(g, p.x, p.y, p.z);
     if (key) key[i] = k;
     const uint32_t lz = k / (g.g[0] * g.g[1]);
-    if (lz == 0u || lz + 1u >= g.zl) err_host[SLAB_ERR_ARRIVAL_OUTSIDE] = 1u;
+    if (lz < G || lz + G >= g.zl) err_host[SLAB_ERR_ARRIVAL_OUTSIDE] = 1u;
 }
 
 // Arrivals join a BOUNDARY LAYER in place.  A particle a neighbour sent lies in the cell layer next to the cut it
@@ -757,7 +838,8 @@ int loop_exchange(void* self, int tag, const void* send_lo, size_t send_lo_bytes
         const double us = E->latency_us + (E->gbs > 0.0 ? (double)big / (E->gbs * 1e3) : 0.0);
         hipLaunchKernelGGL(k_loop_delay, dim3(1), dim3(1), 0, st, (unsigned long long)(us * 100.0));
     }
-    const bool recs = tag == SPH_TAG_MIGRANTS || tag == SPH_TAG_MIGRANTS_REST || tag == SPH_TAG_HALO_A;
+    const bool recs = tag == SPH_TAG_MIGRANTS || tag == SPH_TAG_MIGRANTS_REST || tag == SPH_TAG_HALO_A || tag == SPH_TAG_ONE ||
+                      tag == SPH_TAG_ONE_REST;
     if (!recs) {                                          // (rho, p) pairs, pings: bytes as they are
         if (send_hi_bytes) SPH_HIP(hipMemcpyAsync(recv_lo, send_hi, send_hi_bytes, hipMemcpyDeviceToDevice, st));
         if (send_lo_bytes) SPH_HIP(hipMemcpyAsync(recv_hi, send_lo, send_lo_bytes, hipMemcpyDeviceToDevice, st));
@@ -767,7 +849,7 @@ int loop_exchange(void* self, int tag, const void* send_lo, size_t send_lo_bytes
     const uint32_t n_up = (uint32_t)(send_hi_bytes / 16), n_down = (uint32_t)(send_lo_bytes / 16);
     if (n_up + n_down) {
         hipLaunchKernelGGL(k_loop_copy, dim3(min(ceil_div(n_up + n_down, 256u), 2048u)), dim3(256), 0, st, (const float4*)send_hi,
-                           (float4*)recv_lo, n_up, (const float4*)send_lo, (float4*)recv_hi, n_down, tag == SPH_TAG_MIGRANTS ? 2u : 0u,
+                           (float4*)recv_lo, n_up, (const float4*)send_lo, (float4*)recv_hi, n_down, (tag == SPH_TAG_MIGRANTS || tag == SPH_TAG_ONE) ? 2u : 0u,
                            E->shift, recs ? 1 : 0);
         SPH_HIP(hipGetLastError());
     }
@@ -803,7 +885,17 @@ struct sph_slab {
     char* stage_recv[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
     uint64_t steps = 0, migrants = 0, resorts = 0, ghosts = 0, host_waits = 0, inserts = 0, far_steps = 0, rest_msgs = 0;
-    uint64_t exchanges = 0;              // transport calls so far (3 in a usual step: migrants, halo A, halo B)
+    uint64_t exchanges = 0;              // transport calls so far (3 in a usual step: migrants, halo A, halo B; 1 in the one-message step)
+    // The step's protocol (sph_slab_set_protocol): 3 = MIGRANTS / HALO A / HALO B, three dependent message groups; 1 = ONE group --
+    // header, leavers and the residents of the two layers next to each cut in one message per neighbour, its size fixed in
+    // advance from the counts both ends saw in the PREVIOUS step's headers (one_prev_*; the first step after a create / re-cut
+    // runs the three-group protocol to learn them), ghost densities recomputed here.  Needs two ghost layers in the context.
+    int protocol = 3;
+    bool one_ready = false;              // one_prev_* are those of the step before this one
+    uint32_t one_prev_s[2] = {0, 0};     // records (leavers + two layers) I packed towards each side in the last step
+    uint32_t one_prev_r[2] = {0, 0};     // ... and what each neighbour packed towards me
+    uint32_t msg_cap = 0;                // records a migrant / one-message buffer holds behind its header
+    uint64_t one_steps = 0, one_rest_msgs = 0;
     bool early_force = true;             // the force pass of the innermost layers runs in front of the step's wait, on a stream of its own
                                          // (sph_slab_set_early_force: ~3 us per step when the links are fast, -30 at 40 us per group)
     uint32_t early_cap = 1u << 20;       // slots of that launch at most (~150 us of k_force): what a link's latency needs, no more
@@ -824,13 +916,17 @@ struct sph_slab {
     struct Acc { uint64_t n = 0; double sum = 0.0, max = 0.0; void add(double v) { n++; sum += v; if (v > max) max = v; } };
     Acc t_wait, t_pre, t_post, t_host;
     uint64_t waits_ready = 0;            // waits whose sequence word was there at the first look: the HOST is behind the device
-    Acc t_group[5];                      // by tag - 1: MIGRANTS, HALO_A, HALO_B, MIGRANTS_REST, PING
+    Acc t_group[9];                      // by tag - 1: MIGRANTS, HALO_A, HALO_B, MIGRANTS_REST, PING, (re-cut x2,) ONE, ONE_REST
     bool time_groups = false;
     struct Pending { int tag; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_free;
     struct Progress {
-        bool mig_posted = false;                     // this step's SPH_TAG_MIGRANTS exchange has been handed to the transport
+        bool mig_posted = false;                     // this step's first exchange (MIGRANTS, or ONE) has been handed to the transport
+        bool one = false;                            // the one-message protocol: that exchange carries one_s / one_r records behind the header
+        uint32_t one_s[2] = {0, 0}, one_r[2] = {0, 0};
+        bool next_known = false;                     // this step's headers are in: the NEXT step's one-message sizes follow from them
+        uint32_t next_s[2] = {0, 0}, next_r[2] = {0, 0};
         bool headers = false, rest = false, halo_a = false, halo_b = false;
         bool peer_dead[2] = {false, false};          // that neighbour's header said "abort": nothing more to or from it
         uint32_t rest_s[2] = {0, 0}, rest_r[2] = {0, 0};   // records of the second migrant message (send, receive) per side
@@ -879,7 +975,7 @@ int slab_exchange_raw(sph_slab* s, int tag, const void* send_lo, size_t send_lo_
 int slab_exchange(sph_slab* s, int tag, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
                   const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes) {
     hipEvent_t a = nullptr, b = nullptr;
-    if (s->time_groups && tag >= 1 && tag <= 5) {
+    if (s->time_groups && tag >= 1 && tag <= 9 && tag != SPH_TAG_RECUT_COUNTS && tag != SPH_TAG_RECUT) {
         a = slab_timing_event(s); b = slab_timing_event(s);
         if (a && b) SPH_HIP(hipEventRecord(a, s->comm));
     }
@@ -990,6 +1086,23 @@ int slab_step_body(sph_slab* s, float dt) {
     int rc;
     const auto t_begin = std::chrono::steady_clock::now();
     s->pg = sph_slab::Progress();
+    const size_t rec = 2 * sizeof(float4);
+    // The ONE-MESSAGE step (sph_slab_set_protocol(s, 1); two ghost layers): header, leavers and the residents of the two layers
+    // next to each cut travel in ONE message per neighbour, before the host knows any count -- so its size is fixed by a rule on
+    // the counts both ends saw in the PREVIOUS step's headers (a margin of 1/16 + 1024 records; what does not fit follows in an
+    // exact second message after the wait: the first step of a burst).  The first step after a create / re-cut has no such
+    // counts and runs the three-group protocol.
+    const bool p1 = s->protocol == 1 && s->one_ready && s->world > 1;
+    auto one_cap = [](uint32_t prev) { return (prev + prev / 16u + 1024u + 63u) & ~63u; };
+    const uint32_t S_s[2] = {p1 && s->has_lo ? one_cap(s->one_prev_s[0]) : 0u, p1 && s->has_hi ? one_cap(s->one_prev_s[1]) : 0u};
+    const uint32_t S_r[2] = {p1 && s->has_lo ? one_cap(s->one_prev_r[0]) : 0u, p1 && s->has_hi ? one_cap(s->one_prev_r[1]) : 0u};
+    if (p1) {
+        SPH_REQUIRE(S_s[0] <= s->msg_cap && S_s[1] <= s->msg_cap && S_r[0] <= s->msg_cap && S_r[1] <= s->msg_cap, SPH_E_CAPACITY,
+                    "rank %d: the one-message step would carry %u/%u (send) %u/%u (receive) records; the buffers hold %u", s->rank, S_s[0], S_s[1],
+                    S_r[0], S_r[1], s->msg_cap);
+        s->pg.one = true;
+        for (int k = 0; k < 2; k++) { s->pg.one_s[k] = S_s[k]; s->pg.one_r[k] = S_r[k]; }
+    }
     rc = slab_check_device_flags(s); if (rc) return rc;
     // ---- hash + sort the owned particles (leavers end up at the two ends of the owned range) -----------------------
     rc = step_hash(c); if (rc) return rc;
@@ -1000,22 +1113,24 @@ int slab_step_body(sph_slab* s, float dt) {
     if (rc) return rc;
     const uint32_t layer = c->grid.g[0] * c->grid.g[1];
     const uint32_t n0 = c->n, off0 = c->own_off;
-    const size_t rec = 2 * sizeof(float4);
     // ---- layer bounds, leavers and headers in ONE kernel; the comm stream ships the fixed-size part ------------------
     s->seq++;
     // a few blocks: every block finds the bounds for itself, the leavers (few, at most mcap) are packed in a grid-stride loop;
     // behind them the blocks that build the cell table of the owned slots when the sort left it pending (not on a skipped sort)
-    const uint32_t pack_blocks = min(ceil_div(s->mcap, 256u), 16u), build_blocks = c->owned_cells_pending ? cells_build_blocks(n0) : 0u;
+    // a few blocks (many when they also copy two layers): every block finds the bounds for itself, the leavers and residents are packed in
+    // grid-stride loops; behind them the blocks that build the cell table of the owned slots when the sort left it pending (not on a skipped sort)
+    const uint32_t pack_blocks = p1 ? 128u : min(ceil_div(s->mcap, 256u), 16u), build_blocks = c->owned_cells_pending ? cells_build_blocks(n0) : 0u;
     c->owned_cells_pending = false;
     hipLaunchKernelGGL(k_slab_bounds_pack, dim3(pack_blocks + build_blocks), dim3(256), 0, c->stream, c->keyS + off0, c->posi + off0,
                        c->velr + off0, n0, off0, layer, s->mcap, c->grid, s->early_cap, s->d_lb, s->mig_send[0], s->mig_send[1], pack_blocks,
-                       c->keyS, c->cells, c->mm_count_host_dev + 1);
+                       c->keyS, c->cells, c->mm_count_host_dev + 1, c->ghost_layers, p1 ? 1u : 0u, s->gcap);
     SPH_HIP(hipGetLastError());
     rc = after_main(s); if (rc) return rc;
     // ---- the density of the deep interior goes into the main stream's queue BEFORE the host waits: its slot range
     //      comes from device memory (k_slab_bounds_pack wrote it).  Layers >= 4 from either cut see neither ghosts nor
     //      arrivals (those land in the boundary layers), and no slot of them moves before the force pass.
-    bool deep_valid = c->grid.zl >= 9u;
+    const uint32_t G = c->ghost_layers;           // ghost layers per side: the owned layers are the local layers [G, zl - G)
+    bool deep_valid = c->grid.zl >= 2u * G + 7u;
     if (deep_valid) {
         PhaseTimer t(c, SPH_PH_DENS);
         rc = launch_density_dev_range(c, s->d_lb + DL_DEEP, n0);
@@ -1036,7 +1151,7 @@ int slab_step_body(sph_slab* s, float dt) {
     // a full-size grid of blocks that leave at once, two events and a stream hop bought nothing, every step.  The bounds
     // kernel reports the range whether or not a launch used it, so the launch comes back one step after the range does.
     const bool early_empty = s->early_span_known && s->early_span == 0u;
-    if (deep_valid && s->early_force && s->world > 1 && c->grid.zl >= 13u && !early_empty) {          // (no neighbour, no latency to fill)
+    if (deep_valid && s->early_force && s->world > 1 && c->grid.zl >= 2u * G + 11u && !early_empty) {          // (no neighbour, no latency to fill)
         if (s->early_own_stream && s->early) {
             SPH_HIP(hipEventRecord(s->ev_early_go, c->stream));             // behind the deep density
             SPH_HIP(hipStreamWaitEvent(s->early, s->ev_early_go, 0));
@@ -1067,8 +1182,10 @@ int slab_step_body(sph_slab* s, float dt) {
     const uint32_t inl = min(MIG_INLINE, s->mcap);
     const size_t mig_bytes = (size_t)(1 + inl) * rec;
     s->pg.mig_posted = true;                                    // (also when the call fails: the transport is dead then)
-    rc = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
-                       s->mig_recv[1], mig_bytes);
+    if (p1) rc = slab_exchange(s, SPH_TAG_ONE, s->mig_send[0], (1 + (size_t)S_s[0]) * rec, s->mig_recv[0], (1 + (size_t)S_r[0]) * rec,
+                               s->mig_send[1], (1 + (size_t)S_s[1]) * rec, s->mig_recv[1], (1 + (size_t)S_r[1]) * rec);
+    else rc = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
+                            s->mig_recv[1], mig_bytes);
     if (rc) return rc;
     hipLaunchKernelGGL(k_slab_post_headers, dim3(1), dim3(64), 0, s->comm, s->d_lb, s->has_lo ? s->mig_recv[0] : (float4*)nullptr,
                        s->has_hi ? s->mig_recv[1] : (float4*)nullptr, s->h_lb_dev, s->seq);
@@ -1091,6 +1208,15 @@ int slab_step_body(sph_slab* s, float dt) {
     const uint32_t in_lo = s->has_lo ? s->h_lb[HL_HDR_LO] : 0u, peer_own_lo = s->has_lo ? s->h_lb[HL_HDR_LO + 1] : 0u;
     const uint32_t in_hi = s->has_hi ? s->h_lb[HL_HDR_HI] : 0u, peer_own_hi = s->has_hi ? s->h_lb[HL_HDR_HI + 1] : 0u;
     const uint32_t far_in_lo = s->has_lo ? s->h_lb[HL_HDR_LO + 2] : 0u, far_in_hi = s->has_hi ? s->h_lb[HL_HDR_HI + 2] : 0u;
+    // the SECOND layers next to the cuts (the one-message step's ghosts-of-ghosts; every header carries the counts, so that the
+    // step after a three-group step can size its message): mine from the bounds, the neighbours' from their headers
+    const uint32_t n2_lo = s->has_lo && near_lo >= off0 + lb1 ? min(near_lo - off0, lb2) - lb1 : 0u;
+    const uint32_t n2_hi = s->has_hi && near_hi >= off0 && near_hi - off0 <= lb2 ? lb2 - max(near_hi - off0, lb1) : 0u;
+    const uint32_t n2p_lo = s->has_lo ? s->h_lb[HL_HDR2_LO] : 0u, n2p_hi = s->has_hi ? s->h_lb[HL_HDR2_HI] : 0u;
+    const uint32_t vfar_mine = s->h_lb[HL_VFAR], vfar_peer = (s->has_lo ? s->h_lb[HL_HDR2_LO + 1] : 0u) + (s->has_hi ? s->h_lb[HL_HDR2_HI + 1] : 0u);
+    // records either end of a link packed this step: what the NEXT one-message step is sized from
+    const uint32_t tot_s[2] = {s->has_lo ? m_lo + own_lo + n2_lo : 0u, s->has_hi ? m_hi + own_hi + n2_hi : 0u};
+    const uint32_t tot_r[2] = {s->has_lo ? in_lo + peer_own_lo + n2p_lo : 0u, s->has_hi ? in_hi + peer_own_hi + n2p_hi : 0u};
     {   // What this step still owes its neighbours -- the second migrant message, halo A, halo B -- in numbers BOTH ends of
         // a link see (mine in my header, the neighbour's in its header), clamped to the buffers: if this rank fails from
         // here on it still sends and takes exactly these (slab_fail), so that no neighbour is left waiting for a message.
@@ -1105,11 +1231,19 @@ int slab_step_body(sph_slab* s, float dt) {
         const bool any_rest = m_lo > inl0 || m_hi > inl0 || in_lo > inl0 || in_hi > inl0;
         for (int k = 0; k < 2; k++) {
             const bool has = k == 0 ? s->has_lo : s->has_hi;
+            if (p1) {                     // all that can still be owed is the part of the one message that did not fit its fixed size
+                g.rest_s[k] = tot_s[k] > S_s[k] ? umin(tot_s[k], s->msg_cap) - S_s[k] : 0u;
+                g.rest_r[k] = tot_r[k] > S_r[k] ? umin(tot_r[k], s->msg_cap) - S_r[k] : 0u;
+                continue;
+            }
             g.rest_s[k] = any_rest && mm[k] > inl0 ? mm[k] - inl0 : 0u;
             g.rest_r[k] = any_rest && ii[k] > inl0 ? ii[k] - inl0 : 0u;
             g.h[k] = has ? umin(own[k] + iraw[k] - fi[k], s->gcap) : 0u;
             g.g[k] = has ? umin(peer[k] + mraw[k] - fo[k], s->gcap) : 0u;
         }
+        if (p1) g.halo_a = g.halo_b = true;       // (no such messages in this protocol)
+        g.next_known = true;
+        for (int k = 0; k < 2; k++) { g.next_s[k] = one_cap(tot_s[k]); g.next_r[k] = one_cap(tot_r[k]); }
         SPH_REQUIRE(!g.peer_dead[0] && !g.peer_dead[1], SPH_E_PEER, "rank %d: its %s neighbour reported a failure and stopped (step %llu)",
                     s->rank, g.peer_dead[0] ? (g.peer_dead[1] ? "lower and upper" : "lower") : "upper", (unsigned long long)s->steps);
     }
@@ -1125,6 +1259,26 @@ int slab_step_body(sph_slab* s, float dt) {
     // sorted range of this step
     SPH_REQUIRE(n0 - m_lo - m_hi + in_lo + in_hi <= c->cap && (uint64_t)off0 + n0 - m_hi + in_lo + in_hi <= c->tot, SPH_E_CAPACITY,
                 "rank %d: %u + %u arriving particles exceed the capacity %u", s->rank, n0 - m_lo - m_hi, in_lo + in_hi, c->cap);
+    if (p1) {
+        SPH_REQUIRE(vfar_mine == 0u && vfar_peer == 0u, SPH_E_STATE,
+                    "rank %d: %u leaving / %u arriving particles crossed more than TWO cell layers in one step: the one-message step keeps two "
+                    "ghost layers (the three-group protocol takes such particles as long as they land in an interior layer)", s->rank,
+                    vfar_mine, vfar_peer);
+        SPH_REQUIRE(tot_s[0] <= s->msg_cap && tot_s[1] <= s->msg_cap && tot_r[0] <= s->msg_cap && tot_r[1] <= s->msg_cap &&
+                        peer_own_lo + n2p_lo <= s->gcap && peer_own_hi + n2p_hi <= s->gcap, SPH_E_CAPACITY,
+                    "rank %d: two layers of %u+%u / %u+%u residents (+ %u / %u leavers) exceed the message buffers (%u records) or the ghost "
+                    "capacity %u", s->rank, peer_own_lo, n2p_lo, peer_own_hi, n2p_hi, in_lo, in_hi, s->msg_cap, s->gcap);
+        // what did not fit the size fixed in advance (a burst: many more leavers than in the step before), exact
+        const sph_slab::Progress& g = s->pg;
+        if (g.rest_s[0] | g.rest_s[1] | g.rest_r[0] | g.rest_r[1]) {
+            rc = slab_exchange(s, SPH_TAG_ONE_REST, s->mig_send[0] + 2 * (1 + (size_t)S_s[0]), g.rest_s[0] * rec, s->mig_recv[0] + 2 * (1 + (size_t)S_r[0]),
+                               g.rest_r[0] * rec, s->mig_send[1] + 2 * (1 + (size_t)S_s[1]), g.rest_s[1] * rec,
+                               s->mig_recv[1] + 2 * (1 + (size_t)S_r[1]), g.rest_r[1] * rec);
+            if (rc) return rc;
+            s->one_rest_msgs++;
+        }
+        s->one_steps++;
+    } else
     // ---- more leavers than ride in the fixed-size message: the rest, exact size (both ends know both counts) ----------
     if (m_lo > inl || m_hi > inl || in_lo > inl || in_hi > inl) {
         const size_t s_lo = m_lo > inl ? (size_t)(m_lo - inl) * rec : 0, s_hi = m_hi > inl ? (size_t)(m_hi - inl) * rec : 0;
@@ -1180,7 +1334,7 @@ int slab_step_body(sph_slab* s, float dt) {
                 rc = launch_cells_clear_range(c, l0, l0 + nl); if (rc) return rc;
                 hipLaunchKernelGGL(k_slab_insert, dim3(ceil_div(nl + k, 256u)), dim3(256), 0, c->stream, c->posi, c->velr, c->keyS, l0,
                                    nl, s->mig_recv[side] + 2, k, c->grid, c->posi2, c->velr2, c->keyS2, d0,
-                                   side == 0 ? 1u : c->grid.zl - 2u, side == 0, s->h_lb_dev + HL_ERR);
+                                   side == 0 ? G : c->grid.zl - G - 1u, side == 0, s->h_lb_dev + HL_ERR);
                 hipLaunchKernelGGL(k_slab_copy_back, dim3(ceil_div(nl + k, 256u)), dim3(256), 0, c->stream, c->posi2, c->velr2, c->keyS2,
                                    c->posi, c->velr, c->keyS, d0, nl + k);
                 SPH_HIP(hipGetLastError());
@@ -1210,13 +1364,13 @@ int slab_step_body(sph_slab* s, float dt) {
                 if (!cnt) continue;
                 if (side == 0 && front_slots) {
                     hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(cnt, 256u)), dim3(256), 0, c->stream, s->mig_recv[0] + 2, cnt,
-                                       c->posi + c->own_off - cnt, c->velr + c->own_off - cnt, (uint32_t*)nullptr, c->grid,
+                                       c->posi + c->own_off - cnt, c->velr + c->own_off - cnt, (uint32_t*)nullptr, c->grid, G,
                                        s->h_lb_dev + HL_ERR);
                     continue;
                 }
                 const uint32_t at = c->own_off + c->n + appended;
                 hipLaunchKernelGGL(k_slab_unpack, dim3(ceil_div(cnt, 256u)), dim3(256), 0, c->stream, s->mig_recv[side] + 2, cnt,
-                                   c->posi + at, c->velr + at, merge ? c->k0 + c->n + appended : (uint32_t*)nullptr, c->grid,
+                                   c->posi + at, c->velr + at, merge ? c->k0 + c->n + appended : (uint32_t*)nullptr, c->grid, G,
                                    s->h_lb_dev + HL_ERR);
                 appended += cnt;
             }
@@ -1244,7 +1398,7 @@ int slab_step_body(sph_slab* s, float dt) {
                     fprintf(stderr, "[slab %d] step %llu: far arrivals %u/%u of %u/%u; leavers %u/%u (far %u/%u); bounds %u %u %u %u of %u; "
                             "peer boundary %u/%u\n", s->rank, (unsigned long long)s->steps, far_in_lo, far_in_hi, in_lo, in_hi, m_lo, m_hi,
                             far_lo, far_hi, lb0, lb1, lb2, lb3, n0, peer_own_lo, peer_own_hi);
-                hipLaunchKernelGGL(k_slab_bounds, dim3(1), dim3(64), 0, c->stream, c->keyS + c->own_off, c->n, layer, c->grid.zl,
+                hipLaunchKernelGGL(k_slab_bounds, dim3(1), dim3(64), 0, c->stream, c->keyS + c->own_off, c->n, layer, c->grid.zl, G,
                                    s->d_lb, s->h_lb_dev);
                 SPH_HIP(hipGetLastError());
                 SPH_HIP(hipStreamSynchronize(c->stream));
@@ -1259,8 +1413,11 @@ int slab_step_body(sph_slab* s, float dt) {
         }
     }
     const uint32_t n = c->n;
-    const uint32_t g_lo = s->has_lo ? peer_own_lo + m_lo - far_lo : 0u;   // ghosts I receive = what stayed in the neighbour's
-    const uint32_t g_hi = s->has_hi ? peer_own_hi + m_hi - far_hi : 0u;   // boundary layer + what I just sent INTO that layer
+    // ghosts = what stayed in the neighbour's boundary layer + what I just sent INTO that layer; the one-message step keeps
+    // the neighbour's second layer as well (g1: the inner ghost layer, whose densities this rank computes itself)
+    const uint32_t g1_lo = s->has_lo ? peer_own_lo + m_lo - far_lo : 0u, g1_hi = s->has_hi ? peer_own_hi + m_hi - far_hi : 0u;
+    const uint32_t g_lo = p1 && s->has_lo ? peer_own_lo + n2p_lo + m_lo : g1_lo;
+    const uint32_t g_hi = p1 && s->has_hi ? peer_own_hi + n2p_hi + m_hi : g1_hi;
     const uint32_t h_lo = s->has_lo ? own_lo : 0u, h_hi = s->has_hi ? own_hi : 0u;
     SPH_REQUIRE(own_lo <= n && own_hi <= n, SPH_E_STATE, "rank %d: inconsistent boundary counts", s->rank);
     SPH_REQUIRE(h_lo <= s->gcap && h_hi <= s->gcap && g_lo <= s->gcap && g_hi <= s->gcap && g_lo <= c->own_off &&
@@ -1281,9 +1438,19 @@ int slab_step_body(sph_slab* s, float dt) {
     // another rank's kernels.)
     const bool need_deep_event = early_halo && !(a <= near_lo && b >= near_hi);
     if (need_deep_event) SPH_HIP(hipEventRecord(s->ev_deep, c->stream));
+    // the slots the non-deep density launches cover: the owned range -- and, in the one-message step, the inner ghost layers
+    // on either side (rounded down to a whole 64-slot chunk in front, so that the hole these launches leave for the deep range
+    // stays on the chunk boundaries the deep launch used; the few slots of the OUTER ghost layer that catches get a density
+    // nobody reads: their own neighbourhood is not complete here)
+    uint32_t dens_lo = c->own_off, dens_hi = c->own_off + n;
+    if (p1) {
+        const uint32_t back = (g1_lo + 63u) & ~63u;
+        dens_lo = c->own_off - (back <= g_lo ? back : g1_lo);
+        dens_hi = c->own_off + n + g1_hi;
+    }
     // ---- halo A: boundary layers -> neighbours' ghost layers -----------------------------------------------------------
     hipStream_t pack_stream = early_halo ? s->comm : c->stream;
-    if (h_lo + h_hi)
+    if (!p1 && h_lo + h_hi)
         hipLaunchKernelGGL(k_slab_pack2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, pack_stream, c->posi, c->velr, c->own_off, h_lo,
                            c->own_off + n - h_hi, h_hi, s->halo_send[0], s->halo_send[1]);
     SPH_HIP(hipGetLastError());
@@ -1295,15 +1462,35 @@ int slab_step_body(sph_slab* s, float dt) {
         rc = deep_valid ? launch_density_hole(c, a, b, deep_lo, deep_hi) : launch_density_range(c, a, b);
         if (rc) return rc;
     }
-    rc = slab_exchange(s, SPH_TAG_HALO_A, s->halo_send[0], h_lo * rec, s->halo_recv[0], g_lo * rec, s->halo_send[1], h_hi * rec,
-                       s->halo_recv[1], g_hi * rec);
-    if (rc) return rc;
-    s->pg.halo_a = true;
-    // ghosts go directly in front of / behind the owned range, already in key order; their cells join the table of
-    // the owned slots (comm stream, one kernel: none of it is touched by the interior passes)
-    if (g_lo + g_hi)
-        hipLaunchKernelGGL(k_slab_unpack_ghosts, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->halo_recv[0], g_lo,
-                           c->own_off - g_lo, s->halo_recv[1], g_hi, c->own_off + n, c->posi, c->velr, c->keyS, c->cells, c->grid);
+    if (!p1) {
+        rc = slab_exchange(s, SPH_TAG_HALO_A, s->halo_send[0], h_lo * rec, s->halo_recv[0], g_lo * rec, s->halo_send[1], h_hi * rec,
+                           s->halo_recv[1], g_hi * rec);
+        if (rc) return rc;
+        s->pg.halo_a = true;
+        // ghosts go directly in front of / behind the owned range, already in key order; their cells join the table of
+        // the owned slots (comm stream, one kernel: none of it is touched by the interior passes)
+        if (g_lo + g_hi)
+            hipLaunchKernelGGL(k_slab_unpack_ghosts, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->halo_recv[0], g_lo,
+                               c->own_off - g_lo, s->halo_recv[1], g_hi, c->own_off + n, c->posi, c->velr, c->keyS, c->cells, c->grid);
+    } else if (g_lo + g_hi) {
+        // The one-message step: the neighbours' two layers came with their headers and leavers (behind those, in the same
+        // buffer); no message here.  A side this rank sent nobody to is unpacked as it is; else its own leavers -- still in the
+        // send buffer -- are merged in where the neighbour will put them (k_slab_unpack_ghosts_merge), then the cells.
+        const float4* res_lo = s->mig_recv[0] + 2 * (1 + (size_t)in_lo);
+        const float4* res_hi = s->mig_recv[1] + 2 * (1 + (size_t)in_hi);
+        const uint32_t nr_lo = s->has_lo ? peer_own_lo + n2p_lo : 0u, nr_hi = s->has_hi ? peer_own_hi + n2p_hi : 0u;
+        if (m_lo + m_hi == 0u) {
+            hipLaunchKernelGGL(k_slab_unpack_ghosts, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, res_lo, g_lo, c->own_off - g_lo,
+                               res_hi, g_hi, c->own_off + n, c->posi, c->velr, c->keyS, c->cells, c->grid);
+        } else {
+            hipLaunchKernelGGL(k_slab_unpack_ghosts_merge, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, res_lo, nr_lo,
+                               s->mig_send[0] + 2, s->has_lo ? m_lo : 0u, c->own_off - g_lo, res_hi, nr_hi, s->mig_send[1] + 2, s->has_hi ? m_hi : 0u,
+                               c->own_off + n, c->posi, c->velr, c->keyS, c->grid);
+            OnComm on(s);
+            rc = launch_cells_build_2ranges(c, c->own_off - g_lo, c->own_off, c->own_off + n, c->own_off + n + g_hi);
+            if (rc) return rc;
+        }
+    }
     SPH_HIP(hipGetLastError());
     c->n_glo = g_lo; c->n_ghi = g_hi;
     s->ghosts += g_lo + g_hi;
@@ -1318,10 +1505,10 @@ int slab_step_body(sph_slab* s, float dt) {
         OnComm on(s);
         {
             PhaseTimer t(c, SPH_PH_DENS);
-            rc = launch_density_hole(c, c->own_off, c->own_off + n, deep_lo, deep_hi);
+            rc = launch_density_hole(c, dens_lo, dens_hi, deep_lo, deep_hi);
             if (rc) return rc;
         }
-        if (h_lo + h_hi)
+        if (!p1 && h_lo + h_hi)
             hipLaunchKernelGGL(k_slab_copy_dp2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, c->stream, c->dp + c->own_off,
                                s->dens_send[0], h_lo, c->dp + c->own_off + n - h_hi, s->dens_send[1], h_hi);
         SPH_HIP(hipGetLastError());
@@ -1330,11 +1517,11 @@ int slab_step_body(sph_slab* s, float dt) {
     if (!early_halo) {
         {
             PhaseTimer t(c, SPH_PH_DENS);                        // the two boundary layers
-            rc = launch_density_hole(c, c->own_off, c->own_off + n, a, b);
+            rc = launch_density_hole(c, dens_lo, dens_hi, a, b);
             if (rc) return rc;
         }
         // ---- halo B: (density, pressure) of the same boundary particles, same order ---------------------------------
-        if (h_lo + h_hi)
+        if (!p1 && h_lo + h_hi)
             hipLaunchKernelGGL(k_slab_copy_dp2, dim3(ceil_div(h_lo + h_hi, 256u)), dim3(256), 0, c->stream, c->dp + c->own_off,
                                s->dens_send[0], h_lo, c->dp + c->own_off + n - h_hi, s->dens_send[1], h_hi);
         SPH_HIP(hipGetLastError());
@@ -1366,15 +1553,17 @@ int slab_step_body(sph_slab* s, float dt) {
         }
     }
     if (rc) return rc;
-    rc = slab_exchange(s, SPH_TAG_HALO_B, s->dens_send[0], h_lo * sizeof(float2), s->dens_recv[0], g_lo * sizeof(float2),
-                       s->dens_send[1], h_hi * sizeof(float2), s->dens_recv[1], g_hi * sizeof(float2));
-    if (rc) return rc;
-    s->pg.halo_b = true;
-    if (g_lo + g_hi)
-        hipLaunchKernelGGL(k_slab_unpack_dp2, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->dens_recv[0],
-                           c->dp + c->own_off - g_lo, c->cw + c->own_off - g_lo, g_lo, s->dens_recv[1], c->dp + c->own_off + n,
-                           c->cw + c->own_off + n, g_hi, c->phys);
-    SPH_HIP(hipGetLastError());
+    if (!p1) {
+        rc = slab_exchange(s, SPH_TAG_HALO_B, s->dens_send[0], h_lo * sizeof(float2), s->dens_recv[0], g_lo * sizeof(float2),
+                           s->dens_send[1], h_hi * sizeof(float2), s->dens_recv[1], g_hi * sizeof(float2));
+        if (rc) return rc;
+        s->pg.halo_b = true;
+        if (g_lo + g_hi)
+            hipLaunchKernelGGL(k_slab_unpack_dp2, dim3(ceil_div(g_lo + g_hi, 256u)), dim3(256), 0, s->comm, s->dens_recv[0],
+                               c->dp + c->own_off - g_lo, c->cw + c->own_off - g_lo, g_lo, s->dens_recv[1], c->dp + c->own_off + n,
+                               c->cw + c->own_off + n, g_hi, c->phys);
+        SPH_HIP(hipGetLastError());
+    }   // (the one-message step: the inner ghost layers' densities came out of this rank's own density launches above)
     // the boundary layers' force pass: on the comm stream, behind the ghosts' (rho, p) -- beside the interior launch
     // (it reads what that one reads and writes other slots of the ping-pong arrays), not behind it
     {
@@ -1390,6 +1579,9 @@ int slab_step_body(sph_slab* s, float dt) {
     // (no event here: the comm stream's first action of the next step waits for an event the main stream records behind
     // k_slab_bounds_pack, i.e. behind everything queued above)
     s->steps++;
+    // what either end of each link packed this step: the size rule of the next one-message step (both ends hold the same numbers)
+    for (int k = 0; k < 2; k++) { s->one_prev_s[k] = tot_s[k]; s->one_prev_r[k] = tot_r[k]; }
+    s->one_ready = true;
     if (c->timing) { c->timed_steps++; if (c->events.size() > 3 * 4096) timing_collect(c); }
     {
         const auto t_end = std::chrono::steady_clock::now();
@@ -1425,10 +1617,18 @@ int slab_fail(sph_slab* s, int rc) {
         after_main(s);          // (a bounds kernel of this step may be queued on the main stream: it writes the same header words)
         hipLaunchKernelGGL(k_slab_abort_headers, dim3(1), dim3(64), 0, s->comm, s->mig_send[0], s->mig_send[1]);
         const size_t mig_bytes = (size_t)(1 + inl) * rec;
-        e = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
-                          s->mig_recv[1], mig_bytes);
+        if (g.one)              // the neighbours have posted this step's ONE message at the sizes the rule gave all of us
+            e = slab_exchange(s, SPH_TAG_ONE, s->mig_send[0], (1 + (size_t)g.one_s[0]) * rec, s->mig_recv[0], (1 + (size_t)g.one_r[0]) * rec,
+                              s->mig_send[1], (1 + (size_t)g.one_s[1]) * rec, s->mig_recv[1], (1 + (size_t)g.one_r[1]) * rec);
+        else
+            e = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
+                              s->mig_recv[1], mig_bytes);
     } else if (!s->transport_dead && g.headers && s->world > 1) {
-        if (!g.rest && (g.rest_s[0] | g.rest_s[1] | g.rest_r[0] | g.rest_r[1]))
+        if (!g.rest && g.one && (g.rest_s[0] | g.rest_s[1] | g.rest_r[0] | g.rest_r[1]))
+            e = slab_exchange(s, SPH_TAG_ONE_REST, s->mig_send[0] + 2 * (1 + (size_t)g.one_s[0]), g.rest_s[0] * rec,
+                              s->mig_recv[0] + 2 * (1 + (size_t)g.one_r[0]), g.rest_r[0] * rec, s->mig_send[1] + 2 * (1 + (size_t)g.one_s[1]),
+                              g.rest_s[1] * rec, s->mig_recv[1] + 2 * (1 + (size_t)g.one_r[1]), g.rest_r[1] * rec);
+        else if (!g.rest && (g.rest_s[0] | g.rest_s[1] | g.rest_r[0] | g.rest_r[1]))
             e = slab_exchange(s, SPH_TAG_MIGRANTS_REST, s->mig_send[0] + 2 * (1 + inl), g.rest_s[0] * rec, s->mig_recv[0] + 2 * (1 + inl),
                               g.rest_r[0] * rec, s->mig_send[1] + 2 * (1 + inl), g.rest_s[1] * rec, s->mig_recv[1] + 2 * (1 + inl),
                               g.rest_r[1] * rec);
@@ -1441,8 +1641,16 @@ int slab_fail(sph_slab* s, int rc) {
         if (!e) {                                               // the next step's header: "abort"
             hipLaunchKernelGGL(k_slab_abort_headers, dim3(1), dim3(64), 0, s->comm, s->mig_send[0], s->mig_send[1]);
             const size_t mig_bytes = (size_t)(1 + inl) * rec;
-            e = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
-                              s->mig_recv[1], mig_bytes);
+            // (the neighbours, for whom this step went through, take their next step under the slab's protocol: a one-message
+            // step is sized from THIS step's headers, which both ends have)
+            if (s->protocol == 1 && g.next_known && g.next_s[0] <= s->msg_cap && g.next_s[1] <= s->msg_cap && g.next_r[0] <= s->msg_cap &&
+                g.next_r[1] <= s->msg_cap)
+                e = slab_exchange(s, SPH_TAG_ONE, s->mig_send[0], (1 + (size_t)(s->has_lo ? g.next_s[0] : 0u)) * rec, s->mig_recv[0],
+                                  (1 + (size_t)(s->has_lo ? g.next_r[0] : 0u)) * rec, s->mig_send[1], (1 + (size_t)(s->has_hi ? g.next_s[1] : 0u)) * rec,
+                                  s->mig_recv[1], (1 + (size_t)(s->has_hi ? g.next_r[1] : 0u)) * rec);
+            else
+                e = slab_exchange(s, SPH_TAG_MIGRANTS, s->mig_send[0], mig_bytes, s->mig_recv[0], mig_bytes, s->mig_send[1], mig_bytes,
+                                  s->mig_recv[1], mig_bytes);
         }
     }
     if ((s->transport_dead || e) && s->tr.abort) { s->tr.abort(s->tr.self); s->transport_dead = true; }
@@ -1663,7 +1871,9 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
               hipMemset(s->d_lb, 0, DL_WORDS * sizeof(uint32_t)) == hipSuccess &&
               hipHostMalloc((void**)&s->h_lb, HL_WORDS * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
               hipHostGetDevicePointer((void**)&s->h_lb_dev, (void*)s->h_lb, 0) == hipSuccess;
-    const size_t mig_bytes = (size_t)(1 + s->mcap) * 2 * sizeof(float4), halo_bytes = (size_t)(s->gcap + 1) * 2 * sizeof(float4);
+    // (a context with two ghost layers may run the one-message step: leavers AND two layers of residents in one buffer)
+    s->msg_cap = ctx->ghost_layers >= 2u ? s->mcap + s->gcap + 64u : s->mcap;
+    const size_t mig_bytes = (size_t)(1 + s->msg_cap) * 2 * sizeof(float4), halo_bytes = (size_t)(s->gcap + 1) * 2 * sizeof(float4);
     for (int k = 0; k < 2 && ok; k++)
         ok = hipMalloc((void**)&s->mig_send[k], mig_bytes) == hipSuccess && hipMalloc((void**)&s->mig_recv[k], mig_bytes) == hipSuccess &&
              hipMalloc((void**)&s->halo_send[k], halo_bytes) == hipSuccess && hipMalloc((void**)&s->halo_recv[k], halo_bytes) == hipSuccess &&
@@ -1742,6 +1952,27 @@ int sph_slab_sync(sph_slab* s) {
     return slab_check_device_flags(s);
 }
 
+int sph_slab_set_protocol(sph_slab* s, int groups) {
+    SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
+    SPH_REQUIRE(groups == 1 || groups == 3, SPH_E_INVALID, "the slab step has a one-message and a three-group protocol, not %d", groups);
+    if (groups == 1) {
+        SPH_REQUIRE(s->c->ghost_layers >= 2u, SPH_E_STATE, "the one-message step needs a context with two ghost layers (sph_create_slab_layers)");
+        // the two layers sent to either neighbour must be four different layers: what arrives from one side (even a particle
+        // that crossed two layers) then never lands in a layer the OTHER neighbour holds a copy of
+        SPH_REQUIRE(s->world == 1 || s->c->z_hi - s->c->z_lo >= 4u, SPH_E_STATE,
+                    "the one-message step needs slabs of at least four cell layers (this one: %u)", s->c->z_hi - s->c->z_lo);
+    }
+    s->protocol = groups;
+    s->one_ready = false;                                   // the next step runs the three-group protocol and learns the sizes
+    return SPH_OK;
+}
+
+int sph_slab_protocol(const sph_slab* s, uint64_t out[3]) {
+    SPH_REQUIRE(s && out, SPH_E_INVALID, "null argument");
+    out[0] = (uint64_t)s->protocol; out[1] = s->one_steps; out[2] = s->one_rest_msgs;
+    return SPH_OK;
+}
+
 int sph_slab_set_early_force(sph_slab* s, int on) {
     SPH_REQUIRE(s, SPH_E_INVALID, "null slab");
     s->early_force = on != 0;
@@ -1786,6 +2017,10 @@ int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]) {
         out[SPH_SLAB_T_GROUPS + 3 * g] = (double)s->t_group[g].n;
         out[SPH_SLAB_T_GROUPS + 3 * g + 1] = s->t_group[g].sum;
         out[SPH_SLAB_T_GROUPS + 3 * g + 2] = s->t_group[g].max;
+    }
+    for (int g = 0; g < 2; g++) {
+        const sph_slab::Acc& a = s->t_group[SPH_TAG_ONE - 1 + g];
+        out[SPH_SLAB_T_GROUPS_ONE + 3 * g] = (double)a.n; out[SPH_SLAB_T_GROUPS_ONE + 3 * g + 1] = a.sum; out[SPH_SLAB_T_GROUPS_ONE + 3 * g + 2] = a.max;
     }
     return SPH_OK;
 }
@@ -1957,6 +2192,7 @@ static int slab_recut_body(sph_slab* s, uint32_t new_lo, uint32_t new_hi) {
     c->own_off = base;
     c->n = (uint32_t)n_new;
     rc = set_slab_range(c, new_lo, new_hi); if (rc) return rc;
+    s->one_ready = false;                                   // (the layers changed: the next step learns the message sizes again)
     s->recuts++;
     s->recut_moved += down + up;
     return SPH_OK;

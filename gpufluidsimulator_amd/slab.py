@@ -53,15 +53,17 @@ def cell_layer_of(z, box_z, gz):
 MIN_SLAB_LAYERS = 2
 
 
-def choose_cuts(hist, world):
+def choose_cuts(hist, world, min_layers=None):
     """Count-balanced slab boundaries: cuts[r] .. cuts[r+1] are rank r's cell layers.
+    `min_layers`: 2 (default, below) or 4 for the one-message slab step (sph_slab_set_protocol: the two layers sent to either
+    neighbour must be four different layers).
 
     Every slab keeps at least MIN_SLAB_LAYERS = 2 layers: the halo protocol treats a slab's lowest and highest
     layer as two different boundary layers (what arrives from below lands in the first, what arrives from above in
     the second); with a one-layer slab they would be the same layer and a neighbour would be sent too few ghosts."""
     hist = np.asarray(hist, dtype=np.int64)
     gz, total = hist.shape[0], int(hist.sum())
-    m = MIN_SLAB_LAYERS if world > 1 else 1
+    m = (min_layers or MIN_SLAB_LAYERS) if world > 1 else 1
     if world * m > gz:
         raise ValueError(f"{world} ranks need {m} cell layers each but the grid has only {gz}")
     prefix = np.concatenate([[0], np.cumsum(hist)])
@@ -213,7 +215,7 @@ class HipEngine:
     """One z-slab on one MI355X through the C ABI.  Buffers handed to the halo calls are torch
     CUDA tensors (plumbing: device memory + RCCL); all arithmetic is in the HIP library."""
 
-    def __init__(self, capacity, ghost_capacity, params, z_lo, z_hi, device_index=0):
+    def __init__(self, capacity, ghost_capacity, params, z_lo, z_hi, device_index=0, ghost_layers=1):
         import sys
         if capi._lib is not None and not capi._torch_first and "torch" not in sys.modules:
             raise capi.SphError("libsph_hip.so was loaded before torch was imported: import torch first "
@@ -226,7 +228,7 @@ class HipEngine:
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
         self.ctx = capi.Context(capacity, params=params, device=device_index, slab=(z_lo, z_hi),
-                                ghost_capacity=ghost_capacity)
+                                ghost_capacity=ghost_capacity, ghost_layers=ghost_layers)
         self.ghost_capacity = ghost_capacity
 
     def buffer(self, rows, cols):
@@ -278,7 +280,7 @@ class HipEngine:
 # ------------------------------------------------------------------------------------------------
 class SlabSimulation:
     def __init__(self, comm, engine_factory, box, grid, lattice=None, jitter=True, jitter_dims=None,
-                 capacity_factor=1.5, ghost_factor=3.0, particles=None, capacity_slack=4096, device_lattice=None):
+                 capacity_factor=1.5, ghost_factor=3.0, particles=None, capacity_slack=4096, device_lattice=None, min_layers=None):
         """comm: TorchDistComm | LocalComm.  engine_factory(capacity, ghost_capacity, params, z_lo, z_hi)
         builds this rank's engine.  Either `lattice` (dam break generated slab by slab) or
         `particles` = (pos, vel) of the WHOLE system (small tests)."""
@@ -291,6 +293,7 @@ class SlabSimulation:
         self.box = tuple(float(b) for b in box)
         self.grid = tuple(int(g) for g in grid)
         self.params = capi.default_params(self.box, self.grid)
+        self.min_layers = int(min_layers or MIN_SLAB_LAYERS)
         gz = self.grid[2]
         if device_lattice is None:         # the product engine generates its lattice layers on the device when it can
             device_lattice = getattr(engine_factory, "device_lattice", False)
@@ -301,7 +304,7 @@ class SlabSimulation:
             self.total = int(pos_all.shape[0])
             layers = cell_layer_of(pos_all[:, 2], self.box[2], gz)
             hist = np.bincount(layers, minlength=gz)
-            self.cuts = choose_cuts(hist, self.world)
+            self.cuts = choose_cuts(hist, self.world, self.min_layers)
             z_lo, z_hi = self.cuts[self.rank], self.cuts[self.rank + 1]
             mine = np.nonzero((layers >= z_lo) & (layers < z_hi))[0]
             pos, vel, index = pos_all[mine], vel_all[mine], mine.astype(np.uint32)
@@ -319,7 +322,7 @@ class SlabSimulation:
                                             jitter_dims=jd)
                 hist += np.bincount(cell_layer_of(p[:, 2], self.box[2], gz), minlength=gz)
             hist = comm.allreduce_sum(hist).astype(np.int64)
-            self.cuts = choose_cuts(hist, self.world)
+            self.cuts = choose_cuts(hist, self.world, self.min_layers)
             z_lo, z_hi = self.cuts[self.rank], self.cuts[self.rank + 1]
             # lattice layers that can reach this slab: every layer whose particles hashed into it
             spacing, radius = float(ic.SPACING), float(ic.PARTICLE_RADIUS)
@@ -464,7 +467,7 @@ class SlabSimulation:
         counts = [int(hist[a:b].sum()) for a, b in zip(self.cuts, self.cuts[1:])]
         if max(counts) <= (1.0 + tolerance) * self.total / self.world:
             return None                                    # still balanced: keep the cuts
-        cuts = choose_cuts(hist, self.world)
+        cuts = choose_cuts(hist, self.world, self.min_layers)
         return None if cuts == self.cuts else cuts
 
     def rebalance(self, tolerance=0.02, cuts=None):
@@ -536,15 +539,16 @@ def slab_timing_dict(slab_handle):
     over the steps since the last reset, waits_ready (the header was there before the host looked: host-paced steps), and per
     message group {calls, mean, max} of the event pairs on the comm stream (only while sph_slab_timing_enable)."""
     import ctypes as C
-    w = (C.c_double * 22)()
+    w = (C.c_double * 28)()
     capi._check(capi.load().sph_slab_timing_get(slab_handle, w))
     n = max(w[0], 1.0)
     out = {"steps": int(w[0]), "waits_ready": int(w[1])}
     for k, name in enumerate(("host_wait_us", "host_pre_us", "host_post_us", "host_step_us")):
         out[name] = {"mean": w[2 + 2 * k] / n, "max": w[3 + 2 * k]}
-    for g, name in enumerate(("migrants", "halo_a", "halo_b", "migrants_rest")):
-        c = w[10 + 3 * g]
-        out["exchange_us_" + name] = {"calls": int(c), "mean": w[11 + 3 * g] / c if c else None, "max": w[12 + 3 * g]}
+    for g, name in enumerate(_GROUPS):       # the three-group protocol's four tags, then the one-message protocol's two
+        at = 10 + 3 * g
+        c = w[at]
+        out["exchange_us_" + name] = {"calls": int(c), "mean": w[at + 1] / c if c else None, "max": w[at + 2]}
     return out
 
 
@@ -627,7 +631,17 @@ class NativeSlabSimulation(SlabSimulation):
                f"(on while the two messages + {cls.EARLY_FORCE_SLACK_US:.0f} us exceed it)")
         return bool(slow and exposed), why
 
-    def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, ping_reps=3, early_force="auto", **kw):
+    def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, ping_reps=3, early_force="auto",
+                 protocol=3, **kw):
+        """protocol: 3 = MIGRANTS / HALO A / HALO B (three dependent message groups per step); 1 = the one-message step
+        (sph_slab_set_protocol: two ghost layers, ghost densities recomputed locally; slabs of >= 4 cell layers).  The same on
+        every rank."""
+        if protocol not in (1, 3):
+            raise ValueError("protocol is 1 (one message per step) or 3")
+        self.protocol = int(protocol)
+        if self.protocol == 1:
+            kw.setdefault("min_layers", 4)
+            kw.setdefault("ghost_factor", 5.0)             # two layers of ghosts per side
         self._device_index = device_index
         self._transport_kind = transport
         self._migrant_capacity = migrant_capacity
@@ -638,8 +652,11 @@ class NativeSlabSimulation(SlabSimulation):
         self.early_force = None            # {"on": bool, "why": str}
         self.ping = None               # {bytes: {"mean_us", "max_us"}} of the preflight, per message size of a step
         self.rccl = None               # what the RCCL communicator says about itself (sph_rccl_transport_info)
+        # (SPH_SLAB_GHOST_LAYERS=2: the three-group protocol on contexts with two ghost layers -- a test of the layer numbering)
+        ghost_layers = 2 if self.protocol == 1 or os.environ.get("SPH_SLAB_GHOST_LAYERS") == "2" else 1
+
         def factory(cap, gcap, p, z0, z1):
-            return HipEngine(cap, gcap, p, z0, z1, device_index)
+            return HipEngine(cap, gcap, p, z0, z1, device_index, ghost_layers)
         factory.device_lattice = True
         super().__init__(comm, factory, box, grid, **kw)
         self._bind()
@@ -671,6 +688,8 @@ class NativeSlabSimulation(SlabSimulation):
         h = C.c_void_p()
         capi._check(L.sph_slab_create(C.byref(h), self.engine.ctx.h, self.rank, self.world, tr, int(self._migrant_capacity)))
         self._slab = h
+        if self.protocol == 1:
+            capi._check(L.sph_slab_set_protocol(self._slab, 1))
         if self._transport_kind == "rccl" and self.rccl is None:
             info = (C.c_int * 4)()
             capi._check(L.sph_rccl_transport_info(self._tr, info))
@@ -773,6 +792,9 @@ class NativeSlabSimulation(SlabSimulation):
         ef = (C.c_uint64 * 2)()
         capi._check(capi.load().sph_slab_early_force_stats(self._slab, ef))
         self.stats["early_force_launches"], self.stats["early_force_used"] = int(ef[0]), int(ef[1])
+        pr = (C.c_uint64 * 3)()
+        capi._check(capi.load().sph_slab_protocol(self._slab, pr))
+        self.stats["protocol"], self.stats["one_message_steps"], self.stats["one_message_rests"] = int(pr[0]), int(pr[1]), int(pr[2])
 
     def sync(self):
         capi._check(capi.load().sph_slab_sync(self._slab))
@@ -789,7 +811,7 @@ class NativeSlabSimulation(SlabSimulation):
             counts = [int(hist[a:b].sum()) for a, b in zip(self.cuts, self.cuts[1:])]
             if max(counts) <= (1.0 + tolerance) * self.total / self.world:
                 return False                               # balanced: nothing moves
-            cuts = choose_cuts(hist, self.world)
+            cuts = choose_cuts(hist, self.world, self.min_layers)
         cuts = [int(c) for c in cuts]
         if cuts == self.cuts:
             return False
@@ -853,7 +875,7 @@ def gather_rows(comm, row):
     return np.where(m <= -1e299, np.nan, m)
 
 
-_GROUPS = ("migrants", "halo_a", "halo_b", "migrants_rest")
+_GROUPS = ("migrants", "halo_a", "halo_b", "migrants_rest", "one", "one_rest")
 _HOST = ("host_wait_us", "host_pre_us", "host_post_us", "host_step_us")
 
 

@@ -107,6 +107,13 @@ int sph_create(sph_ctx** out, int device, uint32_t capacity, const sph_params* p
  * one ghost layer on either side (up to ghost_capacity particles each). */
 int sph_create_slab(sph_ctx** out, int device, uint32_t capacity, const sph_params* p,
                     uint32_t z_lo, uint32_t z_hi, uint32_t ghost_capacity);
+/* The same with `ghost_layers` = 1 or 2 ghost cell layers per side (sph_create_slab: 1).  Two are what the ONE-MESSAGE slab
+ * step needs (sph_slab_set_protocol): a rank then holds two layers of each neighbour's particles and recomputes the densities
+ * of the inner one itself, instead of receiving them in a message of their own.  ghost_capacity then bounds the particles
+ * of BOTH layers of a side. */
+int sph_create_slab_layers(sph_ctx** out, int device, uint32_t capacity, const sph_params* p,
+                           uint32_t z_lo, uint32_t z_hi, uint32_t ghost_capacity, uint32_t ghost_layers);
+uint32_t sph_ghost_layers(const sph_ctx* c);        /* 0 for a whole-domain context */
 void sph_destroy(sph_ctx* c);                       /* freeArray x4, particleSystem.cpp:180-183 */
 int sph_set_stream(sph_ctx* c, void* hip_stream);   /* hipStream_t; NULL = default stream */
 int sph_set_params(sph_ctx* c, const sph_params* p);/* the per-update SimParams upload, :723 */
@@ -286,7 +293,9 @@ int sph_layer_histogram(sph_ctx* c, uint32_t* hist, uint32_t n_layers);
  *                    receives are complete (several slabs of one GPU in one process; processes over gloo).
  * Return 0 or a negative SPH_E* code. */
 enum { SPH_TAG_MIGRANTS = 1, SPH_TAG_HALO_A = 2, SPH_TAG_HALO_B = 3, SPH_TAG_MIGRANTS_REST = 4, SPH_TAG_PING = 5,
-       SPH_TAG_RECUT_COUNTS = 6, SPH_TAG_RECUT = 7 };
+       SPH_TAG_RECUT_COUNTS = 6, SPH_TAG_RECUT = 7,
+       SPH_TAG_ONE = 8,        /* the one-message step: header + leavers + two layers of residents, size fixed in advance */
+       SPH_TAG_ONE_REST = 9 }; /* ... and what did not fit that size (exact; a burst) */
 /* ZERO-INITIALISE the struct before filling it in (`sph_transport t = {0};`): sph_slab_create copies it by value, and
  * members added at its end (so far: `abort`, ABI v2 of round 4) must read as NULL in a caller built against an older
  * header -- there is no size field, a garbage `abort` pointer would be called on the first failure. */
@@ -396,7 +405,8 @@ enum {
     SPH_SLAB_T_WAIT = 2,   /* [2] sum, [3] max */
     SPH_SLAB_T_PRE = 4, SPH_SLAB_T_POST = 6, SPH_SLAB_T_HOST = 8,
     SPH_SLAB_T_GROUPS = 10, /* + 3 * (tag - 1): {calls, sum us, max us} for SPH_TAG_MIGRANTS, _HALO_A, _HALO_B, _MIGRANTS_REST */
-    SPH_SLAB_T_WORDS = 22
+    SPH_SLAB_T_GROUPS_ONE = 22, /* {calls, sum us, max us} for SPH_TAG_ONE, then for SPH_TAG_ONE_REST (the one-message protocol) */
+    SPH_SLAB_T_WORDS = 28
 };
 int sph_slab_timing_enable(sph_slab* s, int on);
 int sph_slab_timing_reset(sph_slab* s);
@@ -414,6 +424,20 @@ int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]);
  * number of slots (environment: SPH_SLAB_EARLY_SPAN).  A slab without neighbours (world 1) never launches it.  Same bits either way.
  * out = {steps that launched it, steps that used its result} (a step whose arrivals re-sort the slab discards it). */
 int sph_slab_set_early_force(sph_slab* s, int on);
+/* The message protocol of a step.  3 (default): MIGRANTS (header + leavers) -> the host's wait -> HALO A (boundary layers) ->
+ * HALO B (their densities), three dependent groups per step.  1: ONE group -- header, leavers and the RESIDENTS of the two
+ * cell layers next to each cut in one message per neighbour ("a 2-layer halo, ghost densities recomputed
+ * locally (one message)"): the receiver merges its own leavers into the copy (the order the neighbour will give them), computes
+ * the densities of the inner ghost layer itself -- same candidates, same order, same bits in fp32 -- and the force pass needs no
+ * message.  The message's size is fixed in advance by a rule on the counts both ends saw in the previous step's headers (margin
+ * 1/16 + 1024 records); what does not fit follows in an exact second message (out[2] counts those); the first step after
+ * sph_slab_create / sph_slab_recut / this call runs the three-group protocol to learn the counts.  Needs a context with two
+ * ghost layers (sph_create_slab_layers) and slabs of >= 4 cell layers; a particle that crosses more than TWO layers in a step is
+ * SPH_E_STATE under it.  COLLECTIVE in effect: every rank of the chain must run the same protocol.  Price: ~2x the halo bytes and
+ * the density of one more layer per side; gain: two message latencies off the step's critical path.
+ * sph_slab_protocol: out = {protocol, one-message steps so far, of which needed the second message}. */
+int sph_slab_set_protocol(sph_slab* s, int groups);
+int sph_slab_protocol(const sph_slab* s, uint64_t out[3]);
 int sph_slab_early_force_stats(const sph_slab* s, uint64_t out[2]);
 /* TEST HOOK: sph_upload / sph_set_by_index / sph_reset_lattice / sph_set_params make the next five movers' sorts of a
  * whole-domain context launch BOTH forms (the caller may have changed every particle: the count the device last reported says

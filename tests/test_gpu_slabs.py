@@ -27,7 +27,7 @@ def _comm(hub, dev_hub, r):
 
 
 def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport="local", rebalance_every=0, expect_error=False,
-               early_force="auto"):
+               early_force="auto", protocol=3):
     hub = slab.LocalComm.Hub(world)
     dev_hub = capi.LocalHub(world, timeout_s=60) if transport == "local" else None
     results, errors = [None] * world, []
@@ -35,7 +35,7 @@ def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport=
     def rank_main(r):
         try:
             sim = slab.NativeSlabSimulation(_comm(hub, dev_hub, r), box, grid, device_index=0, transport=transport,
-                                            particles=particles, lattice=lattice, early_force=early_force)
+                                            particles=particles, lattice=lattice, early_force=early_force, protocol=protocol)
             cuts0 = list(sim.cuts)
             handles0 = (sim.engine.ctx.h.value, sim._slab.value)
             sim.run(DT, steps, rebalance_every=rebalance_every)
@@ -93,6 +93,29 @@ def test_slabs_with_migration_match_whole_domain(case, world, transport):
     arrivals, in_place = sum(r[1]["resorts"] for r in res), sum(r[1]["in_place_merges"] for r in res)
     assert arrivals > 0 and in_place == arrivals, "arrivals join their boundary layer in place (k_slab_insert)"
     if case == "tall_up":        # slabs of 12 owned layers: the innermost layers' force pass runs in front of the wait, arrivals or not
+        assert all(r[1]["early_force_used"] == steps for r in res), [r[1] for r in res]
+    _same_bits(st, ref)
+
+
+@pytest.mark.parametrize("case,world,transport", [("up", 3, "local"), ("shear", 3, "local"), ("down", 3, "local"), ("up", 3, "host"),
+                                                  ("tall_up", 2, "local"), ("tall_up", 2, "host")])
+def test_one_message_step_matches_whole_domain_bit_for_bit(case, world, transport):
+    """The ONE-MESSAGE protocol (sph_slab_set_protocol(s, 1); SURVEY.md section 8e "a 2-layer halo, ghost densities recomputed
+    locally (one message)"): header, leavers and the residents of two layers per side in one group per step, the receiver merges
+    its own leavers into its copy of the neighbour's layers and computes the inner ghost layer's densities itself -- same
+    candidates, same order, so still the bits of the one-context run.  The first step learns the message sizes under the
+    three-group protocol; every later step is one transport call (+ one when a message outgrew the size fixed in advance)."""
+    pos, vel, box, grid = make_case(case)
+    steps = 24
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, early_force=(case == "tall_up"), protocol=1)
+    st = res[0][0]
+    ref = _whole_domain(pos, vel, box, grid, steps)
+    assert sum(r[1]["migrants"] for r in res) > 0 and sum(r[3] for r in res) == pos.shape[0]
+    assert all(r[1]["protocol"] == 1 and r[1]["one_message_steps"] == steps - 1 for r in res), [r[1] for r in res]
+    assert all(r[1]["host_waits"] == steps for r in res), "one host wait per step and rank"
+    assert all(r[1]["exchanges"] == 3 + r[1]["rest_messages"] + (steps - 1) + r[1]["one_message_rests"] for r in res), [r[1] for r in res]
+    assert sum(r[1]["resorts"] for r in res) > 0
+    if case == "tall_up":
         assert all(r[1]["early_force_used"] == steps for r in res), [r[1] for r in res]
     _same_bits(st, ref)
 
