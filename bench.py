@@ -188,16 +188,21 @@ def cpu_baseline(budget_s=24.0, headline=None):
 def pmc_child(args):
     """`bench.py --pmc-child <snapshot>` (started under rocprofv3 by pmc_traffic below): the flowing state the parent saved,
     W + K more steps of it.  Nothing is printed; the profiler's counter CSV is the output."""
-    n, _ = capi.Context.snapshot_info(args.pmc_child)
-    cfg = ic.CONFIGS[args.workload]
-    with capi.Context(n, box=cfg["box"], grid=cfg["grid"], device=0) as c:
+    n, p = capi.Context.snapshot_info(args.pmc_child)
+    if args.pmc_slab:       # an N > 1 run's rank 0: its slab's particles stepped ALONE (no neighbours: the boundary layers see no ghosts)
+        z_lo, z_hi = (int(v) for v in args.pmc_slab.split(","))
+        c = capi.Context(n + 4096, params=p, device=args.pmc_device, slab=(z_lo, z_hi), ghost_capacity=1024)
+    else:
+        cfg = ic.CONFIGS[args.workload]
+        c = capi.Context(n, box=cfg["box"], grid=cfg["grid"], device=args.pmc_device)
+    with c:
         c.set_precision(args.precision == "mixed")
         c.load_snapshot(args.pmc_child)
         c.step(float(ic.DEFAULT_DT), args.warmup + args.steps)
         c.sync()
 
 
-def pmc_traffic(ctx, args, steps=20, warmup=5, timeout_s=240):
+def pmc_traffic(ctx, args, steps=20, warmup=5, timeout_s=240, slab=None, device=0):
     """FETCH_SIZE and WRITE_SIZE of k_force<1,1,1> and k_density per launch, measured on the state of this run's timed window:
     the context is saved to a snapshot, and a child process (this script, --pmc-child) steps it under `rocprofv3 --pmc`,
     one pass per counter as MI355X_MICROARCH.md prescribes for gfx950 (the two cannot share a pass; --pmc alone, no trace
@@ -221,7 +226,9 @@ def pmc_traffic(ctx, args, steps=20, warmup=5, timeout_s=240):
             names = [counter] if counter != "SQ" else ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"]
             cmd = [exe, "--pmc"] + names + ["--kernel-include-regex", "k_force|k_density", "--output-format", "csv", "-d", d, "-o", "p",
                    "--", sys.executable, os.path.abspath(__file__), "--pmc-child", snap, "--workload", args.workload, "--precision",
-                   args.precision, "--steps", str(steps), "--warmup", str(warmup)]
+                   args.precision, "--steps", str(steps), "--warmup", str(warmup), "--pmc-device", str(device)]
+            if slab is not None:
+                cmd += ["--pmc-slab", f"{slab[0]},{slab[1]}"]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -373,6 +380,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic for this run")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-slab", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of host time for the cpu_baseline probe (four legs)")
+    ap.add_argument("--protocol", type=int, default=3, choices=[1, 3],
+                    help="slab path: 3 = MIGRANTS / HALO A / HALO B per step; 1 = the one-message step (two ghost layers, ghost "
+                         "densities recomputed locally: sph_slab_set_protocol)")
     ap.add_argument("--force-slab", action="store_true", help="run the z-slab path even with one rank (testing)")
     ap.add_argument("--periodic-z", action="store_true",
                     help="with --force-slab: ONE slab between its own periodic images (loop transport) -- a middle rank's whole step, "
@@ -501,7 +514,7 @@ def main():
         label = (f"HEADLINE config: dam-break {args.workload}, {n} particles, grid {cfg['grid'][0]}^3, the flowing state of the "
                  f"GPU's timed window (after {args.runup} + {args.warmup} + 2 x {args.steps} steps), ONE step, one run; "
                  "team sizes from the 262,144-particle probe (small_sample)")
-        cb = cpu_baseline(headline=(cfg, pos_f, vel_f, label))
+        cb = cpu_baseline(budget_s=args.cpu_budget, headline=(cfg, pos_f, vel_f, label))
         out["cpu_baseline"] = cb
         out["gpu_over_cpu"] = value / cb["value"]
     print(json.dumps(out), flush=True)

@@ -260,19 +260,10 @@ constexpr int UNROLL = SPH_DENS_UNROLL;        // density: candidates per unroll
 #ifndef SPH_FORCE_UNROLL
 #define SPH_FORCE_UNROLL 2
 #endif
-// 1: the collision impulse uses sqrtf and a true division like the reference (dot / (dij * dij)); 0: one v_rcp_f32
-// of r2 (1 ulp).  The PREDICATES are exact either way; this only moves the last bit of the impulse (A/B in DESIGN 4).
-#ifndef SPH_COLL_EXACT_DIV
-#define SPH_COLL_EXACT_DIV 0
-#endif
 // 1: IEEE divisions in the integrate / collision epilogue as the reference writes them (kernelIntegrate f / rho,
 // particleSystem.cu:375-420; kernelComputeCollisions :299); 0 (product): one v_rcp_f32 each.  A/B knob, see integrate_one.
 #ifndef SPH_EXACT_DIV
 #define SPH_EXACT_DIV 0
-#endif
-// 1: viscosity accumulated as sum w_j v_j and sum w_j (see k_force); 0: as sum w_j (v_j - v_i), for A/B runs
-#ifndef SPH_VISC_SPLIT
-#define SPH_VISC_SPLIT 1
 #endif
 
 // Per-row hulls of the wave's candidate ranges (wave-uniform).
@@ -332,15 +323,11 @@ __device__ __forceinline__ void traverse(const Hulls& H, Load&& load, Store&& st
 // OWN candidates from global memory (gathers), row by row -- the same candidates in the same order through the same
 // arithmetic, so a particle's sums have the same bits whichever way its wave goes.  One copy of that loop per kernel,
 // in a branch of its own (a copy per unrolled row cost k_force a spill).
-#ifndef SPH_DIRECT_ROWS
-#define SPH_DIRECT_ROWS 1            // 0: no direct walk at all (A/B runs)
-#endif
 // `key` is the lane's own cell key.  Pre-filter: a hull covers the cells [first key - 1, last key + 1] shifted by the
 // row's offset, so a wave whose keys span at most 64 cells (any ordinary wave: 64 particles at ~8 per cell span ~8) has
 // hulls of at most 66 cells -- long only at > 30 particles per cell, which is dense, not pathological.  Two v_readlane,
 // a subtraction and a compare for those; the nine exact tests only for waves that straddle a row end or are sparse.
 __device__ __forceinline__ bool wave_has_long_hull(const Hulls& H, uint32_t key, uint32_t direct_hull) {
-    if (!SPH_DIRECT_ROWS) return false;
     const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, 63);
     if (k1 - k0 <= 64u && direct_hull >= 128u) return false;        // (thresholds below 128 are test settings: always the exact test)
     bool any = false;
@@ -381,20 +368,10 @@ struct Targets {
 // blocks are dispatched first, then the others in order: on the thin slab whose outer layer is sparse `k_force` 0.302
 // -> 0.276 ms and `k_density` 0.135 -> 0.130 (the times of the state without sparse layers), C3 unchanged
 // (profiles/r04_rotate_dispatch_experiment.txt).  Dispatching everything backwards does the same for the tail but costs
-// C3 3.5 % of wall clock (-DSPH_PAIR_REVERSE=1, profiles/r04_reverse_dispatch_experiment.txt).
-#ifndef SPH_PAIR_REVERSE
-#define SPH_PAIR_REVERSE 0
-#endif
-#ifndef SPH_PAIR_ROTATE
-#define SPH_PAIR_ROTATE 1
-#endif
+// C3 3.5 % of wall clock (profiles/r04_reverse_dispatch_experiment.txt).
 __device__ __forceinline__ uint32_t pair_block() {
-    if (SPH_PAIR_REVERSE) return gridDim.x - 1u - blockIdx.x;
-    if (SPH_PAIR_ROTATE) {
-        const uint32_t rot = max(gridDim.x >> 6, 1u);
-        return blockIdx.x < rot ? gridDim.x - rot + blockIdx.x : blockIdx.x - rot;
-    }
-    return blockIdx.x;
+    const uint32_t rot = max(gridDim.x >> 6, 1u);
+    return blockIdx.x < rot ? gridDim.x - rot + blockIdx.x : blockIdx.x - rot;
 }
 
 __device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, uint32_t lane, uint32_t& i, uint32_t& hi,
@@ -416,42 +393,29 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
                                                                         const uint2* __restrict__ cells,
                                                                         float2* __restrict__ dp, float2* __restrict__ cw,
                                                                         Targets tg, GridDesc g, Phys ph) {
-#ifndef SPH_DENS_SKEW
-#define SPH_DENS_SKEW 0      // 1: one pad entry per 32 (entries 32 apart then sit on different banks); experiment, see DESIGN 5
-#endif
-#if SPH_DENS_SKEW
-#define DSK(j) ((j) + ((j) >> 5))
-#else
-#define DSK(j) (j)
-#endif
-    // SPH_DENS_ZZ (round 5): the z coordinates of TWO neighbouring candidates come out of ONE ds_read_b64.  The LDS pipe
+    // Round 5: the z coordinates of TWO neighbouring candidates come out of ONE ds_read_b64.  The LDS pipe
     // charges an instruction by its bytes with 8 as the minimum -- a ds_read_b32 costs what a ds_read_b64 costs, 1.1 ns per
     // wave-instruction and CU (profiles/r02_lds_read_rates.txt) -- so {x, y} as a b64 plus z as a b32 paid for 16 bytes per
     // candidate and used 12.  Now a group of four candidates is four b64 {x, y} + two b64 {z, z}: 6 reads instead of 8, on
     // the pipe that is 87 % busy in this kernel.  A lane's range may start at an odd entry: the z array is kept twice,
     // s_z[j] = z_j and s_zo[j] = z_(j+1), and a lane reads pairs from the copy in which ITS first candidate sits at an
     // even index (two more ds_write_b32 per staged piece and lane).  Same candidates, same order, same arithmetic: the
-    // sums keep their bits.
-#ifndef SPH_DENS_ZZ
-#define SPH_DENS_ZZ (!SPH_DENS_SKEW && (SPH_DENS_UNROLL % 2 == 0))
-#endif
-    constexpr int DENS_LDS = (DENS_WAVES + 1) * PIECE + 8;          // as LDS_ENT, for this kernel's block
-    constexpr int DENS_ENT = SPH_DENS_SKEW ? DENS_LDS + DENS_LDS / 32 + 2 : DENS_LDS;
+    // sums keep their bits.  (Tried and dropped, records in profiles/: one pad entry per 32 against the bank conflicts of entries
+    // 32 apart -- two more instructions per candidate, 1.37 ms against 0.96, r03; {x, y} b64 + z b32 per candidate, the form
+    // before this one, r05_density_zz_pairs_ab.txt.)
+    static_assert(UNROLL % 2 == 0, "the z-pair walk reads candidates two at a time");
+    constexpr int DENS_ENT = (DENS_WAVES + 1) * PIECE + 8;          // as LDS_ENT, for this kernel's block
     __shared__ float2 s_xy[DENS_ENT];
     __shared__ __attribute__((aligned(8))) float s_z[DENS_ENT];
-#if SPH_DENS_ZZ
     __shared__ __attribute__((aligned(8))) float s_zo_[DENS_ENT + 2];
     float* const s_zo = s_zo_ + 2;                                   // s_zo[-1] exists (the entry in front of the first slice)
-#endif
     // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
     if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)DENS_THREADS >= tg.dev[1]) return;
     for (uint32_t k = threadIdx.x; k < DENS_ENT; k += DENS_THREADS) {   // see LDS_ENT: keep over-reads finite
         s_xy[k] = make_float2(0.f, 0.f);
         s_z[k] = 0.f;
-#if SPH_DENS_ZZ
         s_zo_[k] = 0.f;
         if (k < 2u) s_zo_[DENS_ENT + k] = 0.f;
-#endif
     }
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -506,16 +470,14 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
             q1 = posi[a + WAVE + lane];
         },
         [&]() {
-            s_xy[DSK(slice + lane)] = make_float2(q0.x, q0.y);
-            s_z[DSK(slice + lane)] = q0.z;
-            s_xy[DSK(slice + WAVE + lane)] = make_float2(q1.x, q1.y);
-            s_z[DSK(slice + WAVE + lane)] = q1.z;
-#if SPH_DENS_ZZ
+            s_xy[slice + lane] = make_float2(q0.x, q0.y);
+            s_z[slice + lane] = q0.z;
+            s_xy[slice + WAVE + lane] = make_float2(q1.x, q1.y);
+            s_z[slice + WAVE + lane] = q1.z;
             // the shifted copy; entry slice - 1 belongs to the slice in front (or to the pad): only a lane's masked
             // over-read ever looks at a slice's last shifted entry, and whatever stands there is a finite z
             s_zo[(int)(slice + lane) - 1] = q0.z;
             s_zo[slice + WAVE + lane - 1u] = q1.z;
-#endif
         },
         [&](int r, uint32_t a, uint32_t b) {
             const uint32_t l0 = max(R.lo[r], a), l1 = min(R.hi[r], b);
@@ -524,7 +486,6 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
             uint32_t idx = slice + rel;
             // every lane has at least tmin candidates: that part of the walk needs no per-lane range test
             const uint32_t tmin = wave_min_u32_uniform_first(len) & ~(uint32_t)(UNROLL - 1);
-#if SPH_DENS_ZZ
             // z pairs: candidates (rel, rel + 1), (rel + 2, rel + 3), ... -- from s_z when rel is even, else from the copy
             // shifted by one, where candidate rel sits at the even index rel - 1
             lds_v2f_ptr zp = (lds_v2f_ptr)((rel & 1u) ? (const float*)s_zo : (const float*)s_z) + ((slice + rel) >> 1);
@@ -542,24 +503,6 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
             uint32_t t = 0;
             for (; t < tmin; t += UNROLL) group(t, false);
             for (; __ballot(t < len) != 0ull; t += UNROLL) group(t, true);    // until every lane is through its range
-#else
-            auto pair = [&](int u, bool valid) {
-                const v2f xy = ((lds_v2f_ptr)s_xy)[DSK(idx + u)];
-                const float z = ((lds_f32_ptr)s_z)[DSK(idx + u)];
-                pair_math(xy.x, xy.y, z, valid);
-            };
-            uint32_t t = 0;
-            for (; t < tmin; t += UNROLL) {
-#pragma unroll
-                for (int u = 0; u < UNROLL; u++) pair(u, true);
-                idx += UNROLL;
-            }
-            for (; __ballot(t < len) != 0ull; t += UNROLL) {   // until every lane is through its range
-#pragma unroll
-                for (int u = 0; u < UNROLL; u++) pair(u, t + u < len);
-                idx += UNROLL;
-            }
-#endif
         });
     finish();
 }
@@ -881,26 +824,11 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     // padding): one address register serves all four ds_read_b64 through immediate offsets, and the
     // 8-entry (one cell) distance between the lane groups of a wave is 80 dwords = 16 banks, so the four
     // distinct addresses of a half-wave never share a bank.
-    // SPH_FORCE_B128 = 1 (round 5, an experiment that did NOT pay; kept as an A/B knob): the same 32 bytes as TWO aligned
-    // ds_read_b128, {x,y,z,vx} {vy,vz,cp,w}, at a 48-byte stride (the third float4 is padding; a 32-byte stride puts lanes
-    // 8 entries apart on the same banks).  The bare loop liked it -- 41.5 -> 36.9 ns per candidate per SIMD at 5 waves per
-    // SIMD, profiles/r05_force_b128_experiment.txt: an LDS instruction costs the issuing SIMD VALU slots whatever it carries
-    // -- the kernel did not: SQ_INSTS_LDS 1,031 -> 556 per wave, but SQ_BUSY_CYCLES 1.707e8 -> 1.752e8 (+2.6 %) and the same
-    // 2.56 ms (with 85 % of the cells at 8 particles a b128 at any 16-byte-aligned stride is a two-way bank conflict, which
-    // the bare loop's independent fmas hid and the real dependency chain does not).
-#ifndef SPH_FORCE_B128
-#define SPH_FORCE_B128 0
-#endif
-#if SPH_FORCE_B128
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
-    __shared__ __attribute__((aligned(16))) float4 s_q[LDS_ENT * 3];
-    float2* const s_e = reinterpret_cast<float2*>(s_q);                  // (the zero-fill below: 6 float2 per entry)
-    constexpr int E2 = 6;
-#else
+    // (Round 5 tried the same 32 bytes as TWO aligned ds_read_b128 at a 48-byte stride: LDS instructions halve, SQ_BUSY_CYCLES +2.6 %,
+    // the same 2.56 ms -- at 8 particles per cell every 16-byte-aligned stride is a two-way bank conflict.  Not kept:
+    // profiles/r05_force_b128_experiment.txt.)
     constexpr int E2 = 5;
     __shared__ float2 s_e[LDS_ENT * 5];
-#endif
     // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
     if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)PAIR_THREADS >= tg.dev[1]) return;
     for (uint32_t k = threadIdx.x; k < LDS_ENT * E2; k += PAIR_THREADS)   // see LDS_ENT: keep over-reads finite
@@ -971,12 +899,8 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             const float w = wj * hr;                                // VISC m VISC_LAP (h-r) / rho_j
             const float s = (cpi + cpj) * w * (hr * rinv);          // m (p_i+p_j)/(2 rho_j) 45/(pi h^6) (h-r)^2 / r
             fpx += s * dx; fpy += s * dy; fpz += s * dz;
-#if SPH_VISC_SPLIT
             fvx += w * ux; fvy += w * uy; fvz += w * uz;            // sum w_j v_j  (v_i sum w_j: epilogue)
             sw += w;
-#else
-            fvx += w * (ux - vi.x); fvy += w * (uy - vi.y); fvz += w * (uz - vi.z);
-#endif
         }
         return r2 - coll_next_v;                                    // negative <=> within collision range
     };
@@ -998,12 +922,9 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             dot = -(dx * ux + (dy * uy + dz * uz));                 // r_ij . (v_i - v_j)
         }
         const bool hit = r2c <= ph.coll_dist2 && dot < 0.f;
-#if SPH_COLL_EXACT_DIV
-        float cfac = 0.f;
-        if (hit) { const float dij = sqrtf(r2c); cfac = ph.coll_mass * (dot / (dij * dij)); }
-#else
+        // (one v_rcp_f32 of r2, 1 ulp, for the reference's sqrtf and division dot / (dij * dij): the PREDICATES above are exact
+        // either way; with the exact form the free-run numbers were identical to 9 digits)
         const float cfac = hit ? ph.coll_mass * dot * __builtin_amdgcn_rcpf(r2c) : 0.f;
-#endif
         cvx += cfac * dx; cvy += cfac * dy; cvz += cfac * dz;
         ccount += hit ? 1u : 0u;
     };
@@ -1017,7 +938,7 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             PAIR_STAT(9, sum);
         }
 #endif
-        if (FORCE && SPH_VISC_SPLIT) { fvx = fmaf(-vi.x, sw, fvx); fvy = fmaf(-vi.y, sw, fvy); fvz = fmaf(-vi.z, sw, fvz); }
+        if (FORCE) { fvx = fmaf(-vi.x, sw, fvx); fvy = fmaf(-vi.y, sw, fvy); fvz = fmaf(-vi.z, sw, fvz); }
         bool moved = false;
         if (active) {
             float dvx = 0.f, dvy = 0.f, dvz = 0.f;
@@ -1084,16 +1005,6 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             if (FORCE) { e0 = cw[a + lane]; e1 = cw[a + WAVE + lane]; }
         },
         [&]() {
-#if SPH_FORCE_B128
-            float4* a0p = &s_q[(slice + lane) * 3];
-            float4* a1p = &s_q[(slice + WAVE + lane) * 3];
-            a0p[0] = make_float4(q0.x, q0.y, q0.z, w0.x);
-            a1p[0] = make_float4(q1.x, q1.y, q1.z, w1.x);
-            // {cp_j, w_j} as the density pass left them (neighbour_terms); padding entries hold 0: weight 0
-            a0p[1] = make_float4(w0.y, w0.z, FORCE ? e0.x : 0.f, FORCE ? e0.y : 0.f);
-            a1p[1] = make_float4(w1.y, w1.z, FORCE ? e1.x : 0.f, FORCE ? e1.y : 0.f);
-            return;
-#endif
             float2* e0p = &s_e[(slice + lane) * 5];
             float2* e1p = &s_e[(slice + WAVE + lane) * 5];
             e0p[0] = make_float2(q0.x, q0.y);
@@ -1121,17 +1032,11 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
             uint32_t near = 0u;
             PAIR_STAT(1, 1); PAIR_STAT(2, T);
             auto pair = [&](int u, bool valid) {
-#if SPH_FORCE_B128
-                const lds_v4f_ptr e = (lds_v4f_ptr)s_q + (idx + u) * 3;
-                const v4f qa = e[0], qb = e[1];
-                const float t = pair_math(qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, valid);
-#else
                 const lds_v2f_ptr e = (lds_v2f_ptr)s_e + (idx + u) * 5;
                 const v2f qa = e[0], qb = e[1];
                 v2f qc = {0.f, 0.f}, qd = {0.f, 0.f};
                 if (FORCE) { qc = e[2]; qd = e[3]; }
                 const float t = pair_math(qa.x, qa.y, qb.x, qb.y, qc.x, qc.y, qd.x, qd.y, valid);
-#endif
                 if (COLL) near = __builtin_amdgcn_alignbit(near, __float_as_uint(t), 31);   // (near << 1) | sign(t)
             };
             for (uint32_t t0 = 0; t0 < T; t0 += 32u) {
@@ -1166,15 +1071,9 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
                             const uint32_t hb = 31u - (uint32_t)__clz((int)near);
                             near &= ~(1u << hb);
                             const uint32_t ci = idx0 + (done - 1u - hb);
-#if SPH_FORCE_B128
-                            const float4* e = &s_q[(ci << 1) + ci];          // ci * 3 without v_mul_lo_u32
-                            const float4 qa = e[0], qb = e[1];
-                            collide_math(qa.x, qa.y, qa.z, qa.w, qb.x, qb.y);
-#else
                             const float2* e = &s_e[(ci << 2) + ci];          // ci * 5 without v_mul_lo_u32
                             const float2 qa = e[0], qb = e[1], qc = e[2];
                             collide_math(qa.x, qa.y, qb.x, qb.y, qc.x, qc.y);
-#endif
                         }
                     }
                 }

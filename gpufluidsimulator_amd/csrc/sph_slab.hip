@@ -431,9 +431,6 @@ __global__ __launch_bounds__(256) void k_slab_unpack(const float4* __restrict__ 
 // One thread per resident (counts the arrivals that go in front of it, from LDS) and per arrival (ranks itself among
 // the arrivals, binary search among the residents).  An arrival whose key is NOT in the expected layer would break
 // the order: it is flagged (the step then fails with SPH_E_STATE).
-#ifndef SPH_SLAB_INSERT
-#define SPH_SLAB_INSERT 1            // 0: arrivals always take the pass over all particles (launch_merge_arrivals)
-#endif
 constexpr uint32_t SLAB_INSERT_MAX = 2048;
 __global__ __launch_bounds__(256) void k_slab_insert(const float4* __restrict__ posi, const float4* __restrict__ velr,
                                                      const uint32_t* __restrict__ keyS, uint32_t l0, uint32_t nl,
@@ -1320,7 +1317,7 @@ int slab_step_body(sph_slab* s, float dt) {
         rc = after_comm(s); if (rc) return rc;                  // the received records are in mig_recv
         const bool merge = c->sort_merge && c->order_valid && c->cells_valid && c->cells_lo == c->own_off &&
                            c->cells_hi == c->own_off + c->n;
-        const bool in_place = SPH_SLAB_INSERT && merge && far_in_lo == 0 && far_in_hi == 0 && in_lo <= SLAB_INSERT_MAX &&
+        const bool in_place = merge && far_in_lo == 0 && far_in_hi == 0 && in_lo <= SLAB_INSERT_MAX &&
                               in_hi <= SLAB_INSERT_MAX && in_lo <= c->own_off && own_lo + own_hi <= c->n;
         if (in_place) {
             // only the two boundary layers are touched (see k_slab_insert): their cells leave the table, the merged

@@ -16,14 +16,10 @@ constexpr int SORT_THREADS = 256;            // 4 waves
 #ifndef SPH_SORT_KPT
 #define SPH_SORT_KPT 16
 #endif
-// 1: the ranked pairs of a tile are parked in LDS in digit order and written out with neighbouring threads on
-// neighbouring addresses; 0: every lane stores its pair straight from registers (uncoalesced, but 8 KB of LDS
-// per block instead of 40: three times the waves per CU)
-// (tried: keys and values taking turns in ONE 16 KB buffer, 26 KB of LDS per block -- the registers that hold the
-// tile positions meanwhile cost more waves than the LDS frees: 137-177 us per pass against 106)
-#ifndef SPH_SORT_STAGE
-#define SPH_SORT_STAGE 1
-#endif
+// The ranked pairs of a tile are parked in LDS in digit order and written out with neighbouring threads on neighbouring
+// addresses.  (Tried and dropped: every lane storing its pair straight from registers -- uncoalesced, 8 KB of LDS per block
+// instead of 40; keys and values taking turns in ONE 16 KB buffer, 26 KB of LDS per block -- the registers that hold the
+// tile positions meanwhile cost more waves than the LDS frees: 137-177 us per pass against 106.)
 constexpr int SORT_KPT = SPH_SORT_KPT;       // keys per thread
 constexpr int SORT_TILE = SORT_THREADS * SORT_KPT;       // 4096 keys per block
 
@@ -257,9 +253,7 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
     static_assert(DPT <= 2, "a thread publishes at most two digits in one store");
     __shared__ uint32_t wh[PASS_WAVES][RADIX];      // per-wave digit counts -> running positions inside the tile
     __shared__ uint32_t s_delta[RADIX];             // global position minus LDS position of a digit's keys of this tile
-#if SPH_SORT_STAGE
     __shared__ uint32_t s_key[OS_TILE], s_val[OS_TILE];
-#endif
     __shared__ uint32_t s_wtot[PASS_WAVES];
     __shared__ uint32_t s_tile;
     const uint32_t n = sort_count(n_arg, n_dev);
@@ -383,9 +377,6 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
         // an LDS-typed pointer: a generic `volatile uint32_t*` made every access a flat_load/flat_store with sc0 sc1
         // and a full s_waitcnt behind it
         const lds_u32_ptr pos = (lds_u32_ptr)wh[wave];
-#if !SPH_SORT_STAGE
-        uint32_t lpos[PASS_KPT];                            // position of the key inside the tile (digit order)
-#endif
 #pragma unroll
         for (int t = 0; t < PASS_KPT; t++) {
             if (GROUPED && t == PASS_KPT / 2 && has_d) {
@@ -420,11 +411,7 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
             os_wave_lds_order();
             if (valid && rank == 0) pos[d] = base + (uint32_t)__popc(peers_lo) + (uint32_t)__popc(peers_hi);   // LDS is in order per wave
             os_wave_lds_order();
-#if SPH_SORT_STAGE
             if (valid) { s_key[base + rank] = key[t]; s_val[base + rank] = val[t]; }
-#else
-            lpos[t] = base + rank;
-#endif
         }
 
         OS_STAT(4);                                 // rank (thread 0's wave)
@@ -508,7 +495,6 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
         __syncthreads();
         OS_STAT(6);                                 // waiting for the slowest wave
 
-#if SPH_SORT_STAGE
         // write out in LDS (= digit) order: a digit's keys go to consecutive addresses
         const uint32_t tile_n = min((uint32_t)OS_TILE, n - tile * OS_TILE);
 #pragma unroll 4
@@ -522,17 +508,6 @@ __global__ __launch_bounds__(PASS_THREADS, SPH_OS_PASS_OCC) void k_os_pass(const
                 vout[dst] = s_val[q];
             }
         }
-#else
-#pragma unroll
-        for (int t = 0; t < PASS_KPT; t++) {
-            const uint32_t i = wbase + t * WAVE + lane;
-            if (i < n) {
-                const uint32_t dst = s_delta[(key[t] >> shift) & (RADIX - 1)] + lpos[t];
-                kout[dst] = key[t];
-                vout[dst] = val[t];
-            }
-        }
-#endif
         OS_STAT(7);                                 // write-out issued
         __syncthreads();                                    // LDS is re-used by the next tile
         OS_STAT(8);
@@ -873,18 +848,12 @@ struct SmallTail {
 };
 enum { SORT_FORM_BOTH = 0, SORT_FORM_SMALL = 1, SORT_FORM_BIG = 2 };
 
-#ifndef SPH_OS_SMALL
-#define SPH_OS_SMALL 1          // 0: never take the one-block sort (A/B runs)
-#endif
-#ifndef SPH_OS_FORM_HINT
-#define SPH_OS_FORM_HINT 1      // 0: a whole-domain context always launches both forms of the movers' sort (A/B runs)
-#endif
 template <int BITS>
 static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32_t grid, bool first, uint32_t passes,
                            uint32_t*& kin, uint32_t*& vin, uint32_t*& kout, uint32_t*& vout, const SmallTail& tail) {
     constexpr uint32_t RADIX = 1u << BITS;
     // counts the device may hand to the one-block sort (only when the count lives on the device: the movers' sort)
-    uint32_t small_max = (SPH_OS_SMALL && n_dev && !first) ? OS_SMALL_MAX : 0u;
+    uint32_t small_max = (n_dev && !first) ? OS_SMALL_MAX : 0u;
     // The count lives on the device, so in general BOTH forms are launched and each looks at the count first -- six
     // dispatches that do nothing when the one-block sort takes it (37 us of a 0.63 ms slab step).  A host-paced context
     // (a slab: its host waits for the device once per step) knows the count of the PREVIOUS sort exactly, and the movers
@@ -895,7 +864,7 @@ static int radix_sort_bits(sph_ctx* c, uint32_t n, const uint32_t* n_dev, uint32
     // quarter of the one-block sort's capacity as the margin for what four steps can change, and both forms in between.
     int form = SORT_FORM_BOTH;
     if (small_max && c->host_paced) form = tail.hint <= OS_SMALL_MAX ? SORT_FORM_SMALL : SORT_FORM_BIG;
-    else if (small_max && SPH_OS_FORM_HINT && tail.hint != 0xFFFFFFFFu && c->sort_calls > c->sort_form_both_until)
+    else if (small_max && tail.hint != 0xFFFFFFFFu && c->sort_calls > c->sort_form_both_until)
         form = tail.hint <= OS_SMALL_MAX - OS_SMALL_MAX / 4u ? SORT_FORM_SMALL
              : (tail.hint > OS_SMALL_MAX + OS_SMALL_MAX / 4u ? SORT_FORM_BIG : SORT_FORM_BOTH);
     if (tail.form) *tail.form = form;
@@ -1324,7 +1293,7 @@ static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_
     if (form != SORT_FORM_SMALL) {                              // (the one-block sort ranks the tile boundaries itself)
         const uint32_t rank_tiles = ceil_div(n, MM_RANK_TILE) + 1u;
         hipLaunchKernelGGL(k_mm_tile_rank, dim3(ceil_div(rank_tiles, 256u)), dim3(256), 0, c->stream, A, n, mk, mi, c->mm_count,
-                           c->mm_tileL, c->mm_tileA, SPH_OS_SMALL && form == SORT_FORM_BOTH, OS_SMALL_MAX, front);
+                           c->mm_tileL, c->mm_tileA, form == SORT_FORM_BOTH, OS_SMALL_MAX, front);
         SPH_HIP(hipGetLastError());
     }
     uint32_t* perm = c->keep_perm ? c->v1 : (uint32_t*)nullptr;

@@ -955,7 +955,8 @@ def bench_rank(comm, local, args, transport, log=None):
     cfg, strong, label = bench_config(args, world)
     ef = {"on": True, "off": False}.get(getattr(args, "early_force", "auto"), "auto")
     sim = NativeSlabSimulation(comm, cfg["box"], cfg["grid"], device_index=local, transport=transport,
-                               lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"], early_force=ef)
+                               lattice=cfg["lattice"], jitter=True, jitter_dims=cfg["jitter_dims"], early_force=ef,
+                               protocol=int(getattr(args, "protocol", 3) or 3))
     layers = [b - a for a, b in zip(sim.cuts, sim.cuts[1:])]
     assert min(layers) >= MIN_SLAB_LAYERS or world == 1, sim.cuts
     mixed = getattr(args, "precision", "f32") == "mixed"        # BASELINE config 5's arithmetic
@@ -1010,6 +1011,25 @@ def bench_rank(comm, local, args, transport, log=None):
     sim.slab_timing_enable(False)
     phases_ms = {k: v / probe for k, v in ph.items()}
     diag = bench_diagnostics(sim, comm, phases_ms, host_t, probe_t, n_own)      # collective: every rank
+    # ---- rank 0 completes the line the way the N = 1 bench does, the others wait at the barrier: the HBM-side
+    #      traffic of ITS pair kernels -- its slab's state saved and stepped alone by a child of bench.py under `rocprofv3 --pmc` --
+    #      and the cpu_baseline probe on this box's host cores (the 262,144-particle dam: BASELINE.md section 3)
+    traffic, traffic_note, cpu_base = None, "--no-pmc", None
+    if rank == 0:
+        try:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench as bench_mod
+            if not getattr(args, "no_pmc", False):
+                t_p = time.perf_counter()
+                traffic, traffic_note = bench_mod.pmc_traffic(sim.engine.ctx, args, slab=(sim.z_lo, sim.z_hi), device=local)
+                log(f"[bench] rank 0 PMC traffic passes: {time.perf_counter() - t_p:.1f} s ({'ok' if traffic else traffic_note})")
+            if not getattr(args, "no_cpu", False):
+                cpu_base = bench_mod.cpu_baseline(budget_s=float(getattr(args, "cpu_budget", 24.0)))
+                cpu_base["sample"] += ("; the probe of the N = 1 bench (no leg on this run's own particles: a rank holds a slab of them), "
+                                       "timed on rank 0's host while the other ranks wait")
+        except Exception as e:      # noqa: BLE001 -- the line must not depend on the profiler or the oracle build
+            traffic_note = f"{type(e).__name__}: {e}"
+    comm.barrier()
     out = None
     if rank == 0:
         total = sim.total
@@ -1045,10 +1065,18 @@ def bench_rank(comm, local, args, transport, log=None):
             # rank 0's fused force pass (its interior + boundary launches of one step), algorithmic bytes as at N = 1
             "roofline": {"bound": "valu-issue", "kernel": "k_force<force+collision+integrate> (rank 0, launches of one step)",
                          "achieved": 84.0 * n_own / t_force / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": 84.0 * n_own / t_force / 1e9 / 8000.0, "traffic": None, "traffic_source": None,
+                         "frac": 84.0 * n_own / t_force / 1e9 / 8000.0,
+                         "traffic": traffic["force_fused"] if traffic else None,
+                         "traffic_source": (("rank 0's slab saved to a snapshot and stepped ALONE (no neighbours: its boundary layers see no "
+                                             "ghosts) by a child of bench.py; ") + traffic_note) if traffic else traffic_note,
+                         "traffic_over_algorithmic": (traffic["force_fused"] / (84.0 * n_own)) if traffic else None,
+                         "density_traffic": traffic.get("density") if traffic else None,
                          "algorithmic_bytes_per_particle": 84, "avg_launch_ms": t_force * 1e3,
                          "particles_rank0": int(n_own)},
-            "cpu_baseline": None,      # timed at N = 1 only (bench.py without --gpus)
+            "cpu_baseline": cpu_base,  # rank 0's host, the 262,144-particle probe (None with --no-cpu)
+            "gpu_over_cpu": (total * args.steps / wall / cpu_base["value"]) if cpu_base else None,
+            "protocol": {"groups_per_step": sim.stats.get("protocol", 3), "one_message_steps": sim.stats.get("one_message_steps", 0),
+                         "one_message_rests": sim.stats.get("one_message_rests", 0)},
             # ---- where the time of an N-rank step goes (DESIGN.md section 6 names the row each field confirms or refutes) ----
             "rccl": diag["rccl"],                       # None unless --transport rccl: {world_seen, devices, ping_us}
             "ping_us": diag["ping_us"],                 # preflight: one exchange-shaped group at the step's three message sizes
@@ -1089,13 +1117,17 @@ def bench_periodic(args):
     edge = float(box[2]) / grid[2]
     params = capi.default_params(box, grid)
     per_layer = 2 * nx * ny
-    ctx = capi.Context(int(1.5 * n) + 4096, params=params, device=0, slab=(z_lo, z_hi), ghost_capacity=3 * per_layer + 1024)
+    protocol = int(getattr(args, "protocol", 3) or 3)
+    ctx = capi.Context(int(1.5 * n) + 4096, params=params, device=0, slab=(z_lo, z_hi),
+                       ghost_capacity=(5 if protocol == 1 else 3) * per_layer + 1024, ghost_layers=2 if protocol == 1 else 1)
     ctx.set_precision(getattr(args, "precision", "f32") == "mixed")
     ctx.reset_lattice((nx, ny, 2 * nz), jitter=True, jitter_dims=box, start=n, count=n)      # the planes of layers [z_lo, z_hi)
     tr = C.POINTER(capi.Transport)()
     capi._check(L.sph_loop_transport_create(C.byref(tr), layers * edge, float(args.link_gbs), float(args.link_latency_us)))
     h = C.c_void_p()
     capi._check(L.sph_slab_create(C.byref(h), ctx.h, 1, 3, tr, 0))
+    if protocol == 1:
+        capi._check(L.sph_slab_set_protocol(h, 1))
     ef_arg = getattr(args, "early_force", "auto")
     halo_us = float(args.link_latency_us) + (per_layer * 32 / (float(args.link_gbs) * 1e3) if float(args.link_gbs) > 0 else 0.0)
     ef_on = ef_arg == "on" or (ef_arg == "auto" and NativeSlabSimulation.early_force_rule(float(args.link_latency_us), halo_us, n)[0])
@@ -1155,6 +1187,10 @@ def bench_periodic(args):
                                   (int(v) for v in stats))),
         "owned": int(owned), "finite": finite, "roofline": None, "cpu_baseline": None,
     }
+    pr = (C.c_uint64 * 3)()
+    capi._check(L.sph_slab_protocol(h, pr))
+    out["protocol"] = {"groups_per_step": int(pr[0]), "one_message_steps": int(pr[1]), "one_message_rests": int(pr[2]),
+                       "exchanges": int(L.sph_slab_exchanges(h))}
     ef = (C.c_uint64 * 2)()
     capi._check(L.sph_slab_early_force_stats(h, ef))
     out["early_force"] = {"on": bool(ef_on), "launched": int(ef[0]), "used": int(ef[1])}
