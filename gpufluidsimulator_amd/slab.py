@@ -632,10 +632,12 @@ class NativeSlabSimulation(SlabSimulation):
         return bool(slow and exposed), why
 
     def __init__(self, comm, box, grid, device_index=0, transport="host", migrant_capacity=0, ping_reps=3, early_force="auto",
-                 protocol=3, **kw):
+                 protocol=None, **kw):
         """protocol: 3 = MIGRANTS / HALO A / HALO B (three dependent message groups per step); 1 = the one-message step
         (sph_slab_set_protocol: two ghost layers, ghost densities recomputed locally; slabs of >= 4 cell layers).  The same on
         every rank."""
+        if protocol is None:               # (SPH_SLAB_PROTOCOL=1: the default of callers that do not say -- a test switch)
+            protocol = int(os.environ.get("SPH_SLAB_PROTOCOL", "3"))
         if protocol not in (1, 3):
             raise ValueError("protocol is 1 (one message per step) or 3")
         self.protocol = int(protocol)

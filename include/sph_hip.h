@@ -20,6 +20,29 @@
  *     stream like the reference) and is asynchronous unless the function returns data
  *     to the host; one context must not be used from two host threads at once;
  *   - there is NO CPU fallback: without a gfx950 device sph_create fails.
+ *
+ * What is ABI and what is not (every entry point belongs to exactly one class; the class is repeated as a tag in front of the
+ * declarations that are NOT stable ABI):
+ *   STABLE ABI     what a host class, a driver or a launcher binds; kept across versions (SPH_ABI_VERSION changes otherwise):
+ *                  sph_abi_version sph_last_error sph_device_count sph_select_device sph_selected_device sph_default_params
+ *                  sph_grid_dim_for_edge | sph_create sph_create_slab sph_create_slab_layers sph_destroy sph_set_stream
+ *                  sph_set_params sph_get_params sph_sync sph_num_particles sph_capacity sph_ghost_layers sph_set_precision
+ *                  sph_get_precision | sph_upload sph_set_by_index sph_reset_lattice sph_download sph_download_owned
+ *                  sph_positions_dev sph_download_positions4 sph_snapshot_save sph_snapshot_load sph_snapshot_info |
+ *                  sph_hash sph_sort sph_build_cells sph_density sph_force sph_collide sph_integrate sph_step sph_step_phased
+ *                  sph_force_collide_integrate | sph_timing_enable sph_timing_get sph_timing_reset | the z-slab phase calls
+ *                  (sph_migrants_* sph_slab_counts sph_halo_* sph_layer_histogram) | sph_rccl_unique_id
+ *                  sph_rccl_transport_create/_destroy sph_local_hub_* sph_local_transport_* | sph_slab_create sph_slab_destroy
+ *                  sph_slab_step sph_slab_sync sph_slab_set_wait_timeout sph_slab_set_protocol sph_slab_recut sph_slab_ping
+ *                  sph_slab_failed sph_slab_timing_enable/_reset/_get
+ *   [introspect]   read-only views for parity tests, profiles and bench lines; may grow or change with the implementation:
+ *                  sph_get_keys sph_get_order sph_get_cell_range sph_get_cells sph_cell_key sph_download_forces sph_sort_stats
+ *                  sph_sort_forms sph_last_sort_skipped sph_slab_stats sph_slab_counters sph_slab_in_place_merges
+ *                  sph_slab_exchanges sph_slab_recut_stats sph_slab_early_force_stats sph_slab_protocol sph_rccl_transport_info
+ *   [tuning]       switches whose defaults are the product's settings; in fp32 results do not depend on them (A/B runs):
+ *                  sph_set_sort_mode sph_set_direct_hull sph_set_block_order sph_slab_set_early_force
+ *   [test hook]    exist for tests and measurement harnesses only: sph_test_trust_mover_hint sph_slab_test_raise_flag
+ *                  sph_rccl_transport_selftest sph_loop_transport_create/_destroy
  */
 #ifndef SPH_HIP_H
 #define SPH_HIP_H
@@ -163,7 +186,7 @@ int sph_download(sph_ctx* c, uint32_t index_base, uint32_t index_count, float* p
 /* The owned particles compactly, in slot order: n x xyz, n x xyz, n creation indices (any may be NULL).
  * What a slab driver needs to move whole particles between ranks (re-balancing). */
 int sph_download_owned(sph_ctx* c, float* pos_xyz, float* vel_xyz, uint32_t* index);
-int sph_download_forces(sph_ctx* c, uint32_t index_base, uint32_t index_count, float* fpress_xyz, float* fvisc_xyz,
+/* [introspect] */ int sph_download_forces(sph_ctx* c, uint32_t index_base, uint32_t index_count, float* fpress_xyz, float* fvisc_xyz,
                         float* dv_xyz, int32_t* collision_count);
 /* The `gl_pos` analogue of cudaIntegrate (particleSystem.cu:416-419): float4 (x,y,z,1) per
  * creation index, written by sph_integrate / sph_step.  Device pointer, n*16 bytes. */
@@ -181,14 +204,14 @@ int sph_snapshot_load(sph_ctx* c, const char* path);
 int sph_snapshot_info(const char* path, uint32_t* n, sph_params* p);
 
 /* introspection for per-phase parity tests (sorted order) */
-int sph_get_keys(sph_ctx* c, uint32_t* keys);          /* cell key per slot */
-int sph_get_order(sph_ctx* c, uint32_t* index);        /* creation index per slot */
-int sph_get_cell_range(sph_ctx* c, uint32_t cell, uint32_t* start, uint32_t* end);
+/* [introspect] */ int sph_get_keys(sph_ctx* c, uint32_t* keys);          /* cell key per slot */
+/* [introspect] */ int sph_get_order(sph_ctx* c, uint32_t* index);        /* creation index per slot */
+/* [introspect] */ int sph_get_cell_range(sph_ctx* c, uint32_t cell, uint32_t* start, uint32_t* end);
 /* occupied cells in ascending key order: {key, start, count}; returns the number written
  * (<= max_cells) or a negative code */
-int sph_get_cells(sph_ctx* c, uint32_t max_cells, uint32_t* key, uint32_t* start, uint32_t* count);
+/* [introspect] */ int sph_get_cells(sph_ctx* c, uint32_t max_cells, uint32_t* key, uint32_t* start, uint32_t* count);
 /* local cell key of global cell coordinates (x, y, z): (z_local*gy + y)*gx + x */
-uint32_t sph_cell_key(const sph_ctx* c, uint32_t x, uint32_t y, uint32_t z);
+/* [introspect] */ uint32_t sph_cell_key(const sph_ctx* c, uint32_t x, uint32_t y, uint32_t z);
 
 /* ---- phases (each replaces one seam call; see the SPH_PH_* table) ------------------------ */
 int sph_hash(sph_ctx* c);
@@ -221,19 +244,19 @@ int sph_timing_reset(sph_ctx* c);
  * host never waits for it); the mover count the device last reported; and the sum of the mover counts of
  * all sorts so far (movers_total: particles that changed cell, summed over steps).  Synchronises the stream.
  * Any pointer may be NULL. */
-int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers,
+/* [introspect] */ int sph_sort_stats(sph_ctx* c, uint64_t* sorts, uint64_t* merges, uint64_t* skips, uint32_t* last_movers,
                    uint64_t* movers_total);
 /* How the movers' sorts of the merge path were launched so far: out[0] both forms (the count lives on the device, each
  * kernel looks at it and leaves if it is not its turn), out[1] the one-block sort alone, out[2] the multi-block passes
  * alone -- the last two from the count the device last reported: the previous sort's in a host-paced (slab) context, at most
  * four sorts old in a whole-domain one (there with a margin: both forms while the count is within a quarter of the one-block
  * sort's capacity).  No synchronisation. */
-int sph_sort_forms(const sph_ctx* c, uint64_t out[3]);
+/* [introspect] */ int sph_sort_forms(const sph_ctx* c, uint64_t out[3]);
 /* merge = 1 (default): the sort takes the merge path while few particles change cell (up to 1/8 of them, by
  * the count the device last reported); 0: the full radix sort every step (what SPH_SORT_MERGE=0 in the
  * environment selects at sph_create time); 2: the merge path whenever the previous order is intact, whatever
  * the count (it is exact for any count; for tests).  Takes effect at the next sort. */
-int sph_set_sort_mode(sph_ctx* c, int merge);
+/* [tuning] */ int sph_set_sort_mode(sph_ctx* c, int merge);
 /* The neighbour passes stage, per (dz, dy) row, the hull of a wave's candidate ranges through LDS.  A row whose hull
  * is longer than `slots` (default 512; usual hulls are ~80) is read straight from global memory by every lane instead
  * -- sparse particles next to a dense layer would otherwise stage thousands of slots for a handful of candidates each
@@ -244,17 +267,17 @@ int sph_set_sort_mode(sph_ctx* c, int merge);
  * of the exact one is a heuristic (key span of the wave <= 64 cells: taken as "no hull beyond `slots`", which cells of
  * more than slots / 66 particles can break -- such a wave stages a long hull, slowly but correctly).
  * 0: every row direct; 0xFFFFFFFF: never (for tests and A/B runs).  Takes effect at the next launch. */
-int sph_set_direct_hull(sph_ctx* c, uint32_t slots);
+/* [tuning] */ int sph_set_direct_hull(sph_ctx* c, uint32_t slots);
 /* The ORDER in which the neighbour passes' workgroups take the sorted slots (results do not depend on it).  xcd = 1
  * (default): each of the 8 XCDs walks one contiguous eighth of the slots; ztile = 1 (default): inside its eighth an XCD
  * walks strips of 2^strip_blocks_log2 workgroups (default 4: 16 workgroups = 4096 slots) through all cell layers of the
  * eighth before the next strip, so that the rows of neighbouring layers are re-used out of the XCD's L2: half the HBM-side
  * reads of the plain order.  0 / 0 restores the plain front-to-back order (A/B runs). */
-int sph_set_block_order(sph_ctx* c, int xcd, int ztile, uint32_t strip_blocks_log2);
+/* [tuning] */ int sph_set_block_order(sph_ctx* c, int xcd, int ztile, uint32_t strip_blocks_log2);
 /* 1 if the last sph_sort found that no particle had changed cell and left everything as it was (then
  * every count derived from the sorted order -- sph_slab_counts, sph_halo_count -- is that of the step
  * before), else 0.  No synchronisation. */
-int sph_last_sort_skipped(const sph_ctx* c);
+/* [introspect] */ int sph_last_sort_skipped(const sph_ctx* c);
 
 /* ---- z-slab halo / migration (multi-GPU; no counterpart in the reference) ---------------- */
 /* side: 0 = towards lower z (rank-1), 1 = towards higher z (rank+1).
@@ -316,11 +339,11 @@ int sph_rccl_transport_create(sph_transport** out, const uint8_t id[128], int ra
 void sph_rccl_transport_destroy(sph_transport* t);
 /* two messages of `bytes` and `bytes`/2 bytes from this rank to ITSELF through the transport's communicator (one
  * ncclGroup), compared on the host: checks the dlopen binding of librccl with real traffic on a one-GPU box */
-int sph_rccl_transport_selftest(sph_transport* t, size_t bytes);
+/* [test hook] */ int sph_rccl_transport_selftest(sph_transport* t, size_t bytes);
 /* What the communicator says about itself: {ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclCommGetAsyncError}
  * (-1 where librccl lacks the call).  The multi-GPU bench prints them: a communicator of the wrong size, or one that sits on
  * another device than the slab's context, explains a hang or a slow run before any step is taken. */
-int sph_rccl_transport_info(const sph_transport* t, int out[4]);
+/* [introspect] */ int sph_rccl_transport_info(const sph_transport* t, int out[4]);
 
 /* Device-to-device transport between the slabs of ONE process that share a GPU (one thread per rank): the buffers are
  * device pointers, the copies are queued on the caller's comm stream behind the sender's event, nothing blocks on the
@@ -342,8 +365,8 @@ void sph_local_transport_destroy(sph_transport* t);
  * rank of an N-GPU run that a one-GPU box allows (`bench.py --force-slab --periodic-z`).  Every message is held back by
  * latency_us + bytes / link_gbs (0 / 0: no delay) on the comm stream before it is delivered: the link is a parameter, not a
  * measurement.  sph_slab_ping does not apply (a slab cannot tell its images apart). */
-int sph_loop_transport_create(sph_transport** out, float z_shift, double link_gbs, double latency_us);
-void sph_loop_transport_destroy(sph_transport* t);
+/* [test hook] */ int sph_loop_transport_create(sph_transport** out, float z_shift, double link_gbs, double latency_us);
+/* [test hook] */ void sph_loop_transport_destroy(sph_transport* t);
 
 typedef struct sph_slab sph_slab;
 /* Bind a slab context (sph_create_slab, particles uploaded) to its place in the chain of `world` slabs.  The halo
@@ -364,15 +387,15 @@ int sph_slab_sync(sph_slab* s);
  * stopped with an error never sends its messages */
 int sph_slab_set_wait_timeout(sph_slab* s, double seconds);
 /* {steps, particles sent away, steps with arrivals, ghosts received, host waits} */
-int sph_slab_stats(const sph_slab* s, uint64_t out[5]);
+/* [introspect] */ int sph_slab_stats(const sph_slab* s, uint64_t out[5]);
 /* the same five + {in-place merges, steps with far arrivals, steps that needed a second migrant message} */
-int sph_slab_counters(const sph_slab* s, uint64_t out[8]);
+/* [introspect] */ int sph_slab_counters(const sph_slab* s, uint64_t out[8]);
 /* of the steps with arrivals, those that merged them into the two boundary layers in place (the rest ran a pass over
  * all particles: more than 2048 arrivals on a side, or no valid cell table) */
-uint64_t sph_slab_in_place_merges(const sph_slab* s);
+/* [introspect] */ uint64_t sph_slab_in_place_merges(const sph_slab* s);
 /* transport calls so far: 3 in a usual step (migrants, halo A, halo B), 4 when a side has more leavers than ride in the
  * fixed-size migrant message */
-uint64_t sph_slab_exchanges(const sph_slab* s);
+/* [introspect] */ uint64_t sph_slab_exchanges(const sph_slab* s);
 /* Re-cut (re-balancing): this slab takes over the cell layers [new_z_lo, new_z_hi) of the global grid.  Entirely on the
  * device, the context and the slab object are kept: the owned particles are split by their layer into "to rank - 1" |
  * "stay" | "to rank + 1" (stable), the leaving runs travel point to point through the slab's transport in chunks of the
@@ -385,7 +408,7 @@ uint64_t sph_slab_exchanges(const sph_slab* s);
  * download and destroy).  Replaces nothing in the reference (single GPU); SURVEY.md section 8e "re-cut every K steps". */
 int sph_slab_recut(sph_slab* s, uint32_t new_z_lo, uint32_t new_z_hi);
 /* {re-cuts so far, particles that changed owner in them} */
-int sph_slab_recut_stats(const sph_slab* s, uint64_t out[2]);
+/* [introspect] */ int sph_slab_recut_stats(const sph_slab* s, uint64_t out[2]);
 /* Neighbour ping: `reps` timed rounds (+ one untimed round first) of ONE exchange-shaped group -- `bytes` to and from
  * rank - 1 and rank + 1, through this slab's transport, comm stream and halo buffers -- every word checked on arrival for
  * sender, direction and round.  out = {mean us per group, max us, wrong words}; event times on the comm stream, i.e. what a
@@ -423,7 +446,7 @@ int sph_slab_timing_get(sph_slab* s, double out[SPH_SLAB_T_WORDS]);
  * length and the two evict each other's L2 working sets -- a 16.7 M-particle slab: 3.90 against 3.69 ms); on > 1 sets that
  * number of slots (environment: SPH_SLAB_EARLY_SPAN).  A slab without neighbours (world 1) never launches it.  Same bits either way.
  * out = {steps that launched it, steps that used its result} (a step whose arrivals re-sort the slab discards it). */
-int sph_slab_set_early_force(sph_slab* s, int on);
+/* [tuning] */ int sph_slab_set_early_force(sph_slab* s, int on);
 /* The message protocol of a step.  3 (default): MIGRANTS (header + leavers) -> the host's wait -> HALO A (boundary layers) ->
  * HALO B (their densities), three dependent groups per step.  1: ONE group -- header, leavers and the RESIDENTS of the two
  * cell layers next to each cut in one message per neighbour ("a 2-layer halo, ghost densities recomputed
@@ -437,15 +460,15 @@ int sph_slab_set_early_force(sph_slab* s, int on);
  * the density of one more layer per side; gain: two message latencies off the step's critical path.
  * sph_slab_protocol: out = {protocol, one-message steps so far, of which needed the second message}. */
 int sph_slab_set_protocol(sph_slab* s, int groups);
-int sph_slab_protocol(const sph_slab* s, uint64_t out[3]);
-int sph_slab_early_force_stats(const sph_slab* s, uint64_t out[2]);
+/* [introspect] */ int sph_slab_protocol(const sph_slab* s, uint64_t out[3]);
+/* [introspect] */ int sph_slab_early_force_stats(const sph_slab* s, uint64_t out[2]);
 /* TEST HOOK: sph_upload / sph_set_by_index / sph_reset_lattice / sph_set_params make the next five movers' sorts of a
  * whole-domain context launch BOTH forms (the caller may have changed every particle: the count the device last reported says
  * nothing).  This takes that back, so that a test can put a changed state in front of a sort launched on the old count. */
-int sph_test_trust_mover_hint(sph_ctx* c);
+/* [test hook] */ int sph_test_trust_mover_hint(sph_ctx* c);
 /* TEST HOOK: raise sticky device-side error word `flag` (0: an arrival outside its boundary layer, 1: an arrival outside
  * the slab) as the insert / unpack kernels would; the next sph_slab_step then fails before it has sent anything. */
-int sph_slab_test_raise_flag(sph_slab* s, int flag);
+/* [test hook] */ int sph_slab_test_raise_flag(sph_slab* s, int flag);
 /* 0, or the first error of this slab: a slab that failed stays failed -- it has told its neighbours (they return
  * SPH_E_PEER at their next step), every later sph_slab_step returns the same error, and the state of its context is that
  * of a half-done step: download / destroy only */

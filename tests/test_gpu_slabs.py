@@ -27,7 +27,7 @@ def _comm(hub, dev_hub, r):
 
 
 def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport="local", rebalance_every=0, expect_error=False,
-               early_force="auto", protocol=3):
+               early_force="auto", protocol=None):
     hub = slab.LocalComm.Hub(world)
     dev_hub = capi.LocalHub(world, timeout_s=60) if transport == "local" else None
     results, errors = [None] * world, []
