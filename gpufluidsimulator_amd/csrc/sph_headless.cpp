@@ -8,6 +8,7 @@
 //   -gpus=N            N child PROCESSES, forked before anything touches a GPU, rank r on device r (+ -device=), messages
 //                      over RCCL (sph_rccl_transport_create; rank 0 hands the id to the others through pipes);
 //   -gpus=N -onegpu    N THREADS of this process on one device over the device-to-device transport (a one-GPU box).
+//   -protocol=1        the one-message slab step (sph_slab_set_protocol: two ghost layers, ghost densities recomputed locally).
 // The reference's line is printed with NumDevsUsed = N.
 #include "../../include/particleSystem.h"
 
@@ -64,6 +65,7 @@ struct SlabJob {
     bool warmup;
     float dt;
     const char* out;                 // xyzw per creation index, then vxyz0 (as the one-device -out)
+    int protocol;                    // message groups per step: 3, or 1 (-protocol=1: sph_slab_set_protocol, two ghost layers)
 };
 
 struct Plan { std::vector<uint32_t> cuts; std::vector<uint64_t> hist; uint64_t per_layer = 0; };
@@ -84,7 +86,8 @@ bool plan_slabs(const SlabJob& j, int world, Plan& pl, std::string& err) {
         if (layer(zc - amp) != layer(zc + amp)) { err = "a lattice plane straddles a cell face: use `python bench.py --gpus N`"; return false; }
         pl.hist[layer(zc)] += cnt;
     }
-    if ((uint64_t)world * 2 > gz) { err = "more slabs than pairs of cell layers"; return false; }
+    const uint32_t min_layers = j.protocol == 1 ? 4u : 2u;      // (the one-message step: four layers per slab, slab.py choose_cuts)
+    if ((uint64_t)world * min_layers > gz) { err = "more slabs than groups of " + std::to_string(min_layers) + " cell layers"; return false; }
     std::vector<uint64_t> prefix(gz + 1, 0);
     for (uint32_t z = 0; z < gz; z++) { prefix[z + 1] = prefix[z] + pl.hist[z]; pl.per_layer = std::max(pl.per_layer, pl.hist[z]); }
     pl.cuts.assign(1, 0u);
@@ -92,8 +95,8 @@ bool plan_slabs(const SlabJob& j, int world, Plan& pl, std::string& err) {
         const double target = (double)j.particles * r / world;
         uint32_t z = (uint32_t)(std::lower_bound(prefix.begin(), prefix.end(), (uint64_t)std::ceil(target)) - prefix.begin());
         if (z > 0 && std::fabs((double)prefix[z - 1] - target) <= std::fabs((double)prefix[std::min(z, gz)] - target)) z--;
-        z = std::max(z, pl.cuts.back() + 2u);
-        z = std::min(z, gz - 2u * (uint32_t)(world - r));
+        z = std::max(z, pl.cuts.back() + min_layers);
+        z = std::min(z, gz - min_layers * (uint32_t)(world - r));
         pl.cuts.push_back(z);
     }
     pl.cuts.push_back(gz);
@@ -151,11 +154,12 @@ void rank_main(const SlabJob& j, const Plan& pl, int rank, int world, int device
     const uint32_t grid[3] = {j.grid, j.grid, j.grid};
     sph_params prm;
     sph_default_params(&prm, dims, grid);
-    const uint32_t gcap = (uint32_t)(3 * pl.per_layer + 1024);
+    const uint32_t ghost_layers = j.protocol == 1 ? 2u : 1u;
+    const uint32_t gcap = (uint32_t)((j.protocol == 1 ? 5 : 3) * pl.per_layer + 1024);
     const uint32_t cap = (uint32_t)(1.5 * (double)std::max<uint64_t>(n_own, j.particles / world)) + 4096u;
     sph_ctx* ctx = nullptr; sph_transport* tr = nullptr; sph_slab* slab = nullptr;
-    bool ok = sph_create_slab(&ctx, device, cap, &prm, z_lo, z_hi, gcap) == 0;
-    if (!ok) fail("sph_create_slab");
+    bool ok = sph_create_slab_layers(&ctx, device, cap, &prm, z_lo, z_hi, gcap, ghost_layers) == 0;
+    if (!ok) fail("sph_create_slab_layers");
     if (ok && n_own && sph_reset_lattice(ctx, j.lattice, 1, nullptr, first, (uint32_t)n_own) < 0) { ok = false; fail("sph_reset_lattice"); }
     if (ok && sph_sync(ctx) < 0) { ok = false; fail("set-up"); }
     // test hooks (tests/test_gpu_host_class.py): this rank fails its set-up / never reaches the READY round
@@ -171,6 +175,7 @@ void rank_main(const SlabJob& j, const Plan& pl, int rank, int world, int device
         ok = false; fail("transport");
     }
     if (ok && sph_slab_create(&slab, ctx, rank, world, tr, 0) < 0) { ok = false; fail("sph_slab_create"); }
+    if (ok && j.protocol == 1 && sph_slab_set_protocol(slab, 1) < 0) { ok = false; fail("sph_slab_set_protocol"); }
     if (ok) {       // preflight: one exchange-shaped group at the step's three message sizes, contents checked
         const size_t sizes[3] = {8192, (size_t)std::min<uint64_t>(pl.per_layer * 32, (uint64_t)(gcap + 1) * 32),
                                  (size_t)std::min<uint64_t>(pl.per_layer * 8, (uint64_t)(gcap + 1) * 32)};
@@ -387,7 +392,7 @@ int main(int argc, char** argv) {
     if (!benchmark && !file) fprintf(stderr, "note: no OpenGL in this build -- running headless, as with -benchmark\n");
     if (flag(argc, argv, "help")) {
         printf("usage: sph_headless [-benchmark] [-n=<particles>] [-box=<edge>] [-i=<iterations>] [-device=<id>] [-grid=<cells per axis>] "
-               "[-ic=grid|random] [-steps=<per update>] [-gpus=<N> [-onegpu] [-slab] [-lattice=nx,ny,nz]] "
+               "[-ic=grid|random] [-steps=<per update>] [-gpus=<N> [-onegpu] [-slab] [-lattice=nx,ny,nz] [-protocol=1|3]] "
                "[-dump=<count>] [-log=<file> [-logfreq=<ms>] [-logstyle=oscar|frames]] [-sphere=<update>[,<radius>]] [-out=<file>] [-save=<file>] [-load=<file>] [-file=<file>]\n");
         return 0;
     }
@@ -410,6 +415,8 @@ int main(int argc, char** argv) {
         j.grid = gridDim ? gridDim : sph_grid_dim_for_edge(box, 0.1f);
         j.iterations = iterations; j.substeps = substeps; j.warmup = !flag(argc, argv, "nowarmup"); j.dt = timestep;
         j.out = value(argc, argv, "out");
+        j.protocol = value(argc, argv, "protocol") ? atoi(value(argc, argv, "protocol")) : 3;
+        if (j.protocol != 1 && j.protocol != 3) { fprintf(stderr, "-protocol=%d: 3 (three message groups per step) or 1 (one)\n", j.protocol); return EXIT_FAILURE; }
         return run_slabs(j, gpus, flag(argc, argv, "onegpu"), device);
     }
     int is950 = 0;

@@ -1207,8 +1207,9 @@ int slab_step_body(sph_slab* s, float dt) {
     const uint32_t far_in_lo = s->has_lo ? s->h_lb[HL_HDR_LO + 2] : 0u, far_in_hi = s->has_hi ? s->h_lb[HL_HDR_HI + 2] : 0u;
     // the SECOND layers next to the cuts (the one-message step's ghosts-of-ghosts; every header carries the counts, so that the
     // step after a three-group step can size its message): mine from the bounds, the neighbours' from their headers
-    const uint32_t n2_lo = s->has_lo && near_lo >= off0 + lb1 ? min(near_lo - off0, lb2) - lb1 : 0u;
-    const uint32_t n2_hi = s->has_hi && near_hi >= off0 && near_hi - off0 <= lb2 ? lb2 - max(near_hi - off0, lb1) : 0u;
+    // (the same expressions as the kernel's header words: k_slab_bounds_pack)
+    const uint32_t n2_lo = s->has_lo ? max(near_lo - off0, lb1) - lb1 : 0u;
+    const uint32_t n2_hi = s->has_hi ? lb2 - min(near_hi - off0, lb2) : 0u;
     const uint32_t n2p_lo = s->has_lo ? s->h_lb[HL_HDR2_LO] : 0u, n2p_hi = s->has_hi ? s->h_lb[HL_HDR2_HI] : 0u;
     const uint32_t vfar_mine = s->h_lb[HL_VFAR], vfar_peer = (s->has_lo ? s->h_lb[HL_HDR2_LO + 1] : 0u) + (s->has_hi ? s->h_lb[HL_HDR2_HI + 1] : 0u);
     // records either end of a link packed this step: what the NEXT one-message step is sized from
@@ -2200,6 +2201,8 @@ int sph_slab_recut(sph_slab* s, uint32_t new_z_lo, uint32_t new_z_hi) {
     if (s->failed) { set_error("%s", s->fail_msg); return s->failed; }
     SPH_REQUIRE(new_z_lo < new_z_hi && new_z_hi <= s->c->params.grid[2], SPH_E_INVALID, "bad layer range [%u, %u)", new_z_lo, new_z_hi);
     SPH_REQUIRE(s->world == 1 || new_z_hi - new_z_lo >= 2, SPH_E_INVALID, "a slab needs at least two cell layers");
+    SPH_REQUIRE(s->world == 1 || s->protocol != 1 || new_z_hi - new_z_lo >= 4, SPH_E_INVALID,
+                "the one-message step needs slabs of at least four cell layers (asked for [%u, %u))", new_z_lo, new_z_hi);
     SPH_REQUIRE((s->has_lo || new_z_lo == 0u) && (s->has_hi || new_z_hi == s->c->params.grid[2]), SPH_E_INVALID,
                 "rank %d of %d: the outer slabs reach to the ends of the grid", s->rank, s->world);
     // a particle moves ONE rank per call: a new range that does not even touch the old one would hand particles to a

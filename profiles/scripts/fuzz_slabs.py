@@ -18,6 +18,7 @@ for case in range(ncases):
     nz = int(rng.integers(2 * world * 2, 110))
     box, grid = (8.0, 8.0, 8.0), (128, 128, 128)
     pos, vel = ic.dam_break_lattice((nx, ny, nz), box, jitter=True)
+    protocol = int(os.environ.get("FUZZ_PROTOCOL", "3"))      # 1: the one-message slab step (slabs of >= 4 layers: choose_cuts sees to it)
     mode = int(rng.integers(0, 4))
     if mode == 0:
         vel[:, 2] = float(rng.uniform(-9000, 9000))
@@ -33,7 +34,7 @@ for case in range(ncases):
     t0 = time.time()
     try:
         res = T._run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, rebalance_every=reb,
-                           early_force=True if os.environ.get("FUZZ_EARLY_FORCE") else "auto")
+                           early_force=True if os.environ.get("FUZZ_EARLY_FORCE") else "auto", protocol=protocol)
         st = res[0][0]
         ref = T._whole_domain(pos, vel, box, grid, steps)
         ep = np.abs(st["pos"] - ref["pos"]).max() / 8.0
@@ -48,6 +49,7 @@ for case in range(ncases):
         stats = {k: sum(r[1][k] for r in res) for k in ("migrants", "resorts", "in_place_merges", "far_steps", "rest_messages")}
         stats["rebalances"] = sum(r[1].get("rebalances", 0) for r in res); stats["reb_every"] = reb
         stats["early_force_used"] = sum(r[1].get("early_force_used", 0) for r in res)
+        stats["one_message_steps"] = sum(r[1].get("one_message_steps", 0) for r in res); stats["one_message_rests"] = sum(r[1].get("one_message_rests", 0) for r in res)
         print(f"case {seed0 + case}: world {world} lattice {nx}x{ny}x{nz} mode {mode} steps {steps} {transport}: "
               f"{'ok ' if ok else 'BAD'} {'same-bits' if same else 'DIFFERENT-BITS'} pos {ep:.1e} vel {ev.max():.1e} ({(ev > 1e-5).sum()} > 1e-5) rho {er:.1e} cuts {res[0][2]} {stats} {time.time() - t0:.1f}s", flush=True)
         bad += 0 if ok else 1

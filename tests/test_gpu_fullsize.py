@@ -466,7 +466,7 @@ def test_c4_corner_block_matches_oracle():
     assert np.isfinite(st["pos"]).all() and np.isfinite(st["vel"]).all() and st["density"].min() > 0
 
 
-def _eight_slabs_against_one_context(name, mixed, steps, dt, kick_seed):
+def _eight_slabs_against_one_context(name, mixed, steps, dt, kick_seed, protocol=3, early_force="auto"):
     """`name`'s dam at its stated size, kicked with random velocities (particles cross cell faces and slab cuts on the way),
     in EIGHT z-slab contexts on this one GPU -- eight threads, sph_slab_step over the device-to-device transport: the
     product branch of the exchange, the stream / event edges of an 8-GPU run -- against ONE whole-domain context.
@@ -489,7 +489,7 @@ def _eight_slabs_against_one_context(name, mixed, steps, dt, kick_seed):
             comm = slab.LocalComm(hub, r)
             comm.local_hub = dev_hub
             sim = slab.NativeSlabSimulation(comm, cfg["box"], cfg["grid"], device_index=0, transport="local",
-                                            lattice=cfg["lattice"], jitter=True)
+                                            lattice=cfg["lattice"], jitter=True, protocol=protocol, early_force=early_force)
             ctx = sim.engine.ctx
             ctx.set_precision(mixed)
             first = sim.engine.n                                     # a run of creation indices (device-made lattice layers)
@@ -532,6 +532,21 @@ def test_c4_in_eight_slabs_on_one_gpu_bit_for_bit():
     assert sum(s["migrants"] for s in stats) > 1000, stats             # particles changed rank
     assert all(s["host_waits"] == s["steps"] + s["far_steps"] for s in stats), stats
     assert max(s["owned"] for s in stats) <= 1.05 * n / 8, [s["owned"] for s in stats]
+    for k in ("pos", "vel", "density", "pressure"):
+        assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
+
+
+def test_c4_in_eight_slabs_one_message_step_with_the_early_force_launch_bit_for_bit():
+    """Config 4 at its stated size through the ONE-MESSAGE slab step (sph_slab_set_protocol(s, 1): two ghost layers per side, the
+    inner one's densities recomputed by the receiving rank, one transport call per step after the first) with the early force
+    launch forced ON (the full-size bit-for-bit runs had it off, as every run over the local transport): the same
+    twelve steps, `array_equal` to the one-context run."""
+    got, ref, stats, movers, n = _eight_slabs_against_one_context("C4", False, 12, 2e-5, 41, protocol=1, early_force=True)
+    assert sum(s["owned"] for s in stats) == n and movers > 100000
+    assert sum(s["migrants"] for s in stats) > 1000, stats
+    assert all(s["protocol"] == 1 and s["one_message_steps"] == s["steps"] - 1 for s in stats), stats
+    assert all(s["exchanges"] == 3 + s["rest_messages"] + s["one_message_steps"] + s["one_message_rests"] for s in stats), stats
+    assert all(s["early_force_launches"] > 0 and s["early_force_used"] > 0 for s in stats), stats
     for k in ("pos", "vel", "density", "pressure"):
         assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
 

@@ -222,6 +222,10 @@ def test_driver_gpus_flag_runs_z_slabs_through_the_c_abi():
         a, b = np.fromfile(f1, dtype=np.float32), np.fromfile(f4, dtype=np.float32)
     assert "NumDevsUsed = 4" in text and "4 z-slabs" in text and '"ranks_as": "threads"' in text
     assert a.size == b.size == 2 * 32768 * 4 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    with tempfile.TemporaryDirectory() as d:       # -protocol=1: the one-message slab step (two ghost layers): the same bits
+        f1p = os.path.join(d, "four_p1.bin")
+        text = _run("-benchmark", "-n=32768", "-box=4", "-i=20", "-nowarmup", "-gpus=4", "-onegpu", "-protocol=1", f"-out={f1p}")
+        assert "NumDevsUsed = 4" in text and np.array_equal(np.fromfile(f1p, dtype=np.uint32), a.view(np.uint32))
     bad = subprocess.run([EXE, "-benchmark", "-n=32768", "-box=4", "-i=2", "-gpus=2"], capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "GPUs asked for" in bad.stderr
     # a rank whose set-up fails stops EVERY rank before anybody creates its transport (the READY round), at once

@@ -59,6 +59,13 @@ def _run_slabs(world, box, grid, steps, particles=None, lattice=None, transport=
     return results
 
 
+def _exchanges_ok(stats):
+    """Transport calls of a run under either protocol: three per three-group step, one per one-message step, + the second
+    (exact-size) message of a burst in either."""
+    return stats["exchanges"] == (3 * (stats["steps"] - stats["one_message_steps"]) + stats["rest_messages"] + stats["one_message_steps"] +
+                                  stats["one_message_rests"])
+
+
 def _same_bits(st, ref):
     """An N-slab run holds every cell in the order of the one-context run (arrivals from below in front of the residents
     of their cell, from above behind them: csrc/sph_slab.hip k_slab_insert, sph_sort.hip Front), so every neighbour sum
@@ -235,21 +242,24 @@ def test_slab_entry_points_directly():
         assert c.n == len(mine) - want[3] and c.slab_counts()[0] == want[0]
 
 
-@pytest.mark.parametrize("transport", ["local", "host"])
-def test_rebalance_on_gpu_engines(transport):
+@pytest.mark.parametrize("transport,protocol", [("local", 3), ("host", 3), ("local", 1)])
+def test_rebalance_on_gpu_engines(transport, protocol):
     """slab.SlabSimulation.rebalance() with the product engine: the fluid drifts out of its slabs, the
     cuts follow, whole layers change owner, the physics matches the whole-domain context."""
     pos, vel, box, grid = make_case("up")
     vel[:, 2] = 12000.0
     world, steps = 3, 65
-    results = _run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, rebalance_every=20)
+    results = _run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, rebalance_every=20, protocol=protocol)
     st, stats, cuts1, _, cuts0 = results[0]
     assert stats.get("rebalances", 0) >= 1 and cuts1 != cuts0
     # the re-cut happens on the device (sph_slab_recut): no rank got a new context or a new slab object, and the step
     # counters ran on through it (one host wait and three messages per step, re-cut traffic not counted)
     assert all(r[1]["kept"] for r in results)
     assert all(r[1]["steps"] == steps and r[1]["host_waits"] == steps + r[1]["far_steps"] for r in results), [r[1] for r in results]
-    assert all(r[1]["exchanges"] == 3 * steps + r[1]["rest_messages"] for r in results), [r[1] for r in results]
+    assert all(_exchanges_ok(r[1]) for r in results), [r[1] for r in results]
+    if protocol == 1:       # every step but the first and the one after each re-cut (those learn the message sizes) is ONE message
+        assert all(r[1]["protocol"] == 1 and steps - 1 - r[1].get("rebalances", 0) * 8 <= r[1]["one_message_steps"] < steps for r in results), \
+            [r[1] for r in results]
     owned = [r[3] for r in results]
     assert sum(owned) == pos.shape[0] and max(owned) <= 1.35 * pos.shape[0] / world, owned
     ref = _whole_domain(pos, vel, box, grid, steps)
@@ -286,6 +296,26 @@ def test_particle_crossing_two_layers_in_one_step():
     ref = _whole_domain(pos, vel, box, grid, steps)
     assert np.abs(ref["pos"][fast, 2] - pos[fast, 2]).min() > 0.14         # more than two cell layers (viscosity brakes them fast)
     _same_bits(st, ref)
+
+
+def test_one_message_step_with_particles_crossing_two_layers_and_refusing_three():
+    """The one-message step keeps TWO ghost layers, so a particle that crosses into the neighbour's second layer in one step is
+    still inside the copy this rank holds of that layer: the sender merges it into its ghost copy where the neighbour will put
+    it, the receiver takes it through the pass over all particles as ever -- whole-domain bits.  One that flies FURTHER is in
+    nobody's copy: SPH_E_STATE on the ranks that see it, SPH_E_PEER on the others (the three-group protocol takes such a
+    particle as long as it lands in an interior layer: test_particle_crossing_two_layers_in_one_step)."""
+    pos, vel, box, grid, fast = _far_case()
+    vel[fast, 2] = 1.5e5               # 0.075 = 1.2 cell layers per step: from the top layers of slab 0 into layers 4 and 5 of slab 1
+    steps, world = 4, 3
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel), protocol=1)
+    assert res[0][2] == [0, 4, 8, 64]
+    assert sum(r[1]["far_steps"] for r in res) >= 1 and all(r[1]["one_message_steps"] == steps - 1 for r in res), [r[1] for r in res]
+    ref = _whole_domain(pos, vel, box, grid, steps)
+    assert np.abs(ref["pos"][fast, 2] - pos[fast, 2]).min() > 0.0625
+    _same_bits(res[0][0], ref)
+    pos, vel, box, grid, fast = _far_case()            # 2.24 layers per step: beyond the second layer
+    errors = _run_slabs(world, box, grid, steps, particles=(pos, vel), protocol=1, expect_error=True)
+    assert errors and any("more than TWO cell layers" in str(e) for e in errors), errors
 
 
 def test_a_stopped_neighbour_is_an_error_not_a_hang():
@@ -360,6 +390,23 @@ def test_a_burst_of_leavers_takes_the_second_migrant_message():
     _same_bits(st, ref)
 
 
+def test_one_message_step_burst_outgrows_the_size_fixed_in_advance():
+    """The one message of a step is sized from the counts of the step BEFORE (+ 1/16 + 1024 records); when a whole lattice layer
+    crosses a cut at once the message outgrows that and the rest follows in a second, exact message -- on that step only."""
+    box, grid = (4.0, 4.0, 4.0), (64, 64, 64)
+    steps, world = 6, 3
+    # a 48 x 48 x 24 block: 2304 particles per lattice layer; the layers just under the two cuts (3.75 / 7.75 cells) move
+    # 0.1 cells per step: they cross at the third step, in the middle of the one-message steps
+    pos2, vel2 = ic.dam_break_lattice((48, 48, 24), box, jitter=True)
+    iz2 = np.arange(pos2.shape[0]) // (48 * 48)
+    vel2[(iz2 == 7) | (iz2 == 15), 2] = 1.25e4
+    res = _run_slabs(world, box, grid, steps, particles=(pos2, vel2), protocol=1)
+    assert sum(r[1]["one_message_rests"] for r in res) >= 2, [r[1] for r in res]
+    assert sum(r[1]["migrants"] for r in res) >= 2 * 2304 and all(_exchanges_ok(r[1]) for r in res)
+    assert all(r[1]["one_message_steps"] == steps - 1 for r in res)
+    _same_bits(res[0][0], _whole_domain(pos2, vel2, box, grid, steps))
+
+
 def test_rccl_binding_moves_real_bytes_on_one_rank():
     """The product transport's librccl binding (dlopen, by-value ncclUniqueId, ncclSend/ncclRecv in one group) with real
     traffic: a one-rank communicator sends two messages to itself and compares what arrives (csrc/sph_slab.hip:
@@ -373,7 +420,8 @@ def test_rccl_binding_moves_real_bytes_on_one_rank():
         capi.load().sph_rccl_transport_destroy(tr)
 
 
-def test_slabs_under_heavy_two_way_migration():
+@pytest.mark.parametrize("protocol", [3, 1])
+def test_slabs_under_heavy_two_way_migration(protocol):
     """Stress of the step's rarely taken branches together: random z velocities both ways (a particle crosses a cell layer
     every ~4 steps), thin 3-layer slabs next to a thick one, arrivals on both sides of a slab in the same step, steps with
     arrivals next to steps without (the halo work switches between the comm-stream form and the main-stream form).
@@ -383,9 +431,10 @@ def test_slabs_under_heavy_two_way_migration():
     rng = np.random.default_rng(5)
     vel[:, 2] = rng.uniform(-30000.0, 30000.0, pos.shape[0]).astype(np.float32)
     steps, world = 12, 4
-    res = _run_slabs(world, box, grid, steps, particles=(pos, vel))
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel), protocol=protocol)
     stats = [r[1] for r in res]
-    assert sum(s["migrants"] for s in stats) > 1500, stats          # (viscosity brakes the random motion within a few steps)
+    assert all(_exchanges_ok(s) and s["one_message_steps"] == (steps - 1 if protocol == 1 else 0) for s in stats), stats
+    assert sum(s["migrants"] for s in stats) > (1500 if protocol == 3 else 800), stats          # (viscosity brakes the random motion within a few steps)
     assert sum(s["resorts"] for s in stats) >= steps, stats
     assert all(s["host_waits"] == steps + s["far_steps"] for s in stats)
     assert sum(r[3] for r in res) == pos.shape[0]
@@ -416,7 +465,8 @@ def test_mid_size_slabs_with_deep_interiors_and_migration():
     _same_bits(st, ref)
 
 
-def test_nearly_empty_slabs():
+@pytest.mark.parametrize("protocol", [3, 1])
+def test_nearly_empty_slabs(protocol):
     """Ragged input for the slab step: 40 particles in a 64^3 grid cut into 3 slabs -- two ranks own nothing at first, then a
     few particles wander into one of them (arrivals into an EMPTY slab: no boundary layer to merge into, no cell table yet),
     and an isolated particle sits alone in its layer.  Every kernel of the step must cope with zero-length ranges."""
@@ -429,7 +479,7 @@ def test_nearly_empty_slabs():
     vel = np.zeros_like(pos)
     vel[:, 2] = np.where(np.arange(40) % 2 == 0, 9000.0, -9000.0)       # half go up, half go down: ~14 steps per layer
     steps, world = 45, 3
-    res = _run_slabs(world, box, grid, steps, particles=(pos, vel))
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel), protocol=protocol)
     owned = [r[3] for r in res]
     assert sum(owned) == 40
     assert sum(r[1]["migrants"] for r in res) > 0
@@ -473,6 +523,37 @@ def test_slab_fuzz(seed):
     _same_bits(st, ref)
 
 
+@pytest.mark.parametrize("seed", [100, 104, 109, 122, 1031, 1174, 2008, 2257, 3001, 3002, 3003, 3004])
+def test_slab_fuzz_one_message_step(seed):
+    """The same randomised runs under the one-message protocol (slabs of >= 4 layers: choose_cuts sees to it), bit for bit."""
+    rng = np.random.default_rng(seed)
+    world = int(rng.integers(2, 6))
+    nx, ny = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+    nz = int(rng.integers(2 * world * 2, 110))
+    box, grid = (8.0, 8.0, 8.0), (128, 128, 128)
+    pos, vel = ic.dam_break_lattice((nx, ny, nz), box, jitter=True)
+    mode = int(rng.integers(0, 4))
+    if mode == 0:
+        vel[:, 2] = float(rng.uniform(-9000, 9000))
+    elif mode == 1:
+        vel[:, 2] = rng.uniform(-20000, 20000, pos.shape[0]).astype(np.float32)
+    elif mode == 2:
+        vel[:, 2] = np.where(pos[:, 2] > np.median(pos[:, 2]), 6000.0, -6000.0)
+    else:
+        vel[:] = rng.uniform(-3000, 3000, pos.shape).astype(np.float32)
+    steps = int(rng.integers(5, 40))
+    transport = "local" if rng.random() < 0.8 else "host"
+    res = _run_slabs(world, box, grid, steps, particles=(pos, vel), transport=transport, protocol=1,
+                     rebalance_every=7 if seed >= 3000 else 0, early_force=True if seed % 2 else "auto")
+    assert sum(r[3] for r in res) == pos.shape[0]
+    assert all(r[1]["host_waits"] == steps + r[1]["far_steps"] and _exchanges_ok(r[1]) and r[1]["one_message_steps"] > 0 for r in res), \
+        [r[1] for r in res]
+    fields = ("pos", "vel") if seed >= 3000 and steps % 7 == 0 else ("pos", "vel", "density", "pressure")    # (a re-cut on the last step: densities are the next step's)
+    ref = _whole_domain(pos, vel, box, grid, steps)
+    for k in fields:
+        assert np.array_equal(bits(res[0][0][k]), bits(ref[k])), k
+
+
 @pytest.mark.parametrize("case", ["burst", "ramp"])
 def test_movers_sort_forms_in_a_slab(case):
     """A slab's host knows the mover count of the PREVIOUS sort and launches only the sort form that count asks for
@@ -514,7 +595,8 @@ def test_movers_sort_forms_in_a_slab(case):
     _same_bits(res[0][0], ref)
 
 
-def test_a_failure_on_one_rank_reaches_every_rank_within_steps_not_timeouts():
+@pytest.mark.parametrize("protocol", [3, 1])
+def test_a_failure_on_one_rank_reaches_every_rank_within_steps_not_timeouts(protocol):
     """The top rank of three has room for exactly the particles it starts with; the fluid moves up, so the first lattice
     layer that arrives overflows it: SPH_E_CAPACITY there -- and only there, its neighbours cannot know.  The failing rank
     still exchanges what the step owes (so nobody is left waiting for a halo), then sends "abort" in its next migrant
@@ -532,7 +614,8 @@ def test_a_failure_on_one_rank_reaches_every_rank_within_steps_not_timeouts():
         sim = None
         try:
             sim = slab.NativeSlabSimulation(_comm(hub, dev_hub, r), box, grid, device_index=0, transport="local", particles=(pos, vel),
-                                            capacity_factor=1.0 if r == world - 1 else 1.5, capacity_slack=0 if r == world - 1 else 4096)
+                                            capacity_factor=1.0 if r == world - 1 else 1.5, capacity_slack=0 if r == world - 1 else 4096,
+                                            protocol=protocol)
             for k in range(60):
                 sim.run(DT, 1)
                 steps_done[r] = k + 1
@@ -653,14 +736,16 @@ def test_neighbour_ping_checks_sender_direction_and_size():
     assert "never sent" in str(errors[0]) or "ping" in str(errors[0]), errors
 
 
-def test_slab_timing_reports_every_message_group():
+@pytest.mark.parametrize("protocol", [3, 1])
+def test_slab_timing_reports_every_message_group(protocol):
     """sph_slab_timing_*: host-side step timing is always on; with timing enabled every transport call of a step is
-    bracketed by an event pair on the comm stream -- three groups per step (+ the rest message on a burst)."""
+    bracketed by an event pair on the comm stream -- three groups per step (+ the rest message on a burst), or the one group
+    of the one-message step."""
     pos, vel, box, grid = make_case("up")
     steps = 12
 
     def body(make, r):
-        sim = make(box=box, grid=grid, particles=(pos, vel))
+        sim = make(box=box, grid=grid, particles=(pos, vel), protocol=protocol)
         try:
             sim.run(DT, 3)
             sim.slab_timing_reset(); sim.slab_timing_enable(True)
@@ -679,14 +764,17 @@ def test_slab_timing_reports_every_message_group():
         for k in ("host_wait_us", "host_pre_us", "host_post_us", "host_step_us"):
             assert 0.0 < t[k]["mean"] <= t[k]["max"], (k, t[k])
         assert t["host_step_us"]["mean"] >= t["host_wait_us"]["mean"]
-        for g in ("migrants", "halo_a", "halo_b"):
+        for g in ("migrants", "halo_a", "halo_b") if protocol == 3 else ("one",):
             e = t["exchange_us_" + g]
             assert e["calls"] == steps and 0.0 < e["mean"] <= e["max"], (g, e)
+        for g in ("one", "one_rest") if protocol == 3 else ("migrants", "halo_a", "halo_b"):
+            assert t["exchange_us_" + g]["calls"] == 0, (g, t["exchange_us_" + g])
         assert t["exchange_us_migrants_rest"]["calls"] == 0
-        assert t_off["steps"] == 2 and all(t_off["exchange_us_" + g]["calls"] == 0 for g in ("migrants", "halo_a", "halo_b"))
+        assert t_off["steps"] == 2 and all(t_off["exchange_us_" + g]["calls"] == 0 for g in ("migrants", "halo_a", "halo_b", "one"))
 
 
-def test_a_failure_before_the_migrant_message_reaches_the_neighbours_in_the_same_step():
+@pytest.mark.parametrize("protocol", [3, 1])
+def test_a_failure_before_the_migrant_message_reaches_the_neighbours_in_the_same_step(protocol):
     """a step that fails BEFORE it has posted its migrant message (a device-side flag of the previous step's
     insert kernel, the sort, a launch) used to send nothing -- the neighbours then sat out the whole wait time-out.  Now the
     abort header travels as that step's migrant message: the middle rank of three raises the sticky 'arrival outside its
@@ -697,7 +785,7 @@ def test_a_failure_before_the_migrant_message_reaches_the_neighbours_in_the_same
     t0 = time.perf_counter()
 
     def body(make, r):
-        sim = make(box=box, grid=grid, particles=(pos, vel))
+        sim = make(box=box, grid=grid, particles=(pos, vel), protocol=protocol)
         done, err = 0, None
         try:
             for k in range(20):
@@ -720,7 +808,8 @@ def test_a_failure_before_the_migrant_message_reaches_the_neighbours_in_the_same
     assert max(o[3] for o in out) < 30.0, out
 
 
-def test_a_failure_on_the_last_step_still_lets_every_slab_close():
+@pytest.mark.parametrize("protocol", [3, 1])
+def test_a_failure_on_the_last_step_still_lets_every_slab_close(protocol):
     """a rank that fails queues an "abort" migrant message for its neighbours' NEXT step.  When there is no next
     step (the failure came on the last one) that message is never matched: closing the slab must give up after the wait
     time-out (here 2 s; over RCCL the same bound ends in ncclCommAbort) instead of blocking in a stream synchronise."""
@@ -729,7 +818,7 @@ def test_a_failure_on_the_last_step_still_lets_every_slab_close():
 
     def body(make, r):
         sim = make(box=box, grid=grid, particles=(pos, vel), capacity_factor=1.0 if r == 2 else 1.5,
-                   capacity_slack=0 if r == 2 else 4096)
+                   capacity_slack=0 if r == 2 else 4096, protocol=protocol)
         capi._check(capi.load().sph_slab_set_wait_timeout(sim._slab, 2.0))
         done, err = 0, None
         try:
@@ -797,7 +886,35 @@ def test_recut_by_several_layers_in_hops_and_into_an_empty_slab():
     assert all(o[4]["host_waits"] == o[4]["steps"] + o[4]["far_steps"] for o in out)
 
 
-def test_one_slab_between_its_periodic_images_matches_three_stacked_copies():
+def test_recut_under_the_one_message_step():
+    """sph_slab_recut with the one-message protocol: cuts moved by hand (slabs of >= 4 layers: a thinner one is SPH_E_INVALID
+    there), steps in between -- each re-cut is followed by one three-group step that learns the message sizes again."""
+    pos, vel, box, grid = make_case("shear")
+    world, gz = 3, grid[2]
+    plans = [[0, 4, 8, gz], [0, 6, 10, gz], [0, 4, 8, gz]]
+
+    def body(make, r):
+        sim = make(box=box, grid=grid, particles=(pos, vel), capacity_factor=3.2, protocol=1)
+        try:
+            for cuts in plans:
+                sim.run(DT, 5)
+                sim.rebalance(cuts=cuts)
+            sim.run(DT, 5)
+            sim.sync()
+            bad = capi.load().sph_slab_recut(sim._slab, 0, 2) if r == 0 else 0       # (not collective: refused before anything is sent)
+            return sim.gather_state(), dict(sim.stats), bad
+        finally:
+            sim.close()
+
+    out, errors = _with_ranks(world, body, timeout_s=300)
+    assert errors == [None] * world, errors
+    _same_bits(out[0][0], _whole_domain(pos, vel, box, grid, 5 * (len(plans) + 1)))
+    assert out[0][2] == -1                                                         # SPH_E_INVALID: two layers
+    assert all(o[1]["one_message_steps"] == 20 - 1 - 2 and _exchanges_ok(o[1]) for o in out), [o[1] for o in out]
+
+
+@pytest.mark.parametrize("protocol", [3, 1])
+def test_one_slab_between_its_periodic_images_matches_three_stacked_copies(protocol):
     """The loop transport (sph_loop_transport_create; `bench.py --force-slab --periodic-z`): one slab whose neighbours are its own
     images shifted by the slab height does ALL the work of a rank between two neighbours -- migrants in both directions,
     both halo messages, ghost unpack, boundary launches -- on one device.  Physics check: the same slice stacked THREE times
@@ -818,12 +935,15 @@ def test_one_slab_between_its_periodic_images_matches_three_stacked_copies():
     steps = 5
     z_lo, z_hi = 24, 32
     L = capi.load()
-    with capi.Context(2 * n + 1024, params=capi.default_params(box, grid), slab=(z_lo, z_hi), ghost_capacity=4 * nx * ny + 1024) as c:
+    with capi.Context(2 * n + 1024, params=capi.default_params(box, grid), slab=(z_lo, z_hi), ghost_capacity=8 * nx * ny + 1024,
+                      ghost_layers=2 if protocol == 1 else 1) as c:
         c.upload(P, V)
         tr = C.POINTER(capi.Transport)()
         capi._check(L.sph_loop_transport_create(C.byref(tr), float(H), 0.0, 0.0))
         h = C.c_void_p()
         capi._check(L.sph_slab_create(C.byref(h), c.h, 1, 3, tr, 0))
+        if protocol == 1:
+            capi._check(L.sph_slab_set_protocol(h, 1))
         try:
             capi._check(L.sph_slab_step(h, DT, steps))
             capi._check(L.sph_slab_sync(h))
@@ -835,7 +955,7 @@ def test_one_slab_between_its_periodic_images_matches_three_stacked_copies():
             L.sph_slab_destroy(h)
             L.sph_loop_transport_destroy(tr)
     assert owned == n and int(cnt[1]) > 0 and int(cnt[4]) == steps            # nobody lost, some wrapped around, one wait per step
-    assert exchanges == 3 * steps + int(cnt[7])
+    assert exchanges == (3 * steps if protocol == 3 else 3 + steps - 1) + int(cnt[7])
     lo, hi = P.copy(), P.copy()
     lo[:, 2] = P[:, 2] - H; hi[:, 2] = P[:, 2] + H                        # the images' fp32 positions, as the transport makes them
     ref = _whole_domain(np.concatenate([lo, P, hi]), np.concatenate([V, V, V]), box, grid, steps)
