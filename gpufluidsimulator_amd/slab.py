@@ -280,7 +280,8 @@ class HipEngine:
 # ------------------------------------------------------------------------------------------------
 class SlabSimulation:
     def __init__(self, comm, engine_factory, box, grid, lattice=None, jitter=True, jitter_dims=None,
-                 capacity_factor=1.5, ghost_factor=3.0, particles=None, capacity_slack=4096, device_lattice=None, min_layers=None):
+                 capacity_factor=1.5, ghost_factor=3.0, particles=None, capacity_slack=4096, device_lattice=None, min_layers=None,
+                 python_protocol=3):
         """comm: TorchDistComm | LocalComm.  engine_factory(capacity, ghost_capacity, params, z_lo, z_hi)
         builds this rank's engine.  Either `lattice` (dam break generated slab by slab) or
         `particles` = (pos, vel) of the WHOLE system (small tests)."""
@@ -293,6 +294,12 @@ class SlabSimulation:
         self.box = tuple(float(b) for b in box)
         self.grid = tuple(int(g) for g in grid)
         self.params = capi.default_params(self.box, self.grid)
+        # which protocol THIS class's Python step speaks (NativeSlabSimulation's step is the library's: its own `protocol`)
+        self.python_protocol = int(python_protocol)
+        if self.python_protocol == 1:
+            min_layers = max(int(min_layers or 0), 4)
+            ghost_factor = max(ghost_factor, 6.0)
+        self._one_prev = None            # [[sent lo, sent hi], [received lo, received hi]] record totals of the last step
         self.min_layers = int(min_layers or MIN_SLAB_LAYERS)
         gz = self.grid[2]
         if device_lattice is None:         # the product engine generates its lattice layers on the device when it can
@@ -358,6 +365,9 @@ class SlabSimulation:
         self.capacity = int(capacity_factor * max(n_own, self.total // self.world)) + int(capacity_slack)
         self._factory = engine_factory
         self.engine = engine_factory(self.capacity, self.ghost_capacity, self.params, z_lo, z_hi)
+        if self.python_protocol == 1 and not hasattr(self.engine, "pack_one"):
+            raise ValueError("python_protocol=1 needs an engine with two ghost layers and pack_one / second_layer_counts (the product "
+                             "path runs this protocol inside the library: NativeSlabSimulation(protocol=1))")
         if device_run is None:
             self.engine.upload(pos, vel, index)
         else:
@@ -374,10 +384,76 @@ class SlabSimulation:
         self.recv_lo, self.recv_hi = e.buffer(g, REC), e.buffer(g, REC)
         self.dsend_lo, self.dsend_hi = e.buffer(g, 2), e.buffer(g, 2)
         self.drecv_lo, self.drecv_hi = e.buffer(g, 2), e.buffer(g, 2)
-        self.cnt_recv_lo, self.cnt_recv_hi = e.small([0, 0]), e.small([0, 0])
+        self.cnt_recv_lo, self.cnt_recv_hi = e.small([0, 0, 0]), e.small([0, 0, 0])
 
     # -- one time step ---------------------------------------------------------------------------------
+    @staticmethod
+    def one_message_rows(prev_total):
+        """Records the one message of a step carries behind its header, from the count both ends saw in the step before
+        (csrc/sph_slab.hip: one_cap)."""
+        return (int(prev_total) + int(prev_total) // 16 + 1024 + 63) & ~63
+
+    def _step_one(self, dt):
+        """The ONE-MESSAGE step in Python (the statement of csrc/sph_slab.hip's protocol 1 that CPU ranks can run): header,
+        leavers and the residents of the two layers next to each cut in one message per neighbour whose size was fixed from
+        the previous step's counts; the receiver completes its copy of the neighbour's layers with its own leavers and
+        computes the ghost densities itself (the engine's density pass covers owned + ghosts: the inner ghost layer has its
+        whole neighbourhood here).  No density message.  A message that outgrew its size sends the rest in a second one."""
+        import torch
+        e, c = self.engine, self.comm
+        peers = (self.lo_peer, self.hi_peer)
+        e.hash(); e.sort()
+        m_lo, own_lo, own_hi, m_hi = e.slab_counts()
+        n2_lo, n2_hi = e.second_layer_counts()
+        if peers[0] is None: assert m_lo == 0, "particles below the box floor"
+        if peers[1] is None: assert m_hi == 0, "particles above the box ceiling"
+        mine = ((m_lo, own_lo, n2_lo), (m_hi, own_hi, n2_hi))
+        tot_s = [sum(mine[k]) if peers[k] is not None else 0 for k in (0, 1)]
+        S_s = [self.one_message_rows(self._one_prev[0][k]) if peers[k] is not None else 0 for k in (0, 1)]
+        S_r = [self.one_message_rows(self._one_prev[1][k]) if peers[k] is not None else 0 for k in (0, 1)]
+        g = self.ghost_capacity
+        assert max(S_s + S_r + tot_s) + 1 <= g, "the one message exceeds the buffers"
+        send, recv = (self.send_lo, self.send_hi), (self.recv_lo, self.recv_hi)
+        e.pack_one(send[0], send[1])                       # rows 1..: leavers, then two layers of residents; leavers dropped
+        for k in (0, 1):
+            send[k][0, :3] = e.small(list(mine[k])).to(send[k].dtype)       # (counts < 2^24: exact in fp32)
+        sends = [(peers[k], send[k][:1 + S_s[k]]) for k in (0, 1) if peers[k] is not None]
+        recvs = [(peers[k], recv[k][:1 + S_r[k]]) for k in (0, 1) if peers[k] is not None]
+        c.exchange(sends, recvs)
+        theirs = [tuple(int(v) for v in recv[k][0, :3].tolist()) if peers[k] is not None else (0, 0, 0) for k in (0, 1)]
+        tot_r = [sum(theirs[k]) for k in (0, 1)]
+        assert max(tot_r) + 1 <= g, "a neighbour's message exceeds the buffers"
+        if any(tot_s[k] > S_s[k] or tot_r[k] > S_r[k] for k in (0, 1)):         # a burst: the rest, exact (both ends know both totals)
+            sends = [(peers[k], send[k][1 + S_s[k]:1 + tot_s[k]]) for k in (0, 1) if peers[k] is not None and tot_s[k] > S_s[k]]
+            recvs = [(peers[k], recv[k][1 + S_r[k]:1 + tot_r[k]]) for k in (0, 1) if peers[k] is not None and tot_r[k] > S_r[k]]
+            c.exchange(sends, recvs)
+            self.stats["one_rests"] = self.stats.get("one_rests", 0) + 1
+        # arrivals join the owned set; a second sort merges them (as in the three-group step)
+        arrived = False
+        for k in (0, 1):
+            if theirs[k][0]:
+                e.migrants_append(recv[k][1:1 + theirs[k][0]], theirs[k][0]); arrived = True
+        if arrived:
+            e.hash(); e.sort()
+            self.stats["resorts"] += 1
+        self.stats["migrants"] += m_lo + m_hi
+        # ghosts of a side: the neighbour's two layers of residents + what I just sent into them
+        ghosts = []
+        for k in (0, 1):
+            res = recv[k][1 + theirs[k][0]:1 + tot_r[k]]
+            lv = send[k][1:1 + mine[k][0]]
+            ghosts.append(torch.cat([res, lv]))
+        e.halo_unpack(ghosts[0], ghosts[0].shape[0], ghosts[1], ghosts[1].shape[0])
+        self.stats["ghosts"] += ghosts[0].shape[0] + ghosts[1].shape[0]
+        e.build_cells()
+        e.density()
+        e.force_collide_integrate(dt)
+        self._one_prev = [tot_s, tot_r]
+        self.stats["one_steps"] = self.stats.get("one_steps", 0) + 1
+
     def step(self, dt):
+        if self.python_protocol == 1 and self._one_prev is not None:
+            return self._step_one(dt)
         e, c = self.engine, self.comm
         lo, hi = self.lo_peer, self.hi_peer
         e.hash(); e.sort()
@@ -387,15 +463,20 @@ class SlabSimulation:
             m_lo, own_lo, own_hi, m_hi = self._counts = e.slab_counts()
         if lo is None: assert m_lo == 0, "particles below the box floor"
         if hi is None: assert m_hi == 0, "particles above the box ceiling"
-        # counts: {migrants towards the peer, my boundary-layer particles that stay}
+        # counts: {migrants towards the peer, my boundary-layer particles that stay, my SECOND layer's (what a following
+        # one-message step sizes its message from)}
+        n2_lo, n2_hi = e.second_layer_counts() if self.python_protocol == 1 else (0, 0)
         sends, recvs = [], []
         if lo is not None:
-            sends.append((lo, e.small([m_lo, own_lo]))); recvs.append((lo, self.cnt_recv_lo))
+            sends.append((lo, e.small([m_lo, own_lo, n2_lo]))); recvs.append((lo, self.cnt_recv_lo))
         if hi is not None:
-            sends.append((hi, e.small([m_hi, own_hi]))); recvs.append((hi, self.cnt_recv_hi))
+            sends.append((hi, e.small([m_hi, own_hi, n2_hi]))); recvs.append((hi, self.cnt_recv_hi))
         c.exchange(sends, recvs)
-        in_lo, peer_own_lo = (int(v) for v in self.cnt_recv_lo.tolist()) if lo is not None else (0, 0)
-        in_hi, peer_own_hi = (int(v) for v in self.cnt_recv_hi.tolist()) if hi is not None else (0, 0)
+        in_lo, peer_own_lo, n2p_lo = (int(v) for v in self.cnt_recv_lo.tolist()) if lo is not None else (0, 0, 0)
+        in_hi, peer_own_hi, n2p_hi = (int(v) for v in self.cnt_recv_hi.tolist()) if hi is not None else (0, 0, 0)
+        if self.python_protocol == 1:      # both ends of a link hold the same six numbers
+            self._one_prev = [[m_lo + own_lo + n2_lo if lo is not None else 0, m_hi + own_hi + n2_hi if hi is not None else 0],
+                              [in_lo + peer_own_lo + n2p_lo, in_hi + peer_own_hi + n2p_hi]]
         g = self.ghost_capacity
         assert max(m_lo, m_hi, in_lo, in_hi) <= g, "migrant burst exceeds the ghost capacity"
         # migrants
@@ -512,6 +593,7 @@ class SlabSimulation:
         self.capacity = max(self.capacity, int(1.5 * n_own) + 4096)
         self.engine = self._factory(self.capacity, self.ghost_capacity, self.params, self.z_lo, self.z_hi)
         self._counts = None
+        self._one_prev = None              # (new layers: the next step learns the one message's sizes again)
         self.engine.upload(rec[:, 0:3].copy(), rec[:, 4:7].copy(), np.ascontiguousarray(rec[:, 3]).view(np.uint32).copy())
         self._alloc_buffers()
         self.stats["rebalances"] = self.stats.get("rebalances", 0) + 1

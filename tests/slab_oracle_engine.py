@@ -20,12 +20,15 @@ def _cell(p, bmin, bdim, g):
 
 
 class OracleEngine:
+    GHOST_LAYERS = 1            # OracleEngine2 below: two (the one-message protocol)
+
     def __init__(self, capacity, ghost_capacity, params, z_lo, z_hi):
         self.grid = tuple(int(v) for v in params.grid)
         self.bmin = np.float32(list(params.box_min))
         self.bdim = np.float32(list(params.box_max)) - self.bmin
         self.box = tuple(float(v) for v in self.bdim)
-        self.z_lo, self.z_hi, self.zl = int(z_lo), int(z_hi), int(z_hi - z_lo + 2)
+        self.G = int(self.GHOST_LAYERS)
+        self.z_lo, self.z_hi, self.zl = int(z_lo), int(z_hi), int(z_hi - z_lo + 2 * self.G)
         self.layer = self.grid[0] * self.grid[1]
         self.capacity, self.ghost_capacity = capacity, ghost_capacity
         self.pos = np.zeros((0, 3), np.float32); self.vel = np.zeros((0, 3), np.float32)
@@ -56,7 +59,7 @@ class OracleEngine:
     # grid phases -----------------------------------------------------------------------------------
     def hash(self):
         c = [_cell(self.pos[:, a], self.bmin[a], self.bdim[a], self.grid[a]) for a in range(3)]
-        lz = np.clip(c[2] - self.z_lo + 1, 0, self.zl - 1)
+        lz = np.clip(c[2] - self.z_lo + self.G, 0, self.zl - 1)
         self.key = (lz * self.grid[1] + c[1]) * self.grid[0] + c[0]
 
     def sort_skipped(self): return False        # the CPU test engine always sorts
@@ -69,9 +72,27 @@ class OracleEngine:
         self._clear_ghosts()
 
     def slab_counts(self):
-        L = self.layer
-        lb = np.searchsorted(self.key, [L, 2 * L, (self.zl - 2) * L, (self.zl - 1) * L], side="left")
+        L, G = self.layer, self.G
+        lb = np.searchsorted(self.key, [G * L, (G + 1) * L, (self.zl - G - 1) * L, (self.zl - G) * L], side="left")
         return int(lb[0]), int(lb[1] - lb[0]), int(lb[3] - lb[2]), int(self.n - lb[3])
+
+    # ---- the one-message protocol (slab.SlabSimulation._step_one): two layers per side --------------------------------
+    def second_layer_counts(self):
+        L, G = self.layer, self.G
+        lb = np.searchsorted(self.key, [(G + 1) * L, (G + 2) * L, (self.zl - G - 2) * L, (self.zl - G - 1) * L], side="left")
+        return int(lb[1] - lb[0]), int(lb[3] - lb[2])
+
+    def pack_one(self, lo, hi):
+        """Rows 1.. of each buffer (row 0 is the caller's header): my leavers towards that side, then the RESIDENTS of the two
+        owned layers next to that cut, in slot order; the leavers are dropped from the owned set."""
+        m_lo, own_lo, own_hi, m_hi = self.slab_counts()
+        n2_lo, n2_hi = self.second_layer_counts()
+        n = self.n
+        lo.numpy()[1:1 + m_lo] = self._records(slice(0, m_lo))
+        lo.numpy()[1 + m_lo:1 + m_lo + own_lo + n2_lo] = self._records(slice(m_lo, m_lo + own_lo + n2_lo))
+        hi.numpy()[1:1 + m_hi] = self._records(slice(n - m_hi, n))
+        hi.numpy()[1 + m_hi:1 + m_hi + own_hi + n2_hi] = self._records(slice(n - m_hi - own_hi - n2_hi, n - m_hi))
+        self._keep(slice(m_lo, n - m_hi))
 
     def _records(self, sl):
         r = np.zeros((self.pos[sl].shape[0], 8), np.float32)
@@ -98,8 +119,9 @@ class OracleEngine:
         assert self.n <= self.capacity
 
     def _halo_counts(self):
-        L = self.layer
-        return int(np.searchsorted(self.key, 2 * L)), int(self.n - np.searchsorted(self.key, (self.zl - 2) * L))
+        L, G = self.layer, self.G
+        lb = np.searchsorted(self.key, [G * L, (G + 1) * L, (self.zl - G - 1) * L, (self.zl - G) * L], side="left")
+        return int(lb[1] - lb[0]), int(lb[3] - lb[2])
 
     def halo_pack(self, lo, hi, counts=None):
         h_lo, h_hi = self._halo_counts()
@@ -166,6 +188,12 @@ class OracleEngine:
         return out
 
 
+class OracleEngine2(OracleEngine):
+    """Two ghost layers per side: what the one-message protocol needs (the ghost densities then come out of this engine's own
+    density pass over owned + ghosts: the inner ghost layer's neighbourhood is complete)."""
+    GHOST_LAYERS = 2
+
+
 def make_case(name):
     """Small systems that force particles across slab boundaries within a few steps."""
     from gpufluidsimulator_amd import ic
@@ -184,7 +212,7 @@ def make_case(name):
     return pos, vel, box, grid
 
 
-def gloo_worker(rank, world, port, case, steps, out_dir):
+def gloo_worker(rank, world, port, case, steps, out_dir, protocol=3):
     """Entry of one CPU rank (torch.multiprocessing.spawn): TorchDistComm over gloo."""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -193,12 +221,13 @@ def gloo_worker(rank, world, port, case, steps, out_dir):
     try:
         pos, vel, box, grid = make_case(case)
         comm = slab.TorchDistComm(torch.device("cpu"))
-        sim = slab.SlabSimulation(comm, OracleEngine, box, grid, particles=(pos, vel))
+        sim = slab.SlabSimulation(comm, OracleEngine2 if protocol == 1 else OracleEngine, box, grid, particles=(pos, vel),
+                                  python_protocol=protocol)
         sim.run(5e-7, steps)
         st = sim.gather_state()
         if rank == 0:
             np.savez(os.path.join(out_dir, "out.npz"), cuts=np.array(sim.cuts), migrants=sim.stats["migrants"], **st)
-        stats = comm.allreduce_sum(np.array([sim.stats["migrants"], sim.stats["resorts"]], dtype=np.int64))
+        stats = comm.allreduce_sum(np.array([sim.stats["migrants"], sim.stats["resorts"], sim.stats.get("one_steps", 0)], dtype=np.int64))
         if rank == 0:
             np.save(os.path.join(out_dir, "stats.npy"), stats)
     finally:

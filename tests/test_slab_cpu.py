@@ -13,7 +13,7 @@ import pytest
 
 from gpufluidsimulator_amd import slab
 from oracle import oracle
-from slab_oracle_engine import OracleEngine, gloo_worker, make_case
+from slab_oracle_engine import OracleEngine, OracleEngine2, gloo_worker, make_case
 
 DT = 5e-7
 
@@ -92,17 +92,66 @@ def test_slabs_in_process_match_single_domain(case, world):
         assert np.array_equal(other[0]["pos"], st["pos"])
 
 
-def test_slabs_over_gloo_world_size_2():
+@pytest.mark.parametrize("protocol", [3, 1])
+def test_slabs_over_gloo_world_size_2(protocol):
+    """Two real processes over torch.distributed's gloo backend -- under the three-group protocol and under the one-message
+    protocol (slab.SlabSimulation._step_one, the Python statement of csrc/sph_slab.hip's protocol 1: one fixed-size message
+    per neighbour and step, ghost densities recomputed by the receiver)."""
     import torch.multiprocessing as mp
     steps = 16
     with tempfile.TemporaryDirectory() as d:
-        port = 29500 + (os.getpid() % 2000)
-        mp.spawn(gloo_worker, args=(2, port, "up", steps, d), nprocs=2, join=True)
+        port = 29500 + (os.getpid() % 2000) + protocol
+        mp.spawn(gloo_worker, args=(2, port, "tall_up" if protocol == 1 else "up", steps, d, protocol), nprocs=2, join=True)
         out = np.load(os.path.join(d, "out.npz"))
         stats = np.load(os.path.join(d, "stats.npy"))
-    ref, box = _single_domain("up", steps)
+    ref, box = _single_domain("tall_up" if protocol == 1 else "up", steps)
     _check(out, ref, box)
     assert stats[0] > 0
+    assert stats[2] == (2 * (steps - 1) if protocol == 1 else 0)                 # one-message steps, summed over the two ranks
+
+
+@pytest.mark.parametrize("case,world", [("up", 3), ("shear", 3), ("down", 2)])
+def test_one_message_protocol_in_process_matches_single_domain(case, world):
+    """The one-message protocol with in-process CPU ranks and the oracle engine (two ghost layers): the first step speaks the
+    three-group protocol and learns the counts, every later step is ONE exchange (+ the rest of a message that outgrew its
+    size); no density message at all -- the receiving rank's own density pass covers its ghosts."""
+    steps = 24
+    pos, vel, box, grid = make_case(case)
+    hub = slab.LocalComm.Hub(world)
+    results, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            sim = slab.SlabSimulation(slab.LocalComm(hub, r), OracleEngine2, box, grid, particles=(pos, vel), python_protocol=1)
+            assert all(b - a >= 4 for a, b in zip(sim.cuts, sim.cuts[1:]))
+            sim.run(DT, steps)
+            results[r] = (sim.gather_state(), dict(sim.stats), sim.cuts)
+        except BaseException as e:     # noqa: BLE001
+            errors.append(e)
+            hub.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=600)
+    assert not errors, errors
+    st, stats, cuts = results[0]
+    ref, _ = _single_domain(case, steps)
+    _check(st, ref, box)
+    assert sum(res[1]["migrants"] for res in results) > 0
+    assert all(res[1]["one_steps"] == steps - 1 for res in results), [res[1] for res in results]
+
+
+def test_one_message_rule_and_cuts():
+    """The size rule both ends of a link apply to the previous step's counts (csrc/sph_slab.hip: one_cap), and cuts of at
+    least four layers for the protocol that sends two of them to either side."""
+    f = slab.SlabSimulation.one_message_rows
+    assert f(0) == 1024 and f(1000) == 2112 and f(262144) == 279552 and all(f(k) % 64 == 0 and f(k) >= k + 1024 for k in (1, 63, 4097, 10 ** 6))
+    hist = np.zeros(64, dtype=np.int64); hist[0:16] = 1000
+    assert slab.choose_cuts(hist, 4, 4) == [0, 4, 8, 12, 64]
+    cuts = slab.choose_cuts(hist, 8, 4)
+    assert all(b - a >= 4 for a, b in zip(cuts, cuts[1:])) and cuts[-1] == 64
+    with pytest.raises(ValueError):
+        slab.choose_cuts(np.ones(15), 4, 4)
 
 
 def test_rebalance_moves_the_cuts_and_keeps_the_physics():
