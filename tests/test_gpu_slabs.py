@@ -305,15 +305,16 @@ def test_one_message_step_with_particles_crossing_two_layers_and_refusing_three(
     nobody's copy: SPH_E_STATE on the ranks that see it, SPH_E_PEER on the others (the three-group protocol takes such a
     particle as long as it lands in an interior layer: test_particle_crossing_two_layers_in_one_step)."""
     pos, vel, box, grid, fast = _far_case()
-    vel[fast, 2] = 1.5e5               # 0.075 = 1.2 cell layers per step: from the top layers of slab 0 into layers 4 and 5 of slab 1
-    steps, world = 4, 3
+    vel[fast, 2] = 2.0e5               # 0.1 = 1.6 cell layers per step: from 3.25 / 3.75 cells (the top layer of slab 0) to 4.85 / 5.35,
+    steps, world = 4, 3                # i.e. into the FIRST and the SECOND layer of slab 1
     res = _run_slabs(world, box, grid, steps, particles=(pos, vel), protocol=1)
     assert res[0][2] == [0, 4, 8, 64]
     assert sum(r[1]["far_steps"] for r in res) >= 1 and all(r[1]["one_message_steps"] == steps - 1 for r in res), [r[1] for r in res]
     ref = _whole_domain(pos, vel, box, grid, steps)
     assert np.abs(ref["pos"][fast, 2] - pos[fast, 2]).min() > 0.0625
     _same_bits(res[0][0], ref)
-    pos, vel, box, grid, fast = _far_case()            # 2.24 layers per step: beyond the second layer
+    pos, vel, box, grid, fast = _far_case()
+    vel[fast, 2] = 3.4e5               # 2.72 layers per step: from 3.75 to 6.47 cells, the THIRD layer of slab 1
     errors = _run_slabs(world, box, grid, steps, particles=(pos, vel), protocol=1, expect_error=True)
     assert errors and any("more than TWO cell layers" in str(e) for e in errors), errors
 
@@ -394,15 +395,17 @@ def test_one_message_step_burst_outgrows_the_size_fixed_in_advance():
     """The one message of a step is sized from the counts of the step BEFORE (+ 1/16 + 1024 records); when a whole lattice layer
     crosses a cut at once the message outgrows that and the rest follows in a second, exact message -- on that step only."""
     box, grid = (4.0, 4.0, 4.0), (64, 64, 64)
-    steps, world = 6, 3
-    # a 48 x 48 x 24 block: 2304 particles per lattice layer; the layers just under the two cuts (3.75 / 7.75 cells) move
-    # 0.1 cells per step: they cross at the third step, in the middle of the one-message steps
-    pos2, vel2 = ic.dam_break_lattice((48, 48, 24), box, jitter=True)
-    iz2 = np.arange(pos2.shape[0]) // (48 * 48)
-    vel2[(iz2 == 7) | (iz2 == 15), 2] = 1.25e4
+    steps, world = 8, 2
+    # (Leavers alone never outgrow it: they come out of the residents the message already carried.  What does is fluid reaching
+    # layers that were EMPTY:) a 48 x 48 x 8 block = 2304 particles per lattice plane in cell layers 0..3, all of slab 0 of two
+    # (slabs of >= 4 layers: cuts [0, 4, 64]); the block rises 0.1 cells per step, its top plane (3.75 cells) enters slab 1 at the
+    # third step -- slab 1's boundary layer goes from 0 to 2304 residents at once, against the 1024 records its message was sized for
+    pos2, vel2 = ic.dam_break_lattice((48, 48, 8), box, jitter=True)
+    vel2[:, 2] = 1.25e4
     res = _run_slabs(world, box, grid, steps, particles=(pos2, vel2), protocol=1)
-    assert sum(r[1]["one_message_rests"] for r in res) >= 2, [r[1] for r in res]
-    assert sum(r[1]["migrants"] for r in res) >= 2 * 2304 and all(_exchanges_ok(r[1]) for r in res)
+    assert res[0][2] == [0, 4, 64], res[0][2]
+    assert all(r[1]["one_message_rests"] >= 1 for r in res), [r[1] for r in res]
+    assert sum(r[1]["migrants"] for r in res) >= 2304 and all(_exchanges_ok(r[1]) for r in res)
     assert all(r[1]["one_message_steps"] == steps - 1 for r in res)
     _same_bits(res[0][0], _whole_domain(pos2, vel2, box, grid, steps))
 
