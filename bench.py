@@ -471,7 +471,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["wall"] / args.steps * 1e3,
         # the N = 1 point of the strong-scaling series BASELINE's metric names (the same 16.7 M particles on 1/2/4/8 GPUs)
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "f32 state + packed-f16 density pairs (config 5)", "data": "synthetic",
+        "dtype": "f32" if args.precision == "f32" else "f32 state + packed-f16 density pairs (config 5's arithmetic: an option, slower than fp32 on gfx950)", "data": "synthetic",
         "config": {"workload": f"dam-break {args.workload}: {cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} "
                                f"= {n} particles, grid {cfg['grid'][0]}^3, box {cfg['box'][0]}, dt 5e-7, jittered lattice"
                                f"{' (BASELINE config 4 on one GPU: the N = 1 point of --scaling strong)' if args.workload == 'C4' else ''}, "

@@ -1127,7 +1127,7 @@ def bench_rank(comm, local, args, transport, log=None):
             "metric": "particle-steps/sec", "value": total * args.steps / wall, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32 state + packed-f16 density pairs (config 5)" if mixed else "f32",
+            "dtype": "f32 state + packed-f16 density pairs (config 5's arithmetic: an option, slower than fp32 on gfx950)" if mixed else "f32",
             "data": "synthetic",
             "config": {"workload": f"dam-break {label}: "
                                    f"{cfg['lattice'][0]}x{cfg['lattice'][1]}x{cfg['lattice'][2]} = {total} particles "
