@@ -30,6 +30,13 @@
 //   step through the pass over all particles instead) ; pack boundary layers -> HALO A ; density interior-minus-deep
 //   while it travels ; (event) density boundary ; pack (rho, p) -> HALO B ; force interior ; force boundary on comm
 //
+// Round 6: a second protocol beside this one (sph_slab_set_protocol(s, 1); the context then keeps TWO ghost layers): ONE message per
+// neighbour and step -- header, leavers and the residents of the two layers next to the cut as they are right after the sort, its
+// size fixed in advance by a rule on the previous step's counts -- in the place of MIGRANTS; no HALO A (the receiver merges its own
+// leavers into its copy of the neighbour's layers: k_slab_unpack_ghosts_merge) and no HALO B (the density launch over "everything
+// that is not deep" also covers the inner ghost layers: same candidates, same order, the neighbour's bits).  DESIGN.md section 6
+// has both side by side and the measured table; `p1` marks that protocol's branches in slab_step_body.
+//
 // Equal keys at a cut keep the order of the whole-domain stable sort (what came up from below in front of the residents
 // of its cell, what came down from above behind them): an N-slab run has the bits of the one-context run.
 // A rank that fails still exchanges what the step owes, then sends "abort" in its next migrant header (slab_fail): its

@@ -17,6 +17,11 @@ link); no collective sits on the data path:
     [halo B]    (density, pressure) of the same boundary particles
     fused force + collision + integrate over owned
 
+That is the THREE-GROUP protocol (SlabSimulation.step; in the library: csrc/sph_slab.hip, the default).  The ONE-MESSAGE protocol
+(SlabSimulation._step_one; in the library: sph_slab_set_protocol(s, 1), NativeSlabSimulation(protocol=1)) sends header, leavers and
+two layers of residents in one message per neighbour whose size was fixed from the previous step's counts, and the receiver
+recomputes the ghost densities itself: no density message.
+
 The per-rank compute engine is pluggable ONLY so that tests can drive this protocol on CPU ranks
 (gloo) with the oracle behind it; the product engine is `HipEngine` (libsph_hip.so) and nothing
 else is ever chosen implicitly: without a gfx950 device `HipEngine` raises.

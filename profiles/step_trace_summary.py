@@ -53,9 +53,20 @@ def main():
         g = gaps["<next step's first kernel>"]
         g[0] += 1; g[1] += t1 - cur_end
     total = sum(a[1] for a in agg.values())
-    lines = ["kernel,calls,calls_per_step,total_ns,avg_ns,min_ns,max_ns,ns_per_step"]
+    # per kernel: the UNION of its dispatch intervals (launches of one kernel on two streams overlap: their times add up to more
+    # than the time during which that kernel was running at all -- k_density's two launches of a slab step, k_force's interior
+    # and boundary launches)
+    union = defaultdict(int)
+    ends = {}
+    for s, e, k in win:
+        ce = ends.get(k, 0)
+        if s >= ce:
+            union[k] += e - s; ends[k] = e
+        elif e > ce:
+            union[k] += e - ce; ends[k] = e
+    lines = ["kernel,calls,calls_per_step,total_ns,avg_ns,min_ns,max_ns,ns_per_step,union_ns_per_step"]
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        lines.append(f"\"{k}\",{a[0]},{a[0] / count:.2f},{a[1]},{a[1] / a[0]:.0f},{a[2]},{a[3]},{a[1] / count:.0f}")
+        lines.append(f"\"{k}\",{a[0]},{a[0] / count:.2f},{a[1]},{a[1] / a[0]:.0f},{a[2]},{a[3]},{a[1] / count:.0f},{union[k] / count:.0f}")
     lines.append(f"\"#window: steps {skip + 1}..{skip + count}; span {(t1 - t0) / count / 1e3:.1f} us per step; device busy (union) "
                  f"{busy / count / 1e3:.1f} us per step; idle {(t1 - t0 - busy) / count / 1e3:.1f} us per step; sum of kernel "
                  f"times {total / count / 1e3:.1f} us per step; {len(win) / count:.1f} dispatches per step\",,,,,,,")
