@@ -1123,7 +1123,7 @@ int slab_step_body(sph_slab* s, float dt) {
     // behind them the blocks that build the cell table of the owned slots when the sort left it pending (not on a skipped sort)
     // a few blocks (many when they also copy two layers): every block finds the bounds for itself, the leavers and residents are packed in
     // grid-stride loops; behind them the blocks that build the cell table of the owned slots when the sort left it pending (not on a skipped sort)
-    const uint32_t pack_blocks = p1 ? 512u : min(ceil_div(s->mcap, 256u), 16u), build_blocks = c->owned_cells_pending ? cells_build_blocks(n0) : 0u;
+    const uint32_t pack_blocks = p1 ? 128u : min(ceil_div(s->mcap, 256u), 16u), build_blocks = c->owned_cells_pending ? cells_build_blocks(n0) : 0u;
     c->owned_cells_pending = false;
     hipLaunchKernelGGL(k_slab_bounds_pack, dim3(pack_blocks + build_blocks), dim3(256), 0, c->stream, c->keyS + off0, c->posi + off0,
                        c->velr + off0, n0, off0, layer, s->mcap, c->grid, s->early_cap, s->d_lb, s->mig_send[0], s->mig_send[1], pack_blocks,
@@ -1443,12 +1443,19 @@ int slab_step_body(sph_slab* s, float dt) {
     // another rank's kernels.)
     const bool need_deep_event = early_halo && !(a <= near_lo && b >= near_hi);
     if (need_deep_event) SPH_HIP(hipEventRecord(s->ev_deep, c->stream));
-    // The one-message step also computes the densities of the INNER ghost layer on either side (what HALO B carries in the
-    // three-group step): g1_lo slots in front of the owned range, g1_hi behind it.  Only the boundary chunks' force launch reads
-    // them, so they get launches of their own on the comm stream, queued BEHIND the point where the main stream is released
-    // for its interior force launch (in one launch with the owned non-deep slots they cost the main stream 17 us of waiting per
-    // step at 2 M particles per rank).
-    const uint32_t dens_lo = c->own_off, dens_hi = c->own_off + n;
+    // the slots the non-deep density launches cover: the owned range -- and, in the one-message step, the inner ghost layers
+    // on either side (what HALO B carries in the three-group step), rounded down to a whole 64-slot chunk in front so that the
+    // hole these launches leave for the deep range stays on the chunk boundaries the deep launch used; the few slots of the
+    // OUTER ghost layer that catches get a density nobody reads (their own neighbourhood is not complete here).  ONE launch with
+    // the owned slots: giving the ghost layers launches of their own behind the main stream's release was measured and is
+    // slower -- two partly filled rounds of workgroups beside the interior force launch: +63 us of density kernel time, the
+    // step +4 ... +9 us at every link setting (profiles/r06b_periodic_slab_protocols_ghost_density_split.txt).
+    uint32_t dens_lo = c->own_off, dens_hi = c->own_off + n;
+    if (p1) {
+        const uint32_t back = (g1_lo + 63u) & ~63u;
+        dens_lo = c->own_off - (back <= g_lo ? back : g1_lo);
+        dens_hi = c->own_off + n + g1_hi;
+    }
     // ---- halo A: boundary layers -> neighbours' ghost layers -----------------------------------------------------------
     hipStream_t pack_stream = early_halo ? s->comm : c->stream;
     if (!p1 && h_lo + h_hi)
@@ -1515,15 +1522,6 @@ int slab_step_body(sph_slab* s, float dt) {
         SPH_HIP(hipGetLastError());
     }
     rc = after_comm(s); if (rc) return rc;                      // main: the ghosts (and, early, the boundary densities) are in
-    if (p1 && g1_lo + g1_hi) {
-        // the inner ghost layers' densities (see above): comm stream, behind the unpack; candidates are the ghosts themselves
-        // and this rank's boundary layers, whose positions have been final since the sort / the in-place merge of arrivals
-        OnComm on(s);
-        PhaseTimer t(c, SPH_PH_DENS);
-        if (g1_lo) rc = launch_density_range(c, c->own_off - g1_lo, c->own_off);
-        if (!rc && g1_hi) rc = launch_density_range(c, c->own_off + n, c->own_off + n + g1_hi);
-        if (rc) return rc;
-    }
     if (!early_halo) {
         {
             PhaseTimer t(c, SPH_PH_DENS);                        // the two boundary layers
