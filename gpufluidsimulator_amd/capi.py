@@ -100,6 +100,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_uint64)]),
     "sph_set_sort_mode": (C.c_int, [_P, C.c_int]),
     "sph_set_direct_hull": (C.c_int, [_P, C.c_uint32]),
+    "sph_set_pair_small_launch": (C.c_int, [_P, C.c_uint32]),
     "sph_set_block_order": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint32]),
     "sph_sort_forms": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "sph_test_trust_mover_hint": (C.c_int, [_P]),
@@ -438,6 +439,11 @@ class Context:
         """Rows of the neighbour passes whose staged hull would exceed `slots` are read straight from global memory
         (0: all of them, 0xFFFFFFFF: none); same bits either way."""
         _check(self.L.sph_set_direct_hull(self.h, int(slots) & 0xFFFFFFFF))
+
+    def set_pair_small_launch(self, slots):
+        """A context with fewer than `slots` owned particles launches the neighbour passes in 128-thread workgroups (0: never,
+        0xFFFFFFFF: always; default 524288); same bits either way."""
+        _check(self.L.sph_set_pair_small_launch(self.h, int(slots) & 0xFFFFFFFF))
 
     def timing_get(self):
         ms = (C.c_float * len(PHASES))()

@@ -209,6 +209,10 @@ static int create_impl(sph_ctx** out, int device, uint32_t capacity, const sph_p
             c->order_ztile_dens = zd != 0; c->order_xrot = xr != 0;
         }
     }
+    if (const char* env = getenv("SPH_PAIR_SMALL_SLOTS")) {     // at create time: A/B runs (sph_set_pair_small_launch)
+        unsigned long v = 0;
+        if (sscanf(env, "%lu", &v) == 1) c->pair_small_slots = v > 0xFFFFFFFFul ? 0xFFFFFFFFu : (uint32_t)v;
+    }
     {   // merge sort scratch
         const char* env = getenv("SPH_SORT_MERGE");
         c->sort_merge = !(env && env[0] == '0');
@@ -1036,6 +1040,12 @@ int sph_set_block_order(sph_ctx* c, int xcd, int ztile, uint32_t strip_blocks_lo
 int sph_set_direct_hull(sph_ctx* c, uint32_t slots) {
     SPH_REQUIRE(c, SPH_E_INVALID, "null context");
     c->direct_hull = slots;
+    return SPH_OK;
+}
+
+int sph_set_pair_small_launch(sph_ctx* c, uint32_t slots) {
+    SPH_REQUIRE(c, SPH_E_INVALID, "null context");
+    c->pair_small_slots = slots;
     return SPH_OK;
 }
 

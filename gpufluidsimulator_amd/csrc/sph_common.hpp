@@ -18,6 +18,9 @@ constexpr int WAVE = 64;
 #define SPH_SORT_KPT 16
 #endif
 constexpr uint32_t SORT_TILE_KEYS = 256 * SPH_SORT_KPT;   // keys per radix-sort tile (sph_sort.hip)
+#ifndef SPH_PAIR_SMALL_SLOTS_DEFAULT
+#define SPH_PAIR_SMALL_SLOTS_DEFAULT 524288u
+#endif
 constexpr uint32_t MM_TILE_CHUNKS = 256;   // merge sort: 64-slot chunks per scan tile (sph_sort.hip)
 
 // Grid description passed by value to kernels (replaces the device-resident SimParams*
@@ -95,6 +98,9 @@ struct sph_ctx {
     // pair kernels: a (dz, dy) row whose staged hull would exceed this many slots is read straight from global memory
     // by every lane instead (sph_pairs.hip: traverse; sph_set_direct_hull)
     uint32_t direct_hull = 512;
+    // pair kernels: a context with fewer owned particles than this launches blocks of 128 threads instead of 256 (sph_pairs.hip:
+    // SMALL_THREADS_PAIR; same results bit for bit; sph_set_pair_small_launch)
+    uint32_t pair_small_slots = SPH_PAIR_SMALL_SLOTS_DEFAULT;
     // block order of the pair kernels (sph_device.hpp: BlockOrder; sph_set_block_order): every XCD walks a contiguous eighth
     // of the slots; the fused force pass also walks strips of 2^order_strip_sh blocks through the z layers of that eighth
     bool order_xcd = true, order_ztile = true;

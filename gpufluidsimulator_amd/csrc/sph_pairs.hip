@@ -31,7 +31,15 @@ constexpr int PAIR_WAVES = PAIR_THREADS / WAVE;
 #define SPH_DENS_THREADS SPH_PAIR_THREADS
 #endif
 constexpr int DENS_THREADS = SPH_DENS_THREADS;
-constexpr int DENS_WAVES = DENS_THREADS / WAVE;
+// A SMALL context (fewer than sph_ctx::pair_small_slots owned particles) launches blocks of 128 threads.  Waves are independent
+// of each other (a wave-private LDS slice, no block barrier in the walk), so the block size changes nothing in the results --
+// only how the dispatcher spreads the waves and how long a block's slowest wave holds its CU's resources: config 2's flowing
+// dam (4096 waves in all, some of them sparse and slow) runs `k_force` 14 % and `k_density` 7 % faster with 2-wave blocks, the
+// step 184 -> 162 us; a lattice at rest of the same size does not care; from ~10^6 particles on 128-thread blocks LOSE (config
+// 3: `k_force` +7 %: twice the blocks re-stage the same hulls, and BlockOrder's z strips are cut for 256), and the boundary
+// launches of a 2.1 M-particle slab lose ~1 % of its step.  Measured: profiles/r06_pair_block_size.txt.
+constexpr int SMALL_THREADS_PAIR = 128;
+static inline bool small_blocks(const sph_ctx* c) { return c->n < c->pair_small_slots; }
 constexpr int PIECE = 128;          // staged candidates per piece (2 coalesced loads per lane)
 
 // The candidate walks read LDS through volatile LDS-address-space pointers: each read then stays ONE
@@ -247,12 +255,12 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// LDS: one PIECE-entry slice per wave plus one spare slice.  The unrolled candidate loop may read up
+// LDS (LDS_ENT entries): one PIECE-entry slice per wave plus one spare slice.  The unrolled candidate loop may read up
 // to PIECE+3 entries past the end of a lane's valid range; the spare slice keeps those reads inside
 // the block's allocation.  Such lanes are masked by selecting a zero WEIGHT, and a zero weight times
 // a NaN is a NaN, so everything a lane can over-read must be finite: the arrays are zero-filled once
 // per block, and whatever is staged later comes from the (zero-padded) particle arrays.
-constexpr int LDS_ENT = (PAIR_WAVES + 1) * PIECE + 8;
+constexpr int lds_ent(int threads) { return (threads / WAVE + 1) * PIECE + 8; }      // "LDS_ENT" of a block of `threads`
 #ifndef SPH_DENS_UNROLL
 #define SPH_DENS_UNROLL 4
 #endif
@@ -388,11 +396,12 @@ __device__ __forceinline__ bool wave_targets(const Targets& T, uint32_t wave, ui
 // ---- density + pressure (kernelComputeDensities, particleSystem.cu:132-187) ---------------------------
 // rho_i = sum_{j in 27 cells, r2 < h2} m * POLY6 * (h2 - r2)^3   (self included)   (.cu:28-37)
 // p_i   = max(0, k * (rho_i - rho0))                                              (.cu:15-17)
-__global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const float4* __restrict__ posi,
-                                                                        const uint32_t* __restrict__ keyS,
-                                                                        const uint2* __restrict__ cells,
-                                                                        float2* __restrict__ dp, float2* __restrict__ cw,
-                                                                        Targets tg, GridDesc g, Phys ph) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, SPH_DENS_OCC) void k_density(const float4* __restrict__ posi,
+                                                                   const uint32_t* __restrict__ keyS,
+                                                                   const uint2* __restrict__ cells,
+                                                                   float2* __restrict__ dp, float2* __restrict__ cw,
+                                                                   Targets tg, GridDesc g, Phys ph) {
     // Round 5: the z coordinates of TWO neighbouring candidates come out of ONE ds_read_b64.  The LDS pipe
     // charges an instruction by its bytes with 8 as the minimum -- a ds_read_b32 costs what a ds_read_b64 costs, 1.1 ns per
     // wave-instruction and CU (profiles/r02_lds_read_rates.txt) -- so {x, y} as a b64 plus z as a b32 paid for 16 bytes per
@@ -404,14 +413,14 @@ __global__ __launch_bounds__(DENS_THREADS, SPH_DENS_OCC) void k_density(const fl
     // 32 apart -- two more instructions per candidate, 1.37 ms against 0.96, r03; {x, y} b64 + z b32 per candidate, the form
     // before this one, r05_density_zz_pairs_ab.txt.)
     static_assert(UNROLL % 2 == 0, "the z-pair walk reads candidates two at a time");
-    constexpr int DENS_ENT = (DENS_WAVES + 1) * PIECE + 8;          // as LDS_ENT, for this kernel's block
+    constexpr int DENS_ENT = lds_ent(THREADS);                      // as LDS_ENT, for this kernel's block
     __shared__ float2 s_xy[DENS_ENT];
     __shared__ __attribute__((aligned(8))) float s_z[DENS_ENT];
     __shared__ __attribute__((aligned(8))) float s_zo_[DENS_ENT + 2];
     float* const s_zo = s_zo_ + 2;                                   // s_zo[-1] exists (the entry in front of the first slice)
     // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
-    if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)DENS_THREADS >= tg.dev[1]) return;
-    for (uint32_t k = threadIdx.x; k < DENS_ENT; k += DENS_THREADS) {   // see LDS_ENT: keep over-reads finite
+    if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)THREADS >= tg.dev[1]) return;
+    for (uint32_t k = threadIdx.x; k < DENS_ENT; k += THREADS) {   // see LDS_ENT: keep over-reads finite
         s_xy[k] = make_float2(0.f, 0.f);
         s_z[k] = 0.f;
         s_zo_[k] = 0.f;
@@ -812,8 +821,8 @@ extern "C" void sph_debug_pair_stats(unsigned long long* out, int on) {     // r
 #else
 #define PAIR_STAT(k, v) do { } while (0)
 #endif
-template <bool FORCE, bool COLL, bool INTEG>
-__global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
+template <bool FORCE, bool COLL, bool INTEG, int THREADS>
+__global__ __launch_bounds__(THREADS, SPH_FORCE_OCC) void k_force(
     const float4* __restrict__ posi, const float4* __restrict__ velr, const float2* __restrict__ dp,
     const float2* __restrict__ cw, const uint32_t* __restrict__ keyS, const uint2* __restrict__ cells, float4* __restrict__ fpress,
     float4* __restrict__ fvisc, float4* __restrict__ dvel, float4* __restrict__ posi_out,
@@ -828,10 +837,11 @@ __global__ __launch_bounds__(PAIR_THREADS, SPH_FORCE_OCC) void k_force(
     // the same 2.56 ms -- at 8 particles per cell every 16-byte-aligned stride is a two-way bank conflict.  Not kept:
     // profiles/r05_force_b128_experiment.txt.)
     constexpr int E2 = 5;
-    __shared__ float2 s_e[LDS_ENT * 5];
+    constexpr int ENT = lds_ent(THREADS);
+    __shared__ float2 s_e[ENT * 5];
     // a range read from device memory: the grid is an upper bound, whole blocks beyond the range leave before the zero-fill
-    if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)PAIR_THREADS >= tg.dev[1]) return;
-    for (uint32_t k = threadIdx.x; k < LDS_ENT * E2; k += PAIR_THREADS)   // see LDS_ENT: keep over-reads finite
+    if (tg.dev && tg.dev[0] + ordered_block(pair_block(), gridDim.x, tg.order) * (uint32_t)THREADS >= tg.dev[1]) return;
+    for (uint32_t k = threadIdx.x; k < ENT * E2; k += THREADS)   // see LDS_ENT: keep over-reads finite
         s_e[k] = make_float2(0.f, 0.f);
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1126,15 +1136,18 @@ int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, ui
     uint32_t threads;
     Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
     tg.direct_hull = c->direct_hull;
-    tg.order = block_order(c, ceil_div(threads, (uint32_t)PAIR_THREADS), integrate && force);      // (the fused launch: see BlockOrder)
+    const bool small = small_blocks(c);                                                            // (see SMALL_THREADS_PAIR)
+    const uint32_t bt = small ? (uint32_t)SMALL_THREADS_PAIR : (uint32_t)PAIR_THREADS;
+    tg.order = block_order(c, ceil_div(threads, bt), integrate && force);      // (the fused launch: see BlockOrder)
     SPH_REQUIRE(tg.gap_len == 0u || (((tg.gap_lo - lo) | tg.gap_len) & 63u) == 0u || tg.gap_lo + tg.gap_len == hi, SPH_E_INVALID,
                 "force hole is not made of whole 64-slot chunks");
     if (threads == 0) return SPH_OK;
-    dim3 grid(ceil_div(threads, PAIR_THREADS)), block(PAIR_THREADS);
-#define SPH_LAUNCH_FORCE(F, C, I)                                                                              \
-    hipLaunchKernelGGL((k_force<F, C, I>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->cw, c->keyS, c->cells, \
+    dim3 grid(ceil_div(threads, bt)), block(bt);
+#define SPH_LAUNCH_FORCE_T(F, C, I, T)                                                                         \
+    hipLaunchKernelGGL((k_force<F, C, I, T>), grid, block, 0, c->stream, c->posi, c->velr, c->dp, c->cw, c->keyS, c->cells, \
                        c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, c->k0,              \
                        mark ? c->mm_mask : nullptr, c->mm_tile_cnt, tg, c->own_off, dt, c->grid, c->phys)
+#define SPH_LAUNCH_FORCE(F, C, I) do { if (small) SPH_LAUNCH_FORCE_T(F, C, I, SMALL_THREADS_PAIR); else SPH_LAUNCH_FORCE_T(F, C, I, PAIR_THREADS); } while (0)
     if (force && collide && integrate) SPH_LAUNCH_FORCE(true, true, true);
     else if (force && !collide && !integrate) SPH_LAUNCH_FORCE(true, false, false);
     else if (!force && collide && !integrate) SPH_LAUNCH_FORCE(false, true, false);
@@ -1143,6 +1156,7 @@ int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, ui
         return SPH_E_INVALID;
     }
 #undef SPH_LAUNCH_FORCE
+#undef SPH_LAUNCH_FORCE_T
     SPH_HIP(hipGetLastError());
     return SPH_OK;
 }
@@ -1154,9 +1168,12 @@ int launch_force_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, ui
 int launch_force_dev_range(sph_ctx* c, const uint32_t* range_dev, uint32_t max_count, float dt) {
     if (max_count == 0) return SPH_OK;
     const Targets tg{0u, 0u, 0xFFFFFFFFu, 0u, range_dev, c->direct_hull, BlockOrder{0u, 0u, 0u, 0u, 0u}};
-    hipLaunchKernelGGL((k_force<true, true, true>), dim3(ceil_div(max_count, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi, c->velr,
-                       c->dp, c->cw, c->keyS, c->cells, c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out,
-                       c->keyS2, (uint64_t*)nullptr, c->mm_tile_cnt, tg, 0u, dt, c->grid, c->phys);
+#define SPH_LAUNCH_EARLY(T)                                                                                                         \
+    hipLaunchKernelGGL((k_force<true, true, true, T>), dim3(ceil_div(max_count, (uint32_t)T)), dim3(T), 0, c->stream, c->posi, c->velr,   \
+                       c->dp, c->cw, c->keyS, c->cells, c->fpress, c->fvisc, c->dvel, c->posi2, c->velr2, c->slab ? nullptr : c->pos_out, \
+                       c->keyS2, (uint64_t*)nullptr, c->mm_tile_cnt, tg, 0u, dt, c->grid, c->phys)
+    if (small_blocks(c)) SPH_LAUNCH_EARLY(SMALL_THREADS_PAIR); else SPH_LAUNCH_EARLY(PAIR_THREADS);
+#undef SPH_LAUNCH_EARLY
     SPH_HIP(hipGetLastError());
     return SPH_OK;
 }
@@ -1198,8 +1215,11 @@ static int launch_density_targets(sph_ctx* c, const Targets& tg, uint32_t thread
     if (c->precision == SPH_PRECISION_MIXED_F16)
         hipLaunchKernelGGL(k_density_h, dim3(ceil_div(threads, PAIR_THREADS)), dim3(PAIR_THREADS), 0, c->stream, c->posi,
                            c->keyS, c->cells, c->dp, c->cw, tg, c->grid, c->phys);
+    else if (small_blocks(c))
+        hipLaunchKernelGGL(k_density<SMALL_THREADS_PAIR>, dim3(ceil_div(threads, (uint32_t)SMALL_THREADS_PAIR)), dim3(SMALL_THREADS_PAIR), 0, c->stream,
+                           c->posi, c->keyS, c->cells, c->dp, c->cw, tg, c->grid, c->phys);
     else
-        hipLaunchKernelGGL(k_density, dim3(ceil_div(threads, DENS_THREADS)), dim3(DENS_THREADS), 0, c->stream, c->posi,
+        hipLaunchKernelGGL(k_density<DENS_THREADS>, dim3(ceil_div(threads, (uint32_t)DENS_THREADS)), dim3(DENS_THREADS), 0, c->stream, c->posi,
                            c->keyS, c->cells, c->dp, c->cw, tg, c->grid, c->phys);
     SPH_HIP(hipGetLastError());
     return SPH_OK;
@@ -1211,7 +1231,8 @@ int launch_density_hole(sph_ctx* c, uint32_t lo, uint32_t hi, uint32_t hole_lo, 
     uint32_t threads;
     Targets tg = targets_with_hole(lo, hi, hole_lo, hole_hi, threads);
     tg.direct_hull = c->direct_hull;
-    tg.order = block_order(c, ceil_div(threads, (uint32_t)(c->precision == SPH_PRECISION_MIXED_F16 ? PAIR_THREADS : DENS_THREADS)), c->order_ztile_dens);
+    const uint32_t bt = c->precision == SPH_PRECISION_MIXED_F16 ? (uint32_t)PAIR_THREADS : (small_blocks(c) ? (uint32_t)SMALL_THREADS_PAIR : (uint32_t)DENS_THREADS);
+    tg.order = block_order(c, ceil_div(threads, bt), c->order_ztile_dens);
     return launch_density_targets(c, tg, threads);
 }
 

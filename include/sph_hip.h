@@ -40,7 +40,7 @@
  *                  sph_sort_forms sph_last_sort_skipped sph_slab_stats sph_slab_counters sph_slab_in_place_merges
  *                  sph_slab_exchanges sph_slab_recut_stats sph_slab_early_force_stats sph_slab_protocol sph_rccl_transport_info
  *   [tuning]       switches whose defaults are the product's settings; in fp32 results do not depend on them (A/B runs):
- *                  sph_set_sort_mode sph_set_direct_hull sph_set_block_order sph_slab_set_early_force
+ *                  sph_set_sort_mode sph_set_direct_hull sph_set_pair_small_launch sph_set_block_order sph_slab_set_early_force
  *   [test hook]    exist for tests and measurement harnesses only: sph_test_trust_mover_hint sph_slab_test_raise_flag
  *                  sph_rccl_transport_selftest sph_loop_transport_create/_destroy
  */
@@ -268,6 +268,12 @@ int sph_timing_reset(sph_ctx* c);
  * more than slots / 66 particles can break -- such a wave stages a long hull, slowly but correctly).
  * 0: every row direct; 0xFFFFFFFF: never (for tests and A/B runs).  Takes effect at the next launch. */
 /* [tuning] */ int sph_set_direct_hull(sph_ctx* c, uint32_t slots);
+/* A context that owns FEWER than `slots` particles launches the neighbour passes in workgroups of 128 threads instead of 256
+ * (default 524288).  Waves do not depend on their block (wave-private LDS slices, no block barrier in the walk): same results
+ * bit for bit; config 2's flowing dam steps 12 % faster this way, large launches lose ("small steps").
+ * 0: never; 0xFFFFFFFF: always.  Takes effect at the next launch; SPH_PAIR_SMALL_SLOTS in the environment at create time does
+ * the same for A/B runs. */
+/* [tuning] */ int sph_set_pair_small_launch(sph_ctx* c, uint32_t slots);
 /* The ORDER in which the neighbour passes' workgroups take the sorted slots (results do not depend on it).  xcd = 1
  * (default): each of the 8 XCDs walks one contiguous eighth of the slots; ztile = 1 (default): inside its eighth an XCD
  * walks strips of 2^strip_blocks_log2 workgroups (default 4: 16 workgroups = 4096 slots) through all cell layers of the

@@ -16,9 +16,11 @@ DT = 5e-7
 NEVER = 0xFFFFFFFF
 
 
-def _phases(pos, vel, box, grid, direct_hull, mixed=False):
+def _phases(pos, vel, box, grid, direct_hull, mixed=False, small_blocks=None):
     with capi.Context(pos.shape[0], box=box, grid=grid) as c:
         c.set_direct_hull(direct_hull)
+        if small_blocks is not None:
+            c.set_pair_small_launch(NEVER if small_blocks else 0)
         c.set_precision(mixed)
         c.upload(pos, vel)
         c.hash(); c.sort(); c.build_cells(); c.density(); c.force(); c.collide()
@@ -62,6 +64,23 @@ def test_direct_and_staged_rows_agree_bit_for_bit(case):
             assert np.array_equal(bits(got[k]), bits(ref[k])) if ref[k].dtype == np.float32 else np.array_equal(got[k], ref[k]), (case, hull, k)
 
 
+@pytest.mark.parametrize("case", ["sparse_next_to_dense", "c1_flow"])
+def test_workgroups_of_128_and_of_256_threads_agree_bit_for_bit(case):
+    """A context of fewer than 524,288 particles launches the neighbour passes in workgroups of 128 threads, larger ones in
+    256 (sph_set_pair_small_launch): a wave's work does not depend on its block, so every phase output and four whole steps
+    come out the same bits either way -- under the staged and under the direct walk."""
+    if case == "c1_flow":
+        g = load_golden("c1_flow")
+        pos, vel, box, grid = g["pos"], g["vel"], g["box"], g["grid"]
+    else:
+        pos, vel, box, grid = _sparse_next_to_dense()
+    for hull in (512, 0):
+        ref = _phases(pos, vel, box, grid, hull, small_blocks=False)
+        got = _phases(pos, vel, box, grid, hull, small_blocks=True)
+        for k in ref:
+            assert np.array_equal(bits(got[k]), bits(ref[k])) if ref[k].dtype == np.float32 else np.array_equal(got[k], ref[k]), (case, hull, k)
+
+
 def test_direct_rows_in_mixed_precision_stay_within_the_mixed_tolerance():
     """The packed-fp16 density pass pairs a lane's candidates per staged piece, so its sums depend on the staging anyway
     (mixed): the direct walk is held to the mode's tolerance against the fp32 pass, not to bits."""
@@ -76,14 +95,16 @@ def test_direct_rows_in_mixed_precision_stay_within_the_mixed_tolerance():
 def test_block_orders_agree_bit_for_bit():
     """The ORDER in which the pair kernels' workgroups take the slots (sph_set_block_order: plain, a contiguous eighth per
     XCD, strips through the cell layers of that eighth) changes memory traffic, not results: 2,097,152 particles -- enough
-    workgroups and cell layers for the strips to engage -- stepped under four orders, bit for bit."""
+    workgroups and cell layers for the strips to engage -- stepped under four orders, and under two of them in workgroups of
+    128 threads as well (sph_set_pair_small_launch: twice the blocks per cell layer), bit for bit."""
     box, grid = (16.0, 16.0, 16.0), (256, 256, 256)
     lattice = (128, 128, 128)
     n = lattice[0] * lattice[1] * lattice[2]
     ref = None
-    for order in ((0, 0, 4), (1, 0, 4), (1, 1, 2), (1, 1, 4)):
+    for order in ((0, 0, 4), (1, 0, 4), (1, 1, 2), (1, 1, 4), (1, 1, 4, "small"), (0, 0, 4, "small")):
         with capi.Context(n, box=box, grid=grid) as c:
-            c.set_block_order(*order)
+            c.set_block_order(*order[:3])
+            c.set_pair_small_launch(NEVER if len(order) > 3 else 0)
             c.reset_lattice(lattice, jitter=True)
             c.step(DT, 6)
             got = c.download()
