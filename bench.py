@@ -448,7 +448,7 @@ def main():
     live_sq = (r.get("pmc") or {}).get("sq", {}).get("force_fused")
     if live_sq or (sq and args.workload == "C3" and args.precision == "f32"):
         try:
-            kj = live_sq or json.load(open(os.path.join(ROOT, "profiles", sq[-1])))["k_force<true, true, true>"]
+            kj = live_sq or next(v for k, v in json.load(open(os.path.join(ROOT, "profiles", sq[-1]))).items() if k.startswith("k_force<true, true, true"))
             waves, clk_ghz, simds = kj["SQ_WAVES"], 2.4, 1024
             issue_s = kj["SQ_INSTS_VALU"] * 2.0 / simds / (clk_ghz * 1e9)      # one fp32 wave-instruction = 2 cycles of a SIMD
             issue = {"valu_insts_per_wave": kj["SQ_INSTS_VALU"] / waves, "lds_insts_per_wave": kj["SQ_INSTS_LDS"] / waves,

@@ -25,7 +25,7 @@ per = defaultdict(dict); kn = {}
 for r in csv.DictReader(open(f, newline="")):
     d = int(r["Dispatch_Id"]); per[d][r["Counter_Name"]] = per[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     kn[d] = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sph::", "")
-for pat in ("k_density", "k_force<true, true, true>"):
+for pat in ("k_density", "k_force<true, true, true"):
     ids = sorted(d for d in per if kn[d].startswith(pat))[10:]
     if not ids: continue
     m = {c: sum(per[d].get(c, 0.0) for d in ids) / len(ids) for c in per[ids[0]]}

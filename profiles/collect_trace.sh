@@ -22,7 +22,7 @@ python profiles/trace_window.py $OUT/c3_kernel_trace.csv 6020 100 gpurun_out/${T
 python profiles/trace_window.py $OUT/c3_kernel_trace.csv 6223 100 gpurun_out/${TAG}_c3_fullsort_kernel_stats.csv > /dev/null
 cp $OUT/c3_kernel_stats.csv gpurun_out/${TAG}_c3_whole_run_kernel_stats.csv
 # which steps do the slow launches belong to?  (k_force max 4.52 ms against 2.66 avg somewhere in the run)
-python profiles/kernel_series.py $OUT/c3_kernel_trace.csv "k_force<true, true, true>" gpurun_out/${TAG}_c3_k_force_series.json > gpurun_out/${TAG}_c3_outlier_launches.txt
+python profiles/kernel_series.py $OUT/c3_kernel_trace.csv "k_force<true, true, true" gpurun_out/${TAG}_c3_k_force_series.json > gpurun_out/${TAG}_c3_outlier_launches.txt
 python profiles/kernel_series.py $OUT/c3_kernel_trace.csv "k_density" gpurun_out/${TAG}_c3_k_density_series.json >> gpurun_out/${TAG}_c3_outlier_launches.txt
 python profiles/kernel_series.py $OUT/c3_kernel_trace.csv "k_mm_move" >> gpurun_out/${TAG}_c3_outlier_launches.txt
 rm -rf $OUT

@@ -29,7 +29,7 @@ def window_means(path):
         per_dispatch[d][r["Counter_Name"]] = per_dispatch[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         names[d] = short(r["Kernel_Name"])
     ids = sorted(per_dispatch)
-    marks = [d for d in ids if names[d].startswith("k_force<true, true, true>") or names[d].startswith("k_force<1, 1, 1>")]
+    marks = [d for d in ids if names[d].startswith("k_force<true, true, true") or names[d].startswith("k_force<1, 1, 1>")]
     lo, hi = marks[runup + warm - 1], marks[runup + warm + steps - 1]
     acc = defaultdict(lambda: defaultdict(list))
     for d in ids:
@@ -49,7 +49,7 @@ for p in ("fetch", "write", "sq1", "sq2"):
         res.setdefault(n, {}).update(c)
 N = 16777216
 force = next((v for k, v in res.items() if k.startswith("k_force<")), {})
-dens = res.get("k_density", {})
+dens = next((v for k, v in res.items() if k.startswith("k_density") and not k.startswith("k_density_h")), {})
 traffic = {
     "workload": "C3", "state": "flow", "round": int(tag.lstrip("r") or 0), "collected": __import__("time").strftime("%Y-%m-%d"),
     "method": f"profiles/collect_pmc.sh: rocprofv3 --pmc, one pass per counter group, over `python bench.py --runup {runup} "
@@ -73,4 +73,4 @@ for k, v in sq.items():                         # per-wave instruction counts (w
                 v[c + "_per_wave"] = v[c] / v["SQ_WAVES"]
 json.dump(sq, open(os.path.join(HERE, tag + "_c3_flow_sq_counters.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1)[:3000])
-print(json.dumps({k: sq[k] for k in sq if k.startswith("k_force<") or k == "k_density"}, indent=1))
+print(json.dumps({k: sq[k] for k in sq if k.startswith("k_force<") or k.startswith("k_density")}, indent=1))

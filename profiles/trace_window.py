@@ -27,7 +27,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if r[2].startswith("k_force<true, true, true>") or r[2].startswith("k_force<1, 1, 1>")]
+    marks = [i for i, r in enumerate(rows) if r[2].startswith("k_force<true, true, true") or r[2].startswith("k_force<1, 1, 1>")]
     if len(marks) < skip + count:
         sys.exit(f"only {len(marks)} steps in the trace, need {skip + count}")
     first = marks[skip - 1] + 1 if skip > 0 else 0          # first dispatch after the last skipped step
