@@ -284,7 +284,14 @@ static int do_hash(sph_ctx* c) {
     const uint32_t lo = c->own_off - c->n_glo, hi = c->own_off + c->n + c->n_ghi;
     c->cells_clear_deferred = c->sort_merge && c->order_valid && c->cells_valid && c->cells_lo == lo && c->cells_hi == hi;
     int rc;
-    if (c->cells_clear_deferred) {
+    c->ghost_clear_pending = false;
+    if (c->cells_clear_deferred && c->defer_ghost_clear && (c->n_glo | c->n_ghi)) {
+        // (the slab step: launch_sort, called next, clears them -- sph_ctx::defer_ghost_clear; cells_lo / cells_hi keep the ghosts
+        // until then, so that a full sort's clearing of the whole table range still covers them)
+        c->ghost_clear[0] = lo; c->ghost_clear[1] = c->own_off; c->ghost_clear[2] = c->own_off + c->n; c->ghost_clear[3] = hi;
+        c->ghost_clear_pending = true;
+        rc = SPH_OK;
+    } else if (c->cells_clear_deferred) {
         rc = launch_cells_clear_2ranges(c, lo, c->own_off, c->own_off + c->n, hi);      // both ghost ranges, one launch
         c->cells_lo = c->own_off; c->cells_hi = c->own_off + c->n;
     } else {

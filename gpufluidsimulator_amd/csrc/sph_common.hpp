@@ -117,6 +117,11 @@ struct sph_ctx {
     // the slab step builds the table of the owned slots INSIDE its bounds kernel (one dispatch less on every rank's critical
     // path): it sets `owned_cells_in_bounds` around its sort, the sort then leaves the build `pending` instead of launching it
     bool owned_cells_in_bounds = false, owned_cells_pending = false;
+    // ... and the clearing of the OLD ghosts' cells (a kernel of its own at hash time: k_cells_clear2, ~6 us at the head of every
+    // rank's step) to spare blocks of the sort's k_mm_compact: the slab step sets `defer_ghost_clear` around its hash, the hash
+    // then only notes the two ranges, and launch_sort clears them -- in k_mm_compact when it merges, else with the kernel
+    bool defer_ghost_clear = false, ghost_clear_pending = false;
+    uint32_t ghost_clear[4] = {0, 0, 0, 0};       // slot ranges [0],[1]) and [2],[3])
     bool keys_fresh = false;   // k0 already holds the keys of the current positions (written by the integrate epilogue)
 
     // radix sort scratch

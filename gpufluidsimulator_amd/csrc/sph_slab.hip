@@ -1109,7 +1109,10 @@ int slab_step_body(sph_slab* s, float dt) {
     }
     rc = slab_check_device_flags(s); if (rc) return rc;
     // ---- hash + sort the owned particles (leavers end up at the two ends of the owned range) -----------------------
-    rc = step_hash(c); if (rc) return rc;
+    c->defer_ghost_clear = true;                  // the old ghosts' cells are cleared by the sort's first kernel, not by one of their own
+    rc = step_hash(c);
+    c->defer_ghost_clear = false;
+    if (rc) return rc;
     c->owned_cells_in_bounds = true;              // the sort leaves the table of the owned slots to the bounds kernel below
     c->owned_cells_pending = false;
     rc = step_sort(c);

@@ -1007,7 +1007,21 @@ __global__ __launch_bounds__(256) void k_mm_compact(const uint64_t* __restrict__
                                                     unsigned long long* __restrict__ m_total,
                                                     const uint32_t* __restrict__ A, const uint32_t* __restrict__ B,
                                                     uint32_t* __restrict__ M64, uint32_t* __restrict__ mk,
-                                                    uint32_t* __restrict__ mi, uint2* __restrict__ cells) {
+                                                    uint32_t* __restrict__ mi, uint2* __restrict__ cells,
+                                                    const uint32_t* __restrict__ keys_abs, uint32_t g0lo, uint32_t g0hi,
+                                                    uint32_t g1lo, uint32_t g1hi) {
+    if (blockIdx.x >= nt) {
+        // spare blocks (a slab step): the cells of the OLD ghost ranges [g0lo, g0hi) and [g1lo, g1hi) die here -- what
+        // k_cells_clear2 did in a launch of its own at hash time (sph_ctx::defer_ghost_clear).  Ghost cells hold no owned
+        // particle, so nothing the other blocks clear or read is touched.
+        const uint32_t t = (blockIdx.x - nt) * 256u + threadIdx.x, n0 = g0hi - g0lo;
+        const uint32_t lo = t < n0 ? g0lo : g1lo, hi = t < n0 ? g0hi : g1hi;
+        const uint32_t s = t < n0 ? g0lo + t : g1lo + (t - n0);
+        if (s >= hi) return;
+        const uint32_t k = keys_abs[s];
+        if (s == lo || keys_abs[s - 1] != k) cells[k] = make_uint2(0u, 0u);
+        return;
+    }
     __shared__ uint32_t part[256];
     uint32_t tile_start;
     if (tile_cnt) {
@@ -1276,14 +1290,18 @@ __global__ __launch_bounds__(256) void k_mm_mark_tail(uint32_t n_old, uint32_t n
 // an old key (A) and a new one (B); slots [n, n_tot) -- particles that arrived from a neighbouring slab -- only a
 // new one, and all of them are movers.
 static int launch_sort_merge(sph_ctx* c, uint32_t n, uint32_t n_tot, bool table_live, uint32_t hint, Front front = Front{0u, 0u},
-                             bool count_in_compact = false) {
+                             bool count_in_compact = false, const uint32_t* ghost_clear = nullptr) {
     const uint32_t* A = c->keyS + c->own_off;
     const uint32_t* B = c->k0;
     const uint32_t nchunks = ceil_div(n_tot, 64u), nt = ceil_div(nchunks, MM_TILE_CHUNKS);
     uint32_t* mk = c->mm_k0; uint32_t* mi = c->v0; uint32_t* mk2 = c->mm_k1; uint32_t* mi2 = c->mm_v1;
-    hipLaunchKernelGGL(k_mm_compact, dim3(nt), dim3(256), 0, c->stream, c->mm_mask, nchunks, n, c->mm_tile_off,
+    // (ghost_clear: the old ghosts' cells, cleared by spare blocks of this launch -- launch_sort)
+    const uint32_t gc[4] = {ghost_clear ? ghost_clear[0] : 0u, ghost_clear ? ghost_clear[1] : 0u, ghost_clear ? ghost_clear[2] : 0u,
+                            ghost_clear ? ghost_clear[3] : 0u};
+    const uint32_t gc_blocks = ceil_div((gc[1] - gc[0]) + (gc[3] - gc[2]), 256u);
+    hipLaunchKernelGGL(k_mm_compact, dim3(nt + gc_blocks), dim3(256), 0, c->stream, c->mm_mask, nchunks, n, c->mm_tile_off,
                        count_in_compact ? c->mm_tile_cnt : (const uint32_t*)nullptr, nt, c->mm_count, c->mm_count_host_dev, c->mm_total, A, B,
-                       c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr);
+                       c->mm_M64, mk, mi, table_live ? c->cells : (uint2*)nullptr, c->keyS, gc[0], gc[1], gc[2], gc[3]);
     SPH_HIP(hipGetLastError());
     SmallTail tail;
     int form = SORT_FORM_BOTH;
@@ -1350,6 +1368,11 @@ int launch_sort(sph_ctx* c) {
     // sort could take the merge path, which clears only the cells the movers left
     const bool table_live = c->cells_clear_deferred && c->cells_valid;
     c->cells_clear_deferred = false;
+    // the old ghosts' cells, left by the hash of a slab step (sph_ctx::defer_ghost_clear): spare blocks of k_mm_compact clear
+    // them when this sort merges; a sort that is skipped does it with the kernel; the full sort clears the whole table range,
+    // which still includes them
+    const bool ghosts_left = c->ghost_clear_pending && table_live;
+    c->ghost_clear_pending = false;
     if (can_merge && (*c->mm_count_host <= n / 8u || c->sort_merge_always)) {
         const bool was_still = *c->mm_count_host == 0u;
         const bool count_in_compact = launch_merge_count(c, n);
@@ -1368,10 +1391,16 @@ int launch_sort(sph_ctx* c) {
                 c->last_sort_skipped = true;
                 c->last_perm = nullptr;            // identity
                 c->order_valid = true;             // cells_valid / cells_lo / cells_hi: unchanged and still true
+                if (ghosts_left) {
+                    const int rc2 = launch_cells_clear_2ranges(c, c->ghost_clear[0], c->ghost_clear[1], c->ghost_clear[2], c->ghost_clear[3]);
+                    if (rc2) return rc2;
+                    c->cells_lo = c->own_off; c->cells_hi = c->own_off + n;
+                }
                 return SPH_OK;
             }
         }
-        int rc = launch_sort_merge(c, n, n, table_live, *c->mm_count_host, Front{0u, 0u}, count_in_compact);   // hint: whatever step last reported
+        int rc = launch_sort_merge(c, n, n, table_live, *c->mm_count_host, Front{0u, 0u}, count_in_compact,   // hint: whatever step last reported
+                                   ghosts_left ? c->ghost_clear : (const uint32_t*)nullptr);
         if (rc) return rc;
         c->sort_merges++;
         if (c->cells_valid && !table_live) {       // a table nobody cleared (e.g. sph_sort without sph_hash): start clean

@@ -1108,7 +1108,12 @@ def bench_rank(comm, local, args, transport, log=None):
         try:
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             import bench as bench_mod
-            if not getattr(args, "no_pmc", False):
+            shared_card = bool(getattr(args, "one_gpu", False)) and getattr(args, "ranks_as", "") == "processes"
+            if shared_card:
+                # a rehearsal with the ranks as PROCESSES on one card: the profiler and its child would be two more processes with
+                # the GPU open, and a GPU box admits six (world 4 + the caller + these two = 7: the run is killed)
+                traffic_note = "not measured: the ranks share ONE GPU as processes (--one-gpu under a launcher) and a box admits six processes on a card"
+            elif not getattr(args, "no_pmc", False):
                 t_p = time.perf_counter()
                 traffic, traffic_note = bench_mod.pmc_traffic(sim.engine.ctx, args, slab=(sim.z_lo, sim.z_hi), device=local)
                 log(f"[bench] rank 0 PMC traffic passes: {time.perf_counter() - t_p:.1f} s ({'ok' if traffic else traffic_note})")
