@@ -869,6 +869,15 @@ struct sph_slab {
     bool host_staged = false;            // the transport wants host buffers (tests); else device pointers on the comm stream
     hipStream_t comm = nullptr;
     hipEvent_t ev_main = nullptr, ev_comm = nullptr, ev_deep = nullptr;
+    // The two cross-stream edges every step takes several times -- "comm goes on behind main" (after_main) and the reverse
+    // (after_comm) -- as a sequence number one stream WRITES into a word of device memory and the other WAITS for
+    // (hipStreamWriteValue32 / hipStreamWaitValue32) instead of an event: a chain of small kernels alternating between two
+    // streams runs at 7.4-8.6 us per kernel and hop that way against 14.4-15.9 with an event per hop (profiles/hop_chain.hip,
+    // profiles/r06_cross_stream_hops.txt).  Used where the device supports it and a write / wait pair at create time worked
+    // (SPH_SLAB_HOPS=event in the environment: events, for A/B runs); the rarer edges keep their events.
+    uint32_t* hop_mem = nullptr;         // one word per edge, a cache line apart: HOP_* below
+    uint32_t hop_seq[5] = {0u, 0u, 0u, 0u, 0u};
+    bool hops_by_value = false;
     hipStream_t early = nullptr;         // the early force launch's own stream (behind the deep density by event): its tail then runs
     hipEvent_t ev_early_go = nullptr, ev_early_done = nullptr;   // beside the interior launch instead of in front of it
     bool early_own_stream = true;        // SPH_SLAB_EARLY_STREAM=0: on the main stream (A/B)
@@ -951,6 +960,7 @@ void slab_free(sph_slab* s) {
     hipFree(s->d_lb);
     hipFree(s->recut_blk);
     if (s->h_lb) hipHostFree((void*)s->h_lb);
+    if (s->hop_mem) hipFree(s->hop_mem);
     if (s->ev_main) hipEventDestroy(s->ev_main);
     if (s->ev_comm) hipEventDestroy(s->ev_comm);
     if (s->ev_deep) hipEventDestroy(s->ev_deep);
@@ -1018,15 +1028,37 @@ int slab_exchange_raw(sph_slab* s, int tag, const void* send_lo, size_t send_lo_
 }
 
 // comm stream continues after everything queued on main so far / main after comm
-int after_main(sph_slab* s) {
-    SPH_HIP(hipEventRecord(s->ev_main, s->c->stream));
-    SPH_HIP(hipStreamWaitEvent(s->comm, s->ev_main, 0));
+// One edge "stream `to` goes on behind what `from` holds now", in two halves so that the wait can be queued later than the mark:
+// hop_mark returns the edge's sequence number (the write is ALWAYS queued before any wait that needs it: no wait without its
+// write), hop_wait queues the wait for it.  Events where write / wait value is not available (sph_slab::hops_by_value).
+enum { HOP_MAIN_COMM = 0, HOP_COMM_MAIN = 1, HOP_MAIN_EARLY = 2, HOP_EARLY_MAIN = 3, HOP_DEEP = 4 };
+int hop_mark(sph_slab* s, int edge, hipStream_t from, hipEvent_t ev, uint32_t* value) {
+    if (s->hops_by_value) {
+        *value = ++s->hop_seq[edge];
+        SPH_HIP(hipStreamWriteValue32(from, s->hop_mem + 16 * edge, *value, 0));
+        return SPH_OK;
+    }
+    *value = 0u;
+    SPH_HIP(hipEventRecord(ev, from));
     return SPH_OK;
 }
-int after_comm(sph_slab* s) {
-    SPH_HIP(hipEventRecord(s->ev_comm, s->comm));
-    SPH_HIP(hipStreamWaitEvent(s->c->stream, s->ev_comm, 0));
+int hop_wait(sph_slab* s, int edge, hipStream_t to, hipEvent_t ev, uint32_t value) {
+    if (s->hops_by_value) {
+        SPH_HIP(hipStreamWaitValue32(to, s->hop_mem + 16 * edge, value, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        return SPH_OK;
+    }
+    SPH_HIP(hipStreamWaitEvent(to, ev, 0));
     return SPH_OK;
+}
+int after_main(sph_slab* s) {
+    uint32_t v;
+    int rc = hop_mark(s, HOP_MAIN_COMM, s->c->stream, s->ev_main, &v);
+    return rc ? rc : hop_wait(s, HOP_MAIN_COMM, s->comm, s->ev_main, v);
+}
+int after_comm(sph_slab* s) {
+    uint32_t v;
+    int rc = hop_mark(s, HOP_COMM_MAIN, s->comm, s->ev_comm, &v);
+    return rc ? rc : hop_wait(s, HOP_COMM_MAIN, s->c->stream, s->ev_comm, v);
 }
 
 // launchers use the context's stream: this runs them on the comm stream instead
@@ -1154,20 +1186,22 @@ int slab_step_body(sph_slab* s, float dt) {
     // changes by a few slots a step) -- whatever a too small grid leaves out is computed by the interior launch below
     const uint32_t early_grid_slots = s->early_span_known ? min(n0, ((s->early_span + s->early_span / 64u + 1023u) & ~255u)) : n0;
     bool early_pending = false;          // the launch runs on its own stream: the main stream has not waited for it yet
+    uint32_t early_done_v = 0u;          // (the sequence number of that edge: hop_mark)
     // "the last step's range was EMPTY" (layer 5 not inside the deep range, a sparse slab) is not "unknown": no launch then --
     // a full-size grid of blocks that leave at once, two events and a stream hop bought nothing, every step.  The bounds
     // kernel reports the range whether or not a launch used it, so the launch comes back one step after the range does.
     const bool early_empty = s->early_span_known && s->early_span == 0u;
     if (deep_valid && s->early_force && s->world > 1 && c->grid.zl >= 2u * G + 11u && !early_empty) {          // (no neighbour, no latency to fill)
         if (s->early_own_stream && s->early) {
-            SPH_HIP(hipEventRecord(s->ev_early_go, c->stream));             // behind the deep density
-            SPH_HIP(hipStreamWaitEvent(s->early, s->ev_early_go, 0));
+            uint32_t go;                                                    // behind the deep density
+            rc = hop_mark(s, HOP_MAIN_EARLY, c->stream, s->ev_early_go, &go); if (rc) return rc;
+            rc = hop_wait(s, HOP_MAIN_EARLY, s->early, s->ev_early_go, go); if (rc) return rc;
             hipStream_t saved = c->stream;
             c->stream = s->early;
             { PhaseTimer t(c, SPH_PH_FORCE); rc = launch_force_dev_range(c, s->d_lb + DL_EARLY, early_grid_slots, dt); }
             c->stream = saved;
             if (rc) return rc;
-            SPH_HIP(hipEventRecord(s->ev_early_done, s->early));
+            rc = hop_mark(s, HOP_EARLY_MAIN, s->early, s->ev_early_done, &early_done_v); if (rc) return rc;
             early_pending = true;
         } else {
             PhaseTimer t(c, SPH_PH_FORCE);
@@ -1179,13 +1213,13 @@ int slab_step_body(sph_slab* s, float dt) {
     }
     // whoever re-sorts or re-writes the ping-pong arrays on the main stream must come behind the early launch
     auto join_early = [&]() -> int {
-        if (early_pending) { SPH_HIP(hipStreamWaitEvent(c->stream, s->ev_early_done, 0)); early_pending = false; }
+        if (early_pending) { const int rj = hop_wait(s, HOP_EARLY_MAIN, c->stream, s->ev_early_done, early_done_v); if (rj) return rj; early_pending = false; }
         return SPH_OK;
     };
     struct JoinOnExit {                  // (an error return leaves the step half done: the next sort must still come behind the launch)
-        sph_slab* s; bool* pending;
-        ~JoinOnExit() { if (*pending) hipStreamWaitEvent(s->c->stream, s->ev_early_done, 0); }
-    } join_on_exit{s, &early_pending};
+        sph_slab* s; bool* pending; uint32_t* value;
+        ~JoinOnExit() { if (*pending) (void)hop_wait(s, HOP_EARLY_MAIN, s->c->stream, s->ev_early_done, *value); }
+    } join_on_exit{s, &early_pending, &early_done_v};
     const uint32_t inl = min(MIG_INLINE, s->mcap);
     const size_t mig_bytes = (size_t)(1 + inl) * rec;
     s->pg.mig_posted = true;                                    // (also when the call fails: the transport is dead then)
@@ -1445,7 +1479,8 @@ int slab_step_body(sph_slab* s, float dt) {
     // three 2-rank rehearsals of round 3: the high-priority comm stream overtook a deep launch that queued behind
     // another rank's kernels.)
     const bool need_deep_event = early_halo && !(a <= near_lo && b >= near_hi);
-    if (need_deep_event) SPH_HIP(hipEventRecord(s->ev_deep, c->stream));
+    uint32_t deep_v = 0u;
+    if (need_deep_event) { rc = hop_mark(s, HOP_DEEP, c->stream, s->ev_deep, &deep_v); if (rc) return rc; }
     // the slots the non-deep density launches cover: the owned range -- and, in the one-message step, the inner ghost layers
     // on either side (what HALO B carries in the three-group step), rounded down to a whole 64-slot chunk in front so that the
     // hole these launches leave for the deep range stays on the chunk boundaries the deep launch used; the few slots of the
@@ -1578,7 +1613,7 @@ int slab_step_body(sph_slab* s, float dt) {
     // the boundary layers' force pass: on the comm stream, behind the ghosts' (rho, p) -- beside the interior launch
     // (it reads what that one reads and writes other slots of the ping-pong arrays), not behind it
     {
-        if (need_deep_event) SPH_HIP(hipStreamWaitEvent(s->comm, s->ev_deep, 0));  // (non-early: ev_main above covers the densities)
+        if (need_deep_event) { rc = hop_wait(s, HOP_DEEP, s->comm, s->ev_deep, deep_v); if (rc) return rc; }  // (non-early: ev_main above covers the densities)
         OnComm on(s);
         PhaseTimer t(c, SPH_PH_FORCE);
         rc = launch_force_hole(c, c->own_off, c->own_off + n, a, b, true, true, true, dt, mark);
@@ -1898,6 +1933,20 @@ int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph
                  hipHostMalloc((void**)&s->stage_recv[k], s->stage_bytes) == hipSuccess;
     }
     if (!ok) { set_error("sph_slab_create: allocation failed"); slab_free(s); return SPH_E_NOMEM; }
+    {   // cross-stream edges by write / wait value where that works on this device (see hop_mem)
+        const char* e = getenv("SPH_SLAB_HOPS");
+        int can = 0;
+        if (!(e && e[0] == 'e') && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) == hipSuccess && can &&
+            hipMalloc((void**)&s->hop_mem, 5 * 16 * sizeof(uint32_t)) == hipSuccess && hipMemset(s->hop_mem, 0, 5 * 16 * sizeof(uint32_t)) == hipSuccess &&
+            hipDeviceSynchronize() == hipSuccess) {
+            // one pair each way, waited for here: a runtime that accepts the calls but cannot serve them must not be found out mid-step
+            s->hops_by_value = true;
+            const bool fine = after_main(s) == SPH_OK && after_comm(s) == SPH_OK && hipStreamSynchronize(s->comm) == hipSuccess &&
+                              hipStreamSynchronize(ctx->stream) == hipSuccess;
+            if (!fine) { s->hops_by_value = false; (void)hipGetLastError(); }
+        }
+        if (!s->hops_by_value && s->hop_mem) { hipFree(s->hop_mem); s->hop_mem = nullptr; }
+    }
     for (int k = 0; k < HL_WORDS; k++) s->h_lb[k] = 0u;
     ctx->host_paced = true;            // sph_slab_step waits for the device once per step
     *out = s;
