@@ -2,6 +2,9 @@
 # Kernel trace of ONE slab between its periodic images (a middle rank's whole step), early force off and on:
 #   bash profiles/collect_periodic_trace.sh [tag] [latency_us] [gbs]
 set -e
+# kernel traces are taken with EVENT hops: the product's write / wait-value hops are spinning one-workgroup kernels of the runtime
+# (__amd_rocclr_streamOpsWait), which a kernel trace counts as device-busy time and which rocprofv3's own serialisation slows down
+export SPH_SLAB_HOPS=event
 TAG=${1:-r05}; LAT=${2:-0}; GBS=${3:-0}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for EF in off on; do

@@ -5,6 +5,9 @@
 # (bench.py --force-slab --lattice 256,256,32: the slab step of ONE slab with no neighbours -- sort chain, bounds, split density, force, the
 # host wait of the real step, no transfers) and summarises the timed window with profiles/step_trace_summary.py.
 set -e
+# kernel traces are taken with EVENT hops: the product's write / wait-value hops are spinning one-workgroup kernels of the runtime
+# (__amd_rocclr_streamOpsWait), which a kernel trace counts as device-busy time and which rocprofv3's own serialisation slows down
+export SPH_SLAB_HOPS=event
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_slab8; rm -rf $OUT; mkdir -p $OUT
