@@ -377,7 +377,10 @@ void sph_local_transport_destroy(sph_transport* t);
 typedef struct sph_slab sph_slab;
 /* Bind a slab context (sph_create_slab, particles uploaded) to its place in the chain of `world` slabs.  The halo
  * capacity is the context's ghost capacity; migrant_capacity (records per side and step, 0 = half the ghost capacity)
- * bounds the leavers / arrivals of one step and side (only 255 of them ride in the fixed-size message of every step).  The transport struct is copied. */
+ * bounds the leavers / arrivals of one step and side (only 255 of them ride in the fixed-size message of every step).  The transport struct is copied.
+ * The step orders its streams by sequence numbers (hipStreamWriteValue32 / hipStreamWaitValue32 on a word of device memory) where the
+ * device serves that pair -- tried once here, with both streams drained -- and by events otherwise; SPH_SLAB_HOPS=event in the
+ * environment forces events (A/B runs, kernel traces: the runtime's wait is a spinning one-workgroup kernel). */
 int sph_slab_create(sph_slab** out, sph_ctx* ctx, int rank, int world, const sph_transport* transport,
                     uint32_t migrant_capacity);
 void sph_slab_destroy(sph_slab* s);
