@@ -696,11 +696,12 @@ class NativeSlabSimulation(SlabSimulation):
     call into libsph_hip.so per rank: sph_slab_step queues sort, migrants, halo A, density, halo B and the fused
     force pass on two HIP streams and waits for the device once (csrc/sph_slab.hip)."""
 
-    # the early force launch (sph_slab_set_early_force) costs ~3 us per step when a message group takes less than this on an
+    # the early force launch (sph_slab_set_early_force) costs 5-12 us per step when a message group takes less than this on an
     # idle device (the preflight ping of the 8 KB migrant message) and wins beyond it: measured on a slab between its periodic
-    # images, DESIGN.md section 6.  "auto" switches it off only for such links.
-    EARLY_FORCE_MIN_PING_US = 12.0
-    EARLY_FORCE_MIN_HALO_PING_US = 45.0      # ... unless a halo-A-sized message takes more than this (a slow link rather than a late one)
+    # images with the round's last code (DESIGN.md section 6, profiles/r06d_periodic_slab_protocols.txt: at 20 us per group --
+    # a ping of 28 -- still 5 us slower sustained, at 40 us -- a ping of 48 -- 30 us faster).  "auto" switches it off for such links.
+    EARLY_FORCE_MIN_PING_US = 32.0
+    EARLY_FORCE_MIN_HALO_PING_US = 75.0      # ... unless a halo-A-sized message takes more than this (a slow link rather than a late one: 10 us + 75 GB/s is level)
     # ... and off again when the slab is so big that the deep density launch (queued in front of the wait anyway) outlasts the
     # two messages on the path: ~half a slab's particles are "deep", k_density does ~18,800 of them per us (C3, flowing).  A
     # 16.7 M-particle slab (config 5's rank) behind a 10 us / 153 GB/s link: 3.71 ms per step without, 3.85 with it.

@@ -260,8 +260,10 @@ def test_early_force_rule_follows_the_measured_crossovers():
     rule = slab.NativeSlabSimulation.early_force_rule
     n8 = 2097152                                    # an eighth of config 3
     assert rule(16.0, 16.0, n8)[0] is False         # device copies only: +6 us per step with it
-    assert rule(19.0, 47.0, n8)[0] is True          # 10 us + 153 GB/s: break-even, on
+    assert rule(19.0, 47.0, n8)[0] is False         # 10 us + 153 GB/s: 7 us per step slower with it (round 6's last table)
+    assert rule(28.0, 57.0, n8)[0] is False         # 20 us per group: still 5 us slower
     assert rule(48.0, 79.0, n8)[0] is True          # 40 us per group: -30 us per step
+    assert rule(17.0, 74.0, n8)[0] is False         # 10 us + 75 GB/s: level
     assert rule(5.0, 130.0, n8)[0] is True          # a slow link rather than a late one
     assert rule(22.0, 147.0, 16777216)[0] is False  # a config-5 rank: its deep density launch outlasts the messages
     assert rule(91.0, 214.0, 16777216)[0] is False
